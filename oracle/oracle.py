@@ -1,0 +1,349 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/mppi_oracle.c).
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import this module. Nothing under mppi-tf_amd/ does.
+
+The arithmetic lives in C (each C function cites the reference file:line it restates); this
+file only marshals numpy arrays.  `dtype` selects the fp32 (parity target, C++ reference is
+DT_FLOAT) or fp64 (Python reference / truth bound) instantiation.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmppi_oracle.so")
+
+MAX_LAYERS = 8
+ACTION_COST_CPP, ACTION_COST_PY = 0, 1
+MODEL_POINT_MASS, MODEL_MLP = 0, 1
+
+
+def build(force=False):
+    """Compile the oracle with gcc (recipe: oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in
+            ("mppi_oracle.c", "mppi_oracle_impl.inc", "mppi_oracle_decl.inc", "mppi_oracle.h", "Makefile")]
+    if (not force and os.path.exists(_SO)
+            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libmppi_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def _structs(real):
+    P = C.POINTER(real)
+
+    class Cost(C.Structure):
+        _fields_ = [("s", C.c_int), ("a", C.c_int), ("action_cost_kind", C.c_int),
+                    ("lam", real), ("gamma", real), ("upsilon", real),
+                    ("goal", P), ("Q", P), ("sigma_inv", P)]
+
+    class Mlp(C.Structure):
+        _fields_ = [("s", C.c_int), ("a", C.c_int), ("n_layers", C.c_int),
+                    ("widths", C.c_int * MAX_LAYERS),
+                    ("W", P * MAX_LAYERS), ("b", P * MAX_LAYERS),
+                    ("xmean", P), ("xstd", P), ("ymean", P), ("ystd", P)]
+
+    class Problem(C.Structure):
+        _fields_ = [("cost", Cost), ("tau", C.c_int), ("model_kind", C.c_int),
+                    ("threads", C.c_int), ("A", P), ("B", P), ("mlp", Mlp)]
+
+    return Cost, Mlp, Problem
+
+
+class _Inst:
+    """One precision instantiation of the C oracle."""
+
+    def __init__(self, lib, suffix, real, npdt):
+        self.lib, self.suffix, self.real, self.npdt = lib, suffix, real, np.dtype(npdt)
+        self.P = C.POINTER(real)
+        self.Cost, self.Mlp, self.Problem = _structs(real)
+
+    def fn(self, name, restype=None):
+        f = getattr(self.lib, name + self.suffix)
+        f.restype = restype
+        return f
+
+    def arr(self, x, shape=None):
+        a = np.ascontiguousarray(np.asarray(x, dtype=self.npdt))
+        if shape is not None:
+            a = a.reshape(shape)
+        return a
+
+    def ptr(self, a):
+        return a.ctypes.data_as(self.P) if a is not None else None
+
+
+_lib = None
+_insts = {}
+
+
+def _get(dtype):
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+    key = np.dtype(dtype).name
+    if key not in _insts:
+        if key == "float32":
+            _insts[key] = _Inst(_lib, "_f32", C.c_float, np.float32)
+        elif key == "float64":
+            _insts[key] = _Inst(_lib, "_f64", C.c_double, np.float64)
+        else:
+            raise ValueError(dtype)
+    return _insts[key]
+
+
+def num_threads():
+    _get(np.float32)
+    _lib.orc_num_threads.restype = C.c_int
+    return int(_lib.orc_num_threads())
+
+
+# --------------------------------------------------------------------------- model (A4)
+def block_diag(mat, nb, dtype=np.float32):
+    I = _get(dtype)
+    m = I.arr(mat)
+    r, c = m.shape
+    out = np.zeros((nb * r, nb * c), I.npdt)
+    I.fn("orc_block_diag")(I.ptr(m), r, c, nb, I.ptr(out))
+    return out
+
+
+def pm_matrices(dt, mass, s, a, dtype=np.float32):
+    I = _get(dtype)
+    A = np.zeros((s, s), I.npdt)
+    B = np.zeros((s, a), I.npdt)
+    I.fn("orc_pm_matrices")(I.real(dt), I.real(mass), s, a, I.ptr(A), I.ptr(B))
+    return A, B
+
+
+def model_free_step(A, x, dtype=np.float32):
+    I = _get(dtype)
+    A = I.arr(A)
+    s = A.shape[0]
+    x = I.arr(x, (-1, s))
+    out = np.zeros_like(x)
+    I.fn("orc_model_free_step")(I.ptr(A), s, I.ptr(x), x.shape[0], I.ptr(out))
+    return out
+
+
+def model_action_step(B, v, dtype=np.float32):
+    I = _get(dtype)
+    B = I.arr(B)
+    s, a = B.shape
+    v = I.arr(v, (-1, a))
+    out = np.zeros((v.shape[0], s), I.npdt)
+    I.fn("orc_model_action_step")(I.ptr(B), s, a, I.ptr(v), v.shape[0], I.ptr(out))
+    return out
+
+
+def model_step(A, B, x, v, dtype=np.float32):
+    I = _get(dtype)
+    A, B = I.arr(A), I.arr(B)
+    s, a = B.shape
+    x, v = I.arr(x, (-1, s)), I.arr(v, (-1, a))
+    out = np.zeros((v.shape[0], s), I.npdt)
+    I.fn("orc_model_step")(I.ptr(A), I.ptr(B), s, a, I.ptr(x), x.shape[0], I.ptr(v), v.shape[0], I.ptr(out))
+    return out
+
+
+# --------------------------------------------------------------------------- cost (A5-A7)
+def mat_inverse(S, dtype=np.float32):
+    I = _get(dtype)
+    S = I.arr(S)
+    n = S.shape[0]
+    out = np.zeros_like(S)
+    rc = I.fn("orc_mat_inverse", C.c_int)(I.ptr(S), n, I.ptr(out))
+    if rc:
+        raise np.linalg.LinAlgError("singular sigma")
+    return out
+
+
+def _q_full(I, Q, s):
+    Q = I.arr(Q)
+    if Q.ndim == 1:  # Diag(in_Q), cost_base.cpp:40
+        Q = I.arr(np.diag(Q))
+    assert Q.shape == (s, s)
+    return Q
+
+
+class Problem:
+    """Holds the numpy buffers + the C struct of one oracle problem instance."""
+
+    def __init__(self, tau, s, a, dt=0.1, mass=1.0, lam=1.0, sigma=None, goal=None, Q=None,
+                 gamma=1.0, upsilon=1.0, action_cost=ACTION_COST_CPP, mlp=None, threads=1,
+                 dtype=np.float32):
+        I = self.I = _get(dtype)
+        self.tau, self.s, self.a = tau, s, a
+        self.sigma = I.arr(np.eye(a) if sigma is None else sigma, (a, a))
+        self.sigma_inv = mat_inverse(self.sigma, dtype)
+        if goal is None:  # controller_base.cpp:43-46: (1,0) per axis
+            goal = np.tile([1.0, 0.0], s // 2)
+        self.goal = I.arr(goal, (s,))
+        self.Q = _q_full(I, np.ones(s) if Q is None else Q, s)
+        self.lam = float(lam)
+        p = self.c = I.Problem()
+        p.cost.s, p.cost.a, p.cost.action_cost_kind = s, a, action_cost
+        p.cost.lam, p.cost.gamma, p.cost.upsilon = lam, gamma, upsilon
+        p.cost.goal, p.cost.Q, p.cost.sigma_inv = I.ptr(self.goal), I.ptr(self.Q), I.ptr(self.sigma_inv)
+        p.tau, p.threads = tau, threads
+        self._keep = []
+        if mlp is None:
+            p.model_kind = MODEL_POINT_MASS
+            self.A, self.B = pm_matrices(dt, mass, s, a, dtype)
+            p.A, p.B = I.ptr(self.A), I.ptr(self.B)
+        else:
+            p.model_kind = MODEL_MLP
+            self._fill_mlp(p.mlp, mlp)
+
+    def _fill_mlp(self, m, mlp):
+        I = self.I
+        Ws, bs = mlp["W"], mlp["b"]
+        m.s, m.a, m.n_layers = self.s, self.a, len(Ws)
+        for l, (W, b) in enumerate(zip(Ws, bs)):
+            W, b = I.arr(W), I.arr(b)
+            self._keep += [W, b]
+            m.widths[l] = W.shape[1]
+            m.W[l], m.b[l] = I.ptr(W), I.ptr(b)
+        n_in = self.s + self.a
+        for name, default, n in (("xmean", 0.0, n_in), ("xstd", 1.0, n_in),
+                                 ("ymean", 0.0, self.s), ("ystd", 1.0, self.s)):
+            v = I.arr(mlp.get(name, np.full(n, default)), (n,))
+            self._keep.append(v)
+            setattr(m, name, I.ptr(v))
+
+    # A5
+    def state_cost(self, x):
+        I = self.I
+        x = I.arr(x, (-1, self.s))
+        out = np.zeros(x.shape[0], I.npdt)
+        I.fn("orc_final_cost")(C.byref(self.c.cost), I.ptr(x), x.shape[0], I.ptr(out))
+        return out
+
+    # A6
+    def action_cost(self, u, eps):
+        I = self.I
+        u, eps = I.arr(u, (self.a,)), I.arr(eps, (-1, self.a))
+        if self.c.cost.action_cost_kind == ACTION_COST_PY:
+            f = I.fn("orc_action_cost_py", I.real)
+            return np.array([f(I.ptr(u), I.ptr(e), I.ptr(self.sigma_inv), self.a, I.real(self.c.cost.lam),
+                               I.real(self.c.cost.gamma), I.real(self.c.cost.upsilon)) for e in eps], I.npdt)
+        f = I.fn("orc_action_cost_cpp", I.real)
+        return np.array([f(I.ptr(u), I.ptr(e), I.ptr(self.sigma_inv), self.a, I.real(self.c.cost.lam))
+                         for e in eps], I.npdt)
+
+    # A7 (one step)
+    def step_cost(self, x, u, eps):
+        I = self.I
+        x, u, eps = I.arr(x, (-1, self.s)), I.arr(u, (self.a,)), I.arr(eps, (-1, self.a))
+        out = np.zeros(x.shape[0], I.npdt)
+        I.fn("orc_step_cost")(C.byref(self.c.cost), I.ptr(x), I.ptr(u), I.ptr(eps), x.shape[0], I.ptr(out))
+        return out
+
+    def mlp_step(self, x, v):
+        I = self.I
+        x, v = I.arr(x, (self.s,)), I.arr(v, (self.a,))
+        out = np.zeros(self.s, I.npdt)
+        I.fn("orc_mlp_step")(C.byref(self.c.mlp), I.ptr(x), I.ptr(v), I.ptr(out))
+        return out
+
+    # A7 (full recurrence)
+    def rollout_cost(self, x0, U, eps, traj=False):
+        I = self.I
+        x0, U = I.arr(x0, (self.s,)), I.arr(U, (self.tau, self.a))
+        eps = I.arr(eps, (-1, self.tau, self.a))
+        k = eps.shape[0]
+        out = np.zeros(k, I.npdt)
+        tr = np.zeros((k, self.tau, self.s), I.npdt) if traj else None
+        I.fn("orc_rollout_cost")(C.byref(self.c), I.ptr(x0), I.ptr(U), I.ptr(eps), k, I.ptr(out), I.ptr(tr))
+        return (out, tr) if traj else out
+
+    # A1 with injected noise; returns (u, U_next, cost)
+    def next_with_noise(self, x, U, eps, normalize=False):
+        I = self.I
+        x, U = I.arr(x, (self.s,)), I.arr(U, (self.tau, self.a)).copy()
+        eps = I.arr(eps, (-1, self.tau, self.a))
+        k = eps.shape[0]
+        u = np.zeros(self.a, I.npdt)
+        c = np.zeros(k, I.npdt)
+        I.fn("orc_next_with_noise")(C.byref(self.c), I.ptr(x), I.ptr(U), I.ptr(eps), k, int(normalize),
+                                    I.ptr(u), I.ptr(c))
+        return u, U, c
+
+
+# --------------------------------------------------------------------------- update (A8-A10)
+def update(cost, eps, U, lam, normalize=False, acc_double=True, dtype=np.float32):
+    """Returns dict(beta, arg, exp, nabla, w, wn, Unew)."""
+    I = _get(dtype)
+    cost = I.arr(cost, (-1,))
+    k = cost.shape[0]
+    U = I.arr(U)
+    tau, a = U.shape
+    eps = I.arr(eps, (k, tau, a))
+    beta, nabla = np.zeros(1, I.npdt), np.zeros(1, I.npdt)
+    arg, e, w = (np.zeros(k, I.npdt) for _ in range(3))
+    wn, Un = np.zeros((tau, a), I.npdt), np.zeros((tau, a), I.npdt)
+    I.fn("orc_update")(I.ptr(cost), I.ptr(eps), I.ptr(U), I.real(lam), k, tau, a, int(normalize),
+                       int(acc_double), I.ptr(beta), I.ptr(arg), I.ptr(e), I.ptr(nabla), I.ptr(w),
+                       I.ptr(wn), I.ptr(Un))
+    return dict(beta=beta[0], arg=arg, exp=e, nabla=nabla[0], w=w, wn=wn, Unew=Un)
+
+
+def get_new(U, nb, dtype=np.float32):
+    I = _get(dtype)
+    U = I.arr(U)
+    tau, a = U.shape
+    out = np.zeros((nb, a), I.npdt)
+    I.fn("orc_get_new")(I.ptr(U), tau, a, nb, I.ptr(out))
+    return out
+
+
+def shift(U, init, nb, dtype=np.float32):
+    I = _get(dtype)
+    U = I.arr(U)
+    tau, a = U.shape
+    init = I.arr(init, (-1, a))
+    out = np.zeros((tau - nb + init.shape[0], a), I.npdt)
+    I.fn("orc_shift")(I.ptr(U), tau, a, I.ptr(init), init.shape[0], nb, I.ptr(out))
+    return out
+
+
+def combine_records(rec, U, lam, dtype=np.float32):
+    I = _get(dtype)
+    U = I.arr(U)
+    tau, a = U.shape
+    rec = I.arr(rec, (-1, 2 + tau * a))
+    out = np.zeros((tau, a), I.npdt)
+    I.fn("orc_combine_records")(I.ptr(rec), rec.shape[0], I.ptr(U), I.real(lam), tau, a, I.ptr(out))
+    return out
+
+
+# --------------------------------------------------------------------------- noise (A2)
+def philox4x32_10(ctr, key):
+    _get(np.float32)
+    c = (C.c_uint32 * 4)(*[int(v) for v in ctr])
+    k = (C.c_uint32 * 2)(*[int(v) for v in key])
+    o = (C.c_uint32 * 4)()
+    _lib.orc_philox4x32_10(c, k, o)
+    return [int(v) for v in o]
+
+
+def normals(seed, step, k_offset, k, tau, a):
+    _get(np.float32)
+    out = np.zeros((k, tau, a), np.float32)
+    _lib.orc_normals(C.c_uint64(seed), C.c_uint64(step), C.c_uint64(k_offset), k, tau, a,
+                     out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def noise(seed, step, k_offset, k, tau, a, sigma):
+    _get(np.float32)
+    sigma = np.ascontiguousarray(np.asarray(sigma, np.float32).reshape(a, a))
+    out = np.zeros((k, tau, a), np.float32)
+    _lib.orc_noise(C.c_uint64(seed), C.c_uint64(step), C.c_uint64(k_offset), k, tau, a,
+                   sigma.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out

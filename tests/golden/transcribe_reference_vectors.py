@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/*.json — the reference's own known-answer vectors, as DATA.
+
+Every number below was transcribed by hand from the literals in the reference's unit tests
+(read as text; the reference cannot be compiled or imported here — SURVEY.md §8c):
+  C++  test/test_controller.cpp, test/test_cost.cpp, test/test_model.cpp, test/test_utile.cpp
+  Py   scripts/test.py (TestPointMassModel, TestCost, TestStaticCost, TestController)
+Where the reference test spells an expectation as an arithmetic expression of literals
+(e.g. `(dt*dt)/(2.f*m)`), the same expression is evaluated here in the same precision
+(np.float32 for the C++ tests, python float = fp64 for scripts/test.py) and the RESULT is stored.
+No reference source text is kept; only inputs and expected outputs.
+
+Run:  python tests/golden/transcribe_reference_vectors.py      (idempotent)
+"""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+f32 = np.float32
+
+
+def dump(name, obj):
+    def conv(o):
+        if isinstance(o, np.ndarray):
+            return o.tolist()
+        if isinstance(o, (np.floating,)):
+            return float(o)
+        if isinstance(o, (np.integer,)):
+            return int(o)
+        if isinstance(o, dict):
+            return {k: conv(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [conv(v) for v in o]
+        return o
+    with open(os.path.join(HERE, name + ".json"), "w") as fh:
+        json.dump(conv(obj), fh, indent=1, sort_keys=True)
+        fh.write("\n")
+
+
+# ------------------------------------------------------------------ controller (A3, A8-A10)
+# test_controller.cpp:18-31 fixture (k=5, tau=3, a_dim=2); scripts/test.py:1377-1388 identical.
+COST = [3., 10., 0., 1., 5.]
+NOISE = [[[1., -0.5], [1., -0.5], [2., 1.]],
+         [[0.3, 0.], [2., 0.2], [1.2, 3.]],
+         [[0.5, 0.5], [0.5, 0.5], [0.5, 0.5]],
+         [[0.6, 0.7], [0.2, -0.3], [0.1, -0.4]],
+         [[-2., -3.], [-4., -1.], [0., 0.]]]
+ACTION = [[1., 0.5], [2.3, 4.5], [2.1, -0.4]]
+
+
+def controller():
+    # test_controller.cpp:109-167 testUpdate / scripts/test.py:1427-1468
+    w = [0.034951787275480706, 3.1871904480408675e-05, 0.7020254138530686,
+         0.2582607169364174, 0.004730210030553017]
+    n = np.array(NOISE)
+    wn = [[sum(w[k] * n[k, t, a] for k in range(5)) for a in range(2)] for t in range(3)]
+    dump("controller_update_k5_tau3_a2", dict(
+        source="test/test_controller.cpp:24-31,109-167; scripts/test.py:1377-1388,1427-1468",
+        tol="EXPECT_FLOAT_EQ (4 ulp fp32) / assertAllClose rtol=atol=1e-6",
+        k=5, tau=3, a=2, lam=1.0, cost=COST, noise=NOISE, action=ACTION,
+        beta=0.0, exp_arg=[-3., -10., 0., -1., -5.],
+        exp=[0.049787068367863944, 4.5399929762484854e-05, 1.0, 0.36787944117144233,
+             0.006737946999085467],
+        nabla=1.424449856468154, weights=w, weighted_noise=wn, sum_weights=1.0))
+    # test_controller.cpp:71-107 testDataPrep / scripts/test.py:1400-1425
+    dump("controller_dataprep", dict(
+        source="test/test_controller.cpp:71-107; scripts/test.py:1400-1425",
+        noise=NOISE, action=ACTION,
+        a=[[1., 0.5], [2.3, 4.5], [2.1, -0.4]],
+        n=[[[1., -0.5], [0.3, 0.], [0.5, 0.5], [0.6, 0.7], [-2., -3.]],
+           [[1., -0.5], [2., 0.2], [0.5, 0.5], [0.2, -0.3], [-4., -1.]],
+           [[2., 1.], [1.2, 3.], [0.5, 0.5], [0.1, -0.4], [0., 0.]]]))
+    # test_controller.cpp:169-193 testNew, :195-222 testShiftAndInit / test.py:1470-1494
+    dump("controller_getnew_shift", dict(
+        source="test/test_controller.cpp:169-222; scripts/test.py:1470-1494",
+        action=ACTION,
+        getnew={"0": [], "1": [[1., 0.5]], "2": [[1., 0.5], [2.3, 4.5]],
+                "3": [[1., 0.5], [2.3, 4.5], [2.1, -0.4]]},
+        shift=[dict(init=[[1., 0.5]], nb=1, expected=[[2.3, 4.5], [2.1, -0.4], [1., 0.5]]),
+               dict(init=[[1., 0.5], [2.3, 4.5]], nb=2,
+                    expected=[[2.1, -0.4], [1., 0.5], [2.3, 4.5]])]))
+
+
+# ------------------------------------------------------------------ cost, C++ form (A5-A7)
+def cost_cpp():
+    # test_cost.cpp:27-114 fixtures, :169-239 expectations. lambda = 1, Q given as a diagonal.
+    sc = [
+        dict(name="s2_a2_k1", s=2, a=2, k=1, lam=1.0,
+             state=[[0., 1.]], goal=[1., 1.], action=[1., 1.], eps=[[1., 1.]],
+             sigma=[[1., 0.], [0., 1.]], q_diag=[1., 1.],
+             exp_state=[1.], exp_step=[3.]),
+        dict(name="s4_a2_k1", s=4, a=2, k=1, lam=1.0,
+             state=[[0., 0.5, 2., 0.]], goal=[1., 1., 1., 2.], action=[0.5, 2.], eps=[[0.5, 1.]],
+             sigma=[[1., 0.], [0., 1.]], q_diag=[1., 1., 10., 10.],
+             exp_state=[51.25], exp_step=[53.5]),
+        dict(name="s4_a3_k5", s=4, a=3, k=5, lam=1.0,
+             state=[[0., 0.5, 2., 0.], [0., 2., 0., 0.], [10., 2., 2., 3.], [1., 1., 1., 2.],
+                    [3., 4., 5., 6.]],
+             goal=[1., 1., 1., 2.], action=[0.5, 2., 0.25],
+             eps=[[0.5, 1., 2.], [0.5, 2., 0.25], [-2., -0.2, -1.], [0., 0., 0.], [1., 0.5, 3.]],
+             sigma=[[1., 0., 0.], [0., 1., 0.], [0., 0., 1.]], q_diag=[1., 1., 10., 10.],
+             exp_state=[51.25, 52., 102., 0., 333.],
+             exp_step=[51.25 + 2.75, 52 + 4.3125, 102 - 1.65, 0. + 0, 333 + 2.25]),
+    ]
+    dump("cost_cpp", dict(source="test/test_cost.cpp:27-114,169-239",
+                          tol="EXPECT_FLOAT_EQ (4 ulp fp32)", scenarios=sc))
+
+
+# ------------------------------------------------------------------ model, C++ (A4) dt=0.01
+STATE3 = [[0., 0., 0., 0., 0., 0.], [2., 1., 5., 0., -1., -2.], [0.5] * 6,
+          [1., 0., 1., 0., 1., 0.], [-1., 0.5, -3., 2., 0., 0.]]
+ACTION3 = [[1., 1., 1.], [2., 0., -1.], [0., 0., 0.], [0.5, -0.5, 0.5], [3., 3., 3.]]
+STATE_INIT = [[-1., 0.5, -3., 2., 0., 0.]]
+U_COEF = [[1., 1., 1.], [2., 0., -1.], [0., 0., 0.], [0.5, -0.5, 0.5], [3., 3., 3.]]
+
+
+def model_cpp():
+    # test_model.cpp:17-75 fixture; :120-255 expectations, evaluated in float like the test.
+    out = []
+
+    def exp_u(m, dt, coef):
+        acc = (f32(dt) * f32(dt)) / (f32(2.) * f32(m))
+        vel = f32(dt) / f32(m)
+        return [[v for c in row for v in (f32(c) * acc, f32(c) * vel)] for row in coef]
+
+    dt = 0.01
+    out.append(dict(name="step1_k1_s2_a1", s=2, a=1, mass=1.0, dt=dt, state=[[0., 0.]],
+                    action=[[1.]], exp_free=[[0., 0.]], exp_action=exp_u(1., dt, [[1.]])))
+    out.append(dict(name="step2_k1_s4_a2", s=4, a=2, mass=2.0, dt=dt, state=[[0.] * 4],
+                    action=[[1., 1.]], exp_free=[[0.] * 4], exp_action=exp_u(2., dt, [[1., 1.]])))
+    d = f32(dt)
+    free3 = [[0.] * 6,
+             [f32(2.) + d, 1., 5., 0., f32(-1.) - f32(2.) * d, -2.],
+             [f32(.5) + d / f32(2.), .5, f32(.5) + d / f32(2.), .5, f32(.5) + d / f32(2.), .5],
+             [1., 0., 1., 0., 1., 0.],
+             [f32(-1.) + d / f32(2.), .5, f32(-3.) + f32(2.) * d, 2., 0., 0.]]
+    out.append(dict(name="large_k5_s6_a3", s=6, a=3, mass=1.5, dt=dt, state=STATE3,
+                    action=ACTION3, exp_free=free3, exp_action=exp_u(1.5, dt, U_COEF)))
+    out.append(dict(name="init_k5_s6_a3", s=6, a=3, mass=1.5, dt=dt, state=STATE_INIT,
+                    action=ACTION3, exp_free=[free3[4]], exp_action=exp_u(1.5, dt, U_COEF)))
+    for sc in out:
+        fr, ac = np.array(sc["exp_free"], f32), np.array(sc["exp_action"], f32)
+        sc["exp_result"] = (ac + fr).astype(f32)  # broadcast when the state has one row
+    dump("model_cpp", dict(source="test/test_model.cpp:17-75,120-255",
+                           tol="EXPECT_FLOAT_EQ (4 ulp fp32)", scenarios=out))
+
+
+# ------------------------------------------------------------------ model, Py (A4) dt=0.1 fp64
+def model_py():
+    # scripts/test.py:43-218 (TestPointMassModel), fp64, assertAllClose 1e-6.
+    dt = 0.1
+    out = []
+
+    def exp_u(m, coef):
+        acc = dt * dt / (2. * m)
+        vel = dt / m
+        return [[v for c in row for v in (c * acc, c * vel)] for row in coef]
+
+    out.append(dict(name="step1_k1_s2_a1_m1", s=2, a=1, mass=1.0, dt=dt, state=[[0., 0.]],
+                    action=[[1.]], exp_free=[[0., 0.]], exp_action=exp_u(1., [[1.]])))
+    out.append(dict(name="step1_k1_s4_a2_m1", s=4, a=2, mass=1.0, dt=dt, state=[[0.] * 4],
+                    action=[[1., 1.]], exp_free=[[0.] * 4], exp_action=exp_u(1., [[1., 1.]])))
+    free3 = [[0.] * 6,
+             [2. + dt, 1., 5., 0., -1. - 2. * dt, -2.],
+             [.5 + .5 * dt, .5, .5 + .5 * dt, .5, .5 + .5 * dt, .5],
+             [1., 0., 1., 0., 1., 0.],
+             [-1. + .5 * dt, .5, -3. + 2. * dt, 2., 0., 0.]]
+    out.append(dict(name="step1_k5_s6_a3_m1d5", s=6, a=3, mass=1.5, dt=dt, state=STATE3,
+                    action=ACTION3, exp_free=free3, exp_action=exp_u(1.5, U_COEF)))
+    out.append(dict(name="init_k5_s6_a3_m1d5", s=6, a=3, mass=1.5, dt=dt, state=STATE_INIT,
+                    action=ACTION3, exp_free=[free3[4]], exp_action=exp_u(1.5, U_COEF)))
+    for sc in out:
+        sc["exp_result"] = (np.array(sc["exp_action"]) + np.array(sc["exp_free"]))
+    # scripts/test.py:173-218 test_step3: three consecutive steps with the same action.
+    m = 1.5
+    acc, vel = dt * dt / (2. * m), dt / m
+    Bu = [[v for c in row for v in (c * 3 * (acc + vel * dt), c * vel * 3)] for row in U_COEF]
+    ex = [[0.] * 6,
+          [2. + dt * 3, 1., 5., 0., -1. - 2. * dt * 3, -2.],
+          [.5 + .5 * dt * 3, .5, .5 + .5 * dt * 3, .5, .5 + .5 * dt * 3, .5],
+          [1., 0., 1., 0., 1., 0.],
+          [-1. + .5 * dt * 3, .5, -3. + 2. * dt * 3, 2., 0., 0.]]
+    step3 = dict(name="step3_k5_s6_a3_m1d5", s=6, a=3, mass=m, dt=dt, state=STATE3,
+                 action=ACTION3, n_steps=3, exp_result=(np.array(Bu) + np.array(ex)))
+    dump("model_py", dict(source="scripts/test.py:43-218", tol="assertAllClose rtol=atol=1e-6",
+                          scenarios=out, step3=step3))
+
+
+# ------------------------------------------------------------------ blockDiag (A4 layout)
+def blockdiag():
+    # test_utile.cpp:15-27 fixture (m=1.5, dt=0.01), :63-173 expectations.
+    m, dt = f32(1.5), f32(0.01)
+    A = [[f32(1.), dt], [f32(0.), f32(1.)]]
+    B = [[(dt * dt) / (f32(2.) * m)], [dt / m]]
+    cases = []
+    for n in (1, 2, 3, 4):
+        ea = np.zeros((2 * n, 2 * n), f32)
+        eb = np.zeros((2 * n, n), f32)
+        for b in range(n):
+            ea[2 * b:2 * b + 2, 2 * b:2 * b + 2] = A
+            eb[2 * b:2 * b + 2, b:b + 1] = B
+        cases.append(dict(n=n, exp_a=ea, exp_b=eb))
+    dump("blockdiag", dict(source="test/test_utile.cpp:15-27,63-173", A=np.array(A, f32),
+                           B=np.array(B, f32), cases=cases))
+
+
+# ------------------------------------------------------------------ cost, Py γ/υ form (A5-A7)
+def cost_py():
+    S4 = [[0., 0.5, 2., 0.], [0., 2., 0., 0.], [10., 2., 2., 3.], [1., 1., 1., 2.], [3., 4., 5., 6.]]
+    E3 = [[0.5, 1., 2.], [0.5, 2., 0.25], [-2., -0.2, -1.], [0., 0., 0.], [1., 0.5, 3.]]
+    I2, I3 = np.eye(2).tolist(), np.eye(3).tolist()
+    Q4 = np.diag([1., 1., 10., 10.]).tolist()
+
+    def ac(gamma, lam, ups, aa, mix, nn, ups_form="inv"):
+        # TestCost spells λ(1-1/υ); TestStaticCost's first three spell λ(1-υ) (same at υ=1).
+        f = (1 - 1. / ups) if ups_form == "inv" else (1 - ups)
+        return [0.5 * (gamma * (aa + 2. * m) + lam * f * n) for m, n in zip(mix, nn)]
+
+    mix3, nn3 = [2.75, 4.3125, -1.65, 0., 2.25], [5.25, 4.3125, 5.04, 0., 10.25]
+    base = []
+    # scripts/test.py:689-838 TestCost (CostBase.action_cost only)
+    base.append(dict(name="s2_a2_l1", a=2, lam=1., gamma=1., upsilon=1., sigma=I2,
+                     action=[1., 1.], noise=[[1., 1.]], exp_action=ac(1., 1., 1., 2., [2.], [0.])))
+    base.append(dict(name="s4_a2_l1", a=2, lam=1., gamma=1., upsilon=1., sigma=I2,
+                     action=[0.5, 2.], noise=[[0.5, 1.]], exp_action=ac(1., 1., 1., 4.25, [2.25], [1.25])))
+    for lam, g, u in ((1., 1., 1.), (10., 2., 3.), (15., 20., 30.)):
+        base.append(dict(name="s4_a3_l%g_g%g_u%g" % (lam, g, u), a=3, lam=lam, gamma=g, upsilon=u,
+                         sigma=I3, action=[0.5, 2., 0.25], noise=E3,
+                         exp_action=ac(g, lam, u, 4.3125, mix3, nn3)))
+    # scripts/test.py:841-1096 TestStaticCost (state + action, Q full matrix)
+    static = []
+    static.append(dict(name="s2_a2_l1", s=2, a=2, lam=1., gamma=1., upsilon=1., sigma=I2,
+                       Q=np.eye(2).tolist(), goal=[1., 1.], state=[[0., 1.]], action=[1., 1.],
+                       noise=[[1., 1.]], exp_action=ac(1., 1., 1., 2., [2.], [0.], "lin"),
+                       exp_state=[1.]))
+    static.append(dict(name="s4_a2_l1", s=4, a=2, lam=1., gamma=1., upsilon=1., sigma=I2, Q=Q4,
+                       goal=[1., 1., 1., 2.], state=[[0., 0.5, 2., 0.]], action=[0.5, 2.],
+                       noise=[[0.5, 1.]], exp_action=ac(1., 1., 1., 4.25, [2.25], [1.25], "lin"),
+                       exp_state=[51.25]))
+    static.append(dict(name="s4_a3_l1", s=4, a=3, lam=1., gamma=1., upsilon=1., sigma=I3, Q=Q4,
+                       goal=[1., 1., 1., 2.], state=S4, action=[0.5, 2., 0.25], noise=E3,
+                       exp_action=ac(1., 1., 1., 4.3125, mix3, nn3, "lin"),
+                       exp_state=[51.25, 52., 102., 0., 333.]))
+    static.append(dict(name="s13_a6_l1", s=13, a=6, lam=1., gamma=1., upsilon=1.,
+                       sigma=np.eye(6).tolist(),
+                       Q=np.diag([1.] * 7 + [10.] * 6).tolist(),
+                       goal=[1., 1., 2., 0., 0., 0., 1., 0., 0., 0., 0., 0., 0.],
+                       state=[[0., 0.5, 2., 0., 0., 0., 1., 1., 2., 3., 4., 5., 6.],
+                              [0., 2., 0., 0., 0.5, 0.5, 0., 4., 5., 6., 1., 2., 3.]],
+                       action=[0.5, 2., 0.25, 4., 1., 1.5],
+                       noise=[[0.5, 1., 2., 3., 4., 5.], [0.5, 2., 0.25, 1.25, 2.5, 0.75]],
+                       exp_action=ac(1., 1., 1., 23.5625, [26.25, 12.9375], [55.25, 12.6875]),
+                       exp_state=[911.25, 917.5]))
+    for sc in static:
+        sc["exp_step"] = (np.array(sc["exp_action"]) + np.array(sc["exp_state"]))
+    dump("cost_py", dict(source="scripts/test.py:685-1096", tol="assertAllClose rtol=atol=1e-6",
+                         action_cost=base, static_cost=static))
+
+
+if __name__ == "__main__":
+    controller()
+    cost_cpp()
+    model_cpp()
+    model_py()
+    blockdiag()
+    cost_py()
+    print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".json")))

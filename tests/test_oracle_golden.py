@@ -1,0 +1,229 @@
+"""Pins the CPU oracle (oracle/) to the reference's own known-answer vectors.
+
+Fixtures: tests/golden/*.json, transcribed from test/test_*.cpp and scripts/test.py
+(see tests/golden/transcribe_reference_vectors.py). Tolerances are the reference's:
+EXPECT_FLOAT_EQ = 4 ulp fp32 for the C++ vectors, assertAllClose(rtol=atol=1e-6) for the
+fp64 Python vectors. CPU-only.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_float_eq, load_golden
+from oracle import oracle as orc
+
+F32, F64 = np.float32, np.float64
+
+
+# ---------------------------------------------------------------- A4 blockDiag / model
+def test_blockdiag_cpp():
+    g = load_golden("blockdiag")
+    for case in g["cases"]:
+        assert_float_eq(orc.block_diag(g["A"], case["n"]), case["exp_a"], what="A n=%d" % case["n"])
+        assert_float_eq(orc.block_diag(g["B"], case["n"]), case["exp_b"], what="B n=%d" % case["n"])
+        assert orc.block_diag(g["A"], case["n"]).shape == (2 * case["n"], 2 * case["n"])
+        assert orc.block_diag(g["B"], case["n"]).shape == (2 * case["n"], case["n"])
+
+
+def test_pm_matrices_match_blockdiag_fixture():
+    g = load_golden("blockdiag")
+    for case in g["cases"]:
+        n = case["n"]
+        A, B = orc.pm_matrices(0.01, 1.5, 2 * n, n)
+        assert_float_eq(A, case["exp_a"], what="A")
+        assert_float_eq(B, case["exp_b"], what="B")
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_model_step_cpp(idx):
+    sc = load_golden("model_cpp")["scenarios"][idx]
+    A, B = orc.pm_matrices(sc["dt"], sc["mass"], sc["s"], sc["a"])
+    free = orc.model_free_step(A, sc["state"])
+    act = orc.model_action_step(B, sc["action"])
+    res = orc.model_step(A, B, sc["state"], sc["action"])
+    assert free.shape == np.asarray(sc["exp_free"]).shape  # [1,s] for the broadcast-init case
+    assert_float_eq(free, sc["exp_free"], what=sc["name"] + " free")
+    assert_float_eq(act, sc["exp_action"], what=sc["name"] + " action")
+    assert_float_eq(res, sc["exp_result"], what=sc["name"] + " result")
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_model_step_py_fp64(idx):
+    sc = load_golden("model_py")["scenarios"][idx]
+    A, B = orc.pm_matrices(sc["dt"], sc["mass"], sc["s"], sc["a"], F64)
+    np.testing.assert_allclose(orc.model_free_step(A, sc["state"], F64), sc["exp_free"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(orc.model_action_step(B, sc["action"], F64), sc["exp_action"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(orc.model_step(A, B, sc["state"], sc["action"], F64), sc["exp_result"],
+                               rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [F32, F64])
+def test_model_three_step_recurrence(dtype):
+    sc = load_golden("model_py")["step3"]
+    A, B = orc.pm_matrices(sc["dt"], sc["mass"], sc["s"], sc["a"], dtype)
+    x = np.asarray(sc["state"])
+    for _ in range(sc["n_steps"]):
+        x = orc.model_step(A, B, x, sc["action"], dtype)
+    np.testing.assert_allclose(x, sc["exp_result"], rtol=1e-6, atol=1e-6)
+
+
+# ---------------------------------------------------------------- A5-A7 cost (C++ form)
+@pytest.mark.parametrize("idx", range(3))
+def test_cost_cpp(idx):
+    sc = load_golden("cost_cpp")["scenarios"][idx]
+    p = orc.Problem(tau=1, s=sc["s"], a=sc["a"], lam=sc["lam"], sigma=sc["sigma"], goal=sc["goal"],
+                    Q=sc["q_diag"], mlp={"W": [np.zeros((sc["s"] + sc["a"], sc["s"]))], "b": [np.zeros(sc["s"])]})
+    assert_float_eq(p.state_cost(sc["state"]), sc["exp_state"], what=sc["name"] + " state")
+    assert_float_eq(p.step_cost(sc["state"], sc["action"], sc["eps"]), sc["exp_step"], what=sc["name"] + " step")
+
+
+# ---------------------------------------------------------------- A5-A7 cost (Python γ/υ form)
+def _py_problem(sc, dtype, s=None):
+    s = s or sc.get("s", 2 * sc["a"])
+    return orc.Problem(tau=1, s=s, a=sc["a"], lam=sc["lam"], gamma=sc["gamma"], upsilon=sc["upsilon"],
+                       sigma=sc["sigma"], goal=sc.get("goal", np.zeros(s)), Q=sc.get("Q", np.eye(s)),
+                       action_cost=orc.ACTION_COST_PY, dtype=dtype,
+                       mlp={"W": [np.zeros((s + sc["a"], s))], "b": [np.zeros(s)]})
+
+
+@pytest.mark.parametrize("idx", range(5))
+@pytest.mark.parametrize("dtype", [F32, F64])
+def test_action_cost_py(idx, dtype):
+    sc = load_golden("cost_py")["action_cost"][idx]
+    p = _py_problem(sc, dtype)
+    tol = 1e-6 if dtype is F64 else 2e-6
+    np.testing.assert_allclose(p.action_cost(sc["action"], sc["noise"]), sc["exp_action"], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("idx", range(4))
+@pytest.mark.parametrize("dtype", [F32, F64])
+def test_static_cost_py(idx, dtype):
+    sc = load_golden("cost_py")["static_cost"][idx]
+    p = _py_problem(sc, dtype)
+    tol = 1e-6 if dtype is F64 else 2e-6
+    np.testing.assert_allclose(p.action_cost(sc["action"], sc["noise"]), sc["exp_action"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(p.state_cost(sc["state"]), sc["exp_state"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(p.step_cost(sc["state"], sc["action"], sc["noise"]), sc["exp_step"], rtol=tol, atol=tol)
+
+
+# ---------------------------------------------------------------- A3 data prep
+def test_dataprep_slicing_is_the_khta_layout():
+    """mPrepareAction/mPrepareNoise (controller_base.cpp:205-213) are U[t] and eps[:,t]; the oracle
+    and the HIP path index the [K,H,a] / [H,a] row-major layout directly."""
+    g = load_golden("controller_dataprep")
+    n, a = np.asarray(g["noise"]), np.asarray(g["action"])
+    for t in range(3):
+        np.testing.assert_array_equal(a[t], g["a"][t])
+        np.testing.assert_array_equal(n[:, t], g["n"][t])
+
+
+# ---------------------------------------------------------------- A8-A9 update chain
+@pytest.mark.parametrize("acc_double", [False, True])
+def test_update_chain_cpp(acc_double):
+    g = load_golden("controller_update_k5_tau3_a2")
+    r = orc.update(g["cost"], g["noise"], g["action"], g["lam"], acc_double=acc_double)
+    assert_float_eq(r["beta"], g["beta"], what="beta")
+    assert_float_eq(r["arg"], g["exp_arg"], what="exp_arg")
+    assert_float_eq(r["exp"], g["exp"], what="exp")
+    assert_float_eq(r["nabla"], g["nabla"], what="nabla")
+    assert_float_eq(r["w"], g["weights"], what="weights")
+    assert_float_eq(r["wn"], g["weighted_noise"], what="weighted noise")
+    assert_float_eq(np.sum(r["w"], dtype=np.float32), g["sum_weights"], what="sum w")
+    assert_float_eq(r["Unew"], np.asarray(g["action"], F32) + np.asarray(g["weighted_noise"], F32), what="U'")
+
+
+def test_update_chain_py_fp64():
+    g = load_golden("controller_update_k5_tau3_a2")
+    r = orc.update(g["cost"], g["noise"], g["action"], g["lam"], dtype=F64)
+    for k_o, k_g in (("beta", "beta"), ("arg", "exp_arg"), ("exp", "exp"), ("nabla", "nabla"),
+                     ("w", "weights"), ("wn", "weighted_noise")):
+        np.testing.assert_allclose(r[k_o], g[k_g], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(r["w"].sum(), 1.0, rtol=1e-6)
+
+
+# ---------------------------------------------------------------- A10 next / shift
+def test_getnew_and_shift():
+    g = load_golden("controller_getnew_shift")
+    for nb, exp in g["getnew"].items():
+        out = orc.get_new(g["action"], int(nb))
+        assert out.shape == (int(nb), 2)
+        assert_float_eq(out, np.asarray(exp, F32).reshape(int(nb), 2), ulps=0)
+    for case in g["shift"]:
+        out = orc.shift(g["action"], case["init"], case["nb"])
+        assert out.shape == (3, 2)
+        assert_float_eq(out, case["expected"], ulps=0)
+
+
+# ---------------------------------------------------------------- self-consistency of the unpinned rows
+def test_rollout_matches_stepwise_composition():
+    """A7 end-to-end has no reference test: check the fused recurrence against the composition of the
+    separately pinned step functions (model step, step cost, final cost) on random inputs."""
+    rng = np.random.default_rng(0)
+    K, H, s, a = 17, 9, 6, 3
+    p = orc.Problem(tau=H, s=s, a=a, dt=0.1, mass=1.5, lam=0.7, sigma=0.25 * np.eye(a),
+                    goal=[1, 0, .5, 0, .75, 0], Q=[1, 2, 3, 4, 5, 6])
+    x0, U = rng.standard_normal(s), rng.standard_normal((H, a))
+    eps = rng.standard_normal((K, H, a)).astype(F32)
+    x = np.tile(np.asarray(x0, F32), (K, 1))
+    c = np.zeros(K, F32)
+    for t in range(H):
+        v = (np.asarray(U[t], F32)[None, :] + eps[:, t]).astype(F32)
+        x = orc.model_step(p.A, p.B, x, v)
+        c = (c + p.step_cost(x, U[t], eps[:, t])).astype(F32)
+    c = (c + p.state_cost(x)).astype(F32)
+    got, traj = p.rollout_cost(x0, U, eps, traj=True)
+    np.testing.assert_array_equal(got, c)
+    np.testing.assert_array_equal(traj[:, -1], x)
+
+
+def test_next_with_noise_is_update_get_shift():
+    rng = np.random.default_rng(1)
+    K, H, s, a = 64, 8, 4, 2
+    p = orc.Problem(tau=H, s=s, a=a)
+    x0, U = rng.standard_normal(s), rng.standard_normal((H, a)).astype(F32)
+    eps = rng.standard_normal((K, H, a)).astype(F32)
+    u, Unext, c = p.next_with_noise(x0, U, eps)
+    r = orc.update(p.rollout_cost(x0, U, eps), eps, U, p.lam)
+    np.testing.assert_array_equal(c, p.rollout_cost(x0, U, eps))
+    np.testing.assert_array_equal(u, r["Unew"][0])
+    np.testing.assert_array_equal(Unext[:-1], r["Unew"][1:])
+    np.testing.assert_array_equal(Unext[-1], 0)
+
+
+def test_combine_records_equals_global_update():
+    """§8e exchange: per-shard (beta_g, eta_g, V_g) records recombine to the unsharded update."""
+    rng = np.random.default_rng(2)
+    K, H, a, lam, G = 96, 5, 3, 0.8, 4
+    cost = (rng.standard_normal(K) * 3 + 10).astype(F32)
+    eps = rng.standard_normal((K, H, a)).astype(F32)
+    U = rng.standard_normal((H, a)).astype(F32)
+    full = orc.update(cost, eps, U, lam)["Unew"]
+    recs = []
+    for g in range(G):
+        sl = slice(g * K // G, (g + 1) * K // G)
+        c64, e64 = cost[sl].astype(F64), eps[sl].astype(F64)
+        b = c64.min()
+        e = np.exp(-(c64 - b) / lam)
+        recs.append(np.concatenate([[b, e.sum()], (e[:, None, None] * e64).sum(0).ravel()]))
+    got = orc.combine_records(np.asarray(recs, F32), U, lam)
+    np.testing.assert_allclose(got, full, rtol=0, atol=2e-6)
+
+
+# ---------------------------------------------------------------- noise stream (A2, unpinned by the reference)
+def test_philox_known_answer_vectors():
+    """Random123's published known-answer tests for philox4x32-10 (kat_vectors)."""
+    assert orc.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_noise_is_shard_invariant_and_standard_normal():
+    z_all = orc.normals(seed=1, step=3, k_offset=0, k=4096, tau=16, a=3)
+    z_lo = orc.normals(seed=1, step=3, k_offset=0, k=2048, tau=16, a=3)
+    z_hi = orc.normals(seed=1, step=3, k_offset=2048, k=2048, tau=16, a=3)
+    np.testing.assert_array_equal(z_all, np.concatenate([z_lo, z_hi]))
+    assert abs(z_all.mean()) < 0.01 and abs(z_all.std() - 1) < 0.01
+    assert not np.array_equal(z_all, orc.normals(1, 4, 0, 4096, 16, 3))
+    sig = np.array([[0.5, 0.1, 0], [0, 0.25, 0], [0.2, 0, 1.0]], F32)
+    e = orc.noise(1, 3, 0, 4096, 16, 3, sig)
+    np.testing.assert_allclose(e, z_all @ sig.T, rtol=1e-6, atol=1e-6)
