@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — rollouts/s of the MPPI control step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is ONE control step of the hot path: K rollouts x H model steps + costs + soft-min update
++ shift, with the state x and the nominal sequence U already resident in HBM and the noise drawn on
+the device (Philox). Workload at N=1: BASELINE configs[2], point_mass3d analytic, K=65536, H=64 —
+the configuration the metric is quoted on. N>1 is WEAK scaling: every rank keeps K=65536 samples of
+a K·N-sample controller, with one all-gather of the (beta, eta, V) record per step (RCCL).
+Rank 0 prints ONE JSON line (value = whole-job rollouts/s, max-over-ranks time).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+K_PER_GPU, H, A = 65536, 64, 3            # BASELINE.json configs[2]
+S = 2 * A
+GOAL = [1.0, 0.0, 0.5, 0.0, 0.75, 0.0]    # MuJoCo target site, zero velocity
+SIGMA = (0.25 * np.eye(A)).astype(np.float32)  # config/envs/point_mass.default.yaml:17-26
+CFG = dict(tau=H, s_dim=S, a_dim=A, dt=0.1, mass=1.0, lam=1.0, sigma=SIGMA, goal=GOAL, seed=1)
+# SURVEY §8d / BASELINE.md §3: algorithmic work per state-step (one (k,t) pair)
+BYTES_PER_STATE_STEP = 12 * A             # noise written once, read twice, fp32
+FLOP_PER_STATE_STEP = 6 * S + 5 * A + 3
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(budget_s=12.0):
+    """The CPU restatement (oracle/, OpenMP over samples) timed on this box's host cores on a bounded
+    sample of the SAME workload: whole control steps (noise + rollouts + update) at K=65536, H=64."""
+    from oracle import oracle as orc
+    p = orc.Problem(tau=H, s=S, a=A, dt=0.1, mass=1.0, lam=1.0, sigma=SIGMA, goal=GOAL, threads=0)
+    x, U = np.zeros(S, np.float32), np.zeros((H, A), np.float32)
+    eps = orc.noise(1, 0, 0, K_PER_GPU, H, A, SIGMA)
+    p.next_with_noise(x, U, eps)  # warm-up (page in, spin up the OpenMP team)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        eps = orc.noise(1, n + 1, 0, K_PER_GPU, H, A, SIGMA)
+        _, U, _ = p.next_with_noise(x, U, eps)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    return {"value": K_PER_GPU * n / el, "unit": "rollouts/s", "cores": orc.num_threads(), "kind": "port",
+            "ms_per_step": 1e3 * el / n,
+            "sample": "%d whole control steps of point_mass3d K=%d H=%d (Philox noise + rollouts + update), "
+                      "OpenMP over samples; the reference itself (TensorFlow) is not runnable here" % (n, K_PER_GPU, H)}
+
+
+def sync_latency(m, steps=200, warmup=20):
+    """Host-synchronous closed loop: mppi_next(x)->u with the plant stepped on the host (the shape of
+    the reference's loop, main.cpp:37-43). Median / p95 ms per control step."""
+    h = m.Handle(k=K_PER_GPU, **CFG)
+    x = np.zeros(S, np.float32)
+    dt, ts = 0.1, []
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        u = h.next(x)
+        t1 = time.perf_counter()
+        if i >= warmup:
+            ts.append(t1 - t0)
+        for j in range(A):  # point-mass plant, fp32, same model
+            x[2 * j] = x[2 * j] + dt * x[2 * j + 1] + (dt * dt / 2) * u[j]
+            x[2 * j + 1] = x[2 * j + 1] + dt * u[j]
+    ts = np.sort(np.asarray(ts)) * 1e3
+    h.close()
+    return float(np.median(ts)), float(ts[int(0.95 * (len(ts) - 1))])
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
+    (profiles/, collected in separate passes per the guide); None when absent."""
+    f = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        return json.load(open(f)).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import mppi_tf_amd as m
+    from mppi_tf_amd.distributed import ShardedController
+
+    k_global = K_PER_GPU * world
+    ctl = ShardedController(device_index=local_rank, k=k_global, **CFG)
+    assert ctl.backend.h.k_local == K_PER_GPU
+    x = torch.zeros(S, dtype=torch.float32, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        ctl.next(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctl.next(x)
+    barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+
+    # second pass, same K steps, with HIP events around the dominant kernel on its launch stream
+    h = ctl.backend.h
+    h.profile_begin(args.steps)
+    for _ in range(args.steps):
+        ctl.next(x)
+    torch.cuda.synchronize(dev)
+    roll_ms, fin_ms, n_prof = h.profile_end()
+    u_last = ctl.u.cpu().numpy()
+    assert np.isfinite(u_last).all()
+
+    if rank == 0:
+        state_steps = K_PER_GPU * H
+        alg_bytes = BYTES_PER_STATE_STEP * state_steps + 8 * K_PER_GPU
+        ach = alg_bytes / (roll_ms * 1e-3) / 1e9 if roll_ms > 0 else 0.0
+        out = {
+            "metric": "rollouts/s (one control step = K rollouts x H steps), point_mass3d H=64",
+            "value": k_global * args.steps / el, "unit": "rollouts/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "state_steps_per_s": k_global * H * args.steps / el,
+            "config": {"workload": "point_mass3d analytic model, K=%d H=%d per GPU (BASELINE configs[2]), "
+                                   "on-device Philox noise, device-resident x/U" % (K_PER_GPU, H),
+                       "K_global": k_global, "K_per_gpu": K_PER_GPU, "H": H, "s_dim": S, "a_dim": A,
+                       "lambda": 1.0, "sigma": "0.25*I", "dt": 0.1, "mass": 1.0,
+                       "parallelism": "K-shard x%d, one all-gather of %d floats per step" % (world, h.record_size)},
+            "roofline": {"bound": "hbm", "kernel": "k_rollout_tile<3,64,false,PHILOX,ROLLOUT>",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_flop_per_launch": FLOP_PER_STATE_STEP * state_steps,
+                         "kernel_ms_avg": roll_ms, "finish_kernel_ms_avg": fin_ms, "launches_timed": n_prof,
+                         "note": "noise is generated and consumed on-chip (LDS), so physical HBM traffic is far below "
+                                 "the 12a B/state-step materialised-noise model; the true limiter is VALU "
+                                 "(Philox4x32-10 + Box-Muller). See DESIGN.md §4."},
+        }
+        if world == 1:
+            med, p95 = sync_latency(m)
+            out["ms_per_control_step_sync"] = {"median": med, "p95": p95,
+                                               "what": "host-synchronous mppi_next(x)->u incl. H2D x, D2H u, 200 closed-loop steps"}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,193 @@
+/*
+ * mppi_c.h — C-ABI of the MI355X-native MPPI control step (libmppi_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of NicolayP/mppi-tf: the per-control-step MPPI
+ * update (perturb K control sequences, roll the model H steps, cost every step, soft-min
+ * weight, reduce to the new nominal sequence).  The reference has no FFI of its own; its
+ * boundary is the public C++ API of `ControllerBase` (include/controller_base.hpp:60-109 in
+ * the reference) as driven by its host loop (src/main.cpp:30-45).  Every entry point below
+ * names the reference interface it replaces.  include/mppi/controller_base.hpp re-creates
+ * the reference's C++ classes on top of these calls; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in signatures; `void *stream` is a hipStream_t (NULL = the
+ *    handle's own stream);
+ *  - all host buffers are caller-owned, fp32, row-major, with the reference's trailing
+ *    singleton dropped:  x[s]  U[tau,a]  eps[K,tau,a]  cost[K];
+ *  - pointers named *_dev are DEVICE pointers on the handle's GPU;
+ *  - every call returns an mppi_status (0 = OK) and never aborts (the reference LOG(FATAL)s
+ *    on a TF error, controller_base.cpp:141); mppi_last_error() gives the text;
+ *  - one handle = one controller, NOT thread-safe per handle (same as the reference: one
+ *    session, mutable m_U); distinct handles are independent;
+ *  - host-pointer calls are synchronous; *_device calls only enqueue on the stream.
+ */
+#ifndef MPPI_C_H_
+#define MPPI_C_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPPI_ABI_VERSION 1
+#define MPPI_MAX_S 32  /* largest state dimension  */
+#define MPPI_MAX_A 16  /* largest action dimension */
+
+typedef struct mppi_handle mppi_handle;
+
+typedef enum {
+    MPPI_OK = 0,
+    MPPI_ERR_INVALID_ARG = 1,    /* bad size / NULL (ref: setGoal -> false, controller_base.cpp:126-130) */
+    MPPI_ERR_NO_DEVICE = 2,      /* no HIP device / device ordinal out of range */
+    MPPI_ERR_HIP = 3,            /* a HIP runtime call failed; see mppi_last_error */
+    MPPI_ERR_UNSUPPORTED = 4,    /* shape / option outside what the kernels implement */
+    MPPI_ERR_SINGULAR_SIGMA = 5, /* Σ not invertible (ref: MatrixInverse fails, cost_base.cpp:39) */
+    MPPI_ERR_ALLOC = 6,
+    MPPI_ERR_IO = 7
+} mppi_status;
+
+enum { MPPI_MODEL_POINT_MASS = 0, /* x' = A x + (B/m) v, src/model_base.cpp:53-82 */
+       MPPI_MODEL_MLP = 1 };      /* x' = x + denorm(MLP(norm([x;v]))), nn_model.py:215-304 convention */
+
+enum { MPPI_ACTION_COST_CPP = 0,  /* λ uᵀΣ⁻¹ε                          src/cost_base.cpp:63-68   */
+       MPPI_ACTION_COST_PY = 1 }; /* ½[γ(uᵀΣ⁻¹u+2uᵀΣ⁻¹ε)+λ(1-1/υ)εᵀΣ⁻¹ε]  costs/cost_base.py:114-170 */
+
+/* what mppi_debug_get returns (observer_base.py:101-187 logs the same intermediates) */
+enum { MPPI_DBG_COSTS = 0,    /* c[K_local]         sample costs of the last step            */
+       MPPI_DBG_BETA = 1,     /* [1]                min cost (over all shards after finish)  */
+       MPPI_DBG_ETA = 2,      /* [1]                Σ exp(-(c-β)/λ)                          */
+       MPPI_DBG_WEIGHTS = 3,  /* w[K_local]         exp(-(c-β)/λ)/η                          */
+       MPPI_DBG_NOISE = 4,    /* eps[K_local,tau,a] the noise the last step used             */
+       MPPI_DBG_U_UPDATED = 5 /* U'[tau,a]          updated sequence before the shift        */ };
+
+/* Learned model_base: Dense(relu) x (n_layers-1) + Dense(linear) -> s_dim outputs. */
+typedef struct {
+    int32_t n_layers;
+    const int32_t *widths;   /* [n_layers] output width of every layer; widths[n_layers-1] == s_dim */
+    const float *const *W;   /* W[l]: [in x out] row-major (Keras kernel layout)                    */
+    const float *const *b;   /* b[l]: [out]                                                         */
+    const float *xmean, *xstd; /* [s+a] input normalisation, NULL -> 0 / 1 (nn_model.py:289-293)     */
+    const float *ymean, *ystd; /* [s]   output de-normalisation, NULL -> 0 / 1 (nn_model.py:295-297) */
+} mppi_mlp_desc;
+
+/* Everything the reference hard-codes in ControllerBase's constructor
+ * (controller_base.cpp:23-71) or reads from its config YAML files, as one POD block. */
+typedef struct {
+    uint32_t struct_size;     /* = sizeof(mppi_config); set by mppi_config_init */
+    int32_t k;                /* samples K (GLOBAL count when sharded)          */
+    int32_t tau;              /* horizon H                                      */
+    int32_t s_dim, a_dim;
+    float dt, mass;
+    float lambda, gamma, upsilon;
+    int32_t action_cost_kind; /* MPPI_ACTION_COST_*                             */
+    int32_t normalize_cost;   /* Py normalizeCost, controller_base.py:468-474   */
+    const float *sigma;       /* [a*a] Σ multiplies z AND Σ⁻¹ enters the cost; NULL -> I  */
+    const float *goal;        /* [s]; NULL -> (1,0) per axis (controller_base.cpp:43-46)  */
+    const float *Q;           /* NULL -> ones (controller_base.cpp:58-60)                 */
+    int32_t q_is_full;        /* 0: Q is the [s] diagonal (C++ Diag(in_Q)); 1: Q is [s*s] (Py) */
+    uint64_t seed;            /* Philox key; default 1 (controller_base.cpp:199)          */
+    int32_t model_kind;       /* MPPI_MODEL_*                                             */
+    const mppi_mlp_desc *mlp; /* only for MPPI_MODEL_MLP                                  */
+    int32_t device;           /* HIP device ordinal                                       */
+    int32_t shard_rank;       /* this handle owns samples [rank*k/count, (rank+1)*k/count) */
+    int32_t shard_count;      /* 1 = unsharded                                            */
+    int32_t flags;            /* reserved, 0                                              */
+} mppi_config;
+
+/* ---- library ------------------------------------------------------------------------- */
+int mppi_abi_version(void);
+const char *mppi_version(void);
+const char *mppi_status_string(mppi_status st);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int mppi_device_count(void);
+
+/* ---- construction (replaces ControllerBase::ControllerBase, controller_base.cpp:23-71) -- */
+/* Fill cfg with the reference constructor's defaults: λ=1, γ=υ=1, Σ=I, Q=1, goal=(1,0)…,
+ * seed=1, point-mass model, C++ action cost, device 0, unsharded. */
+mppi_status mppi_config_init(mppi_config *cfg, int k, int tau, float dt, float mass, int s_dim, int a_dim);
+/* Build the controller: copies every array in cfg, allocates device state (U = 0). */
+mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out);
+/* replaces ControllerBase::~ControllerBase (controller_base.cpp:124) */
+void mppi_destroy(mppi_handle *h);
+const char *mppi_last_error(const mppi_handle *h);
+
+/* ---- the host loop's calls -------------------------------------------------------------- */
+/* replaces ControllerBase::setGoal (controller_base.cpp:126-133). Takes effect on the next
+ * step (the reference bakes the goal into the graph and ignores later calls — a bug we do
+ * not reproduce). n must equal s_dim. */
+mppi_status mppi_set_goal(mppi_handle *h, const float *goal, int n);
+/* replaces ControllerBase::next (controller_base.cpp:135-153): one control step with noise
+ * drawn on the device (Philox4x32-10 via rocRAND's engine); returns u = U'[0] in u_out[a],
+ * keeps shift(U') as the warm start, logs (x,u) like m_db.addX/addU. */
+mppi_status mppi_next(mppi_handle *h, const float *x, int n_x, float *u_out, int n_u);
+/* Same step with the noise INJECTED (the reference's tests inject noise,
+ * test_controller.cpp:24-35): eps is [K_local, tau, a] for this handle's shard. */
+mppi_status mppi_next_with_noise(mppi_handle *h, const float *x, int n_x, const float *eps, size_t n_eps,
+                                 float *u_out, int n_u);
+/* replaces ControllerBase::saveNext / toCSV (controller_base.cpp:155-164) — host bookkeeping */
+mppi_status mppi_save_next(mppi_handle *h, const float *x_next, int n);
+mppi_status mppi_to_csv(mppi_handle *h, const char *filename);
+
+/* ---- controller state (deterministic replay; SURVEY §5 checkpoint row) ------------------ */
+mppi_status mppi_get_action_sequence(mppi_handle *h, float *U, int n);        /* n = tau*a */
+mppi_status mppi_set_action_sequence(mppi_handle *h, const float *U, int n);
+mppi_status mppi_get_step_counter(mppi_handle *h, uint64_t *step);            /* RNG offset */
+mppi_status mppi_set_step_counter(mppi_handle *h, uint64_t step);
+mppi_status mppi_debug_get(mppi_handle *h, int what, float *out, size_t n);
+
+/* ---- the reference's public graph helpers, as plain functions --------------------------- */
+/* ModelBase::mBuildFreeStepGraph / mBuildActionStepGraph / mBuildModelStepGraph
+ * (model_base.cpp:53-82). x is [kx,s] with kx == k or kx == 1 (broadcast initial state,
+ * model_base.hpp:74-75); v is [k,a]. Any output may be NULL. out_free is [kx,s]. */
+mppi_status mppi_model_step(mppi_handle *h, const float *x, int kx, const float *v, int k,
+                            float *out_free, float *out_action, float *out_next);
+/* CostBase::mStateCost / mBuildFinalStepCostGraph (cost_base.cpp:52-61): x[k,s] -> out[k] */
+mppi_status mppi_state_cost(mppi_handle *h, const float *x, int k, float *out);
+/* CostBase::mActionCost (cost_base.cpp:63-68 or the Py form): u[a], eps[k,a] -> out[k] */
+mppi_status mppi_action_cost(mppi_handle *h, const float *u, const float *eps, int k, float *out);
+/* CostBase::mBuildStepCostGraph (cost_base.cpp:43-50): state + action cost -> out[k] */
+mppi_status mppi_step_cost(mppi_handle *h, const float *x, const float *u, const float *eps, int k, float *out);
+/* ControllerBase::mBuildModelGraph (controller_base.cpp:226-273): the full H-step rollout
+ * cost from x[s], U[tau,a], eps[K_local,tau,a] -> cost_out[K_local]. Does not touch state. */
+mppi_status mppi_rollout_cost(mppi_handle *h, const float *x, const float *U, const float *eps, float *cost_out);
+/* ControllerBase::mBeta…mWeightedNoise + mBuildUpdateGraph (controller_base.cpp:166-192,
+ * 215-224) on given costs: cost[K_local], eps[K_local,tau,a], U[tau,a]. Outputs (any may be
+ * NULL): beta[1], exp_arg[K], exp[K], nabla[1], weights[K], weighted_noise[tau,a], U_new[tau,a]. */
+mppi_status mppi_update(mppi_handle *h, const float *cost, const float *eps, const float *U,
+                        float *beta, float *exp_arg, float *exp_out, float *nabla, float *weights,
+                        float *weighted_noise, float *U_new);
+/* ControllerBase::mGetNew / mShift(+mInit0) (controller_base.cpp:310-329), host-side slices */
+mppi_status mppi_get_new(const float *U, int tau, int a, int nb, float *out);
+mppi_status mppi_shift(const float *U, int tau, int a, const float *init, int nb_init, int nb, float *out);
+
+/* ---- device-resident / asynchronous step (streams, K-sharding across GPUs) -------------- */
+/* floats in one shard record: (beta_g, eta_g, V_g[tau*a]) */
+int mppi_record_size(const mppi_handle *h);
+/* samples this handle owns, and the global index of its first sample */
+int mppi_local_samples(const mppi_handle *h);
+int mppi_sample_offset(const mppi_handle *h);
+/* One whole step, enqueue only: x_dev[s] -> u_dev[a]; U and the step counter advance on the
+ * device. Unsharded handles only. */
+mppi_status mppi_next_device(mppi_handle *h, const float *x_dev, float *u_dev, void *stream);
+/* Sharded step, phase 1: rollouts + local soft-min of this shard -> record_dev[record_size]. */
+mppi_status mppi_shard_partial(mppi_handle *h, const float *x_dev, float *record_dev, void *stream);
+/* Sharded step, phase 2: combine n_records records (all shards, rank order — the result of an
+ * all-gather) with r_g = exp(-(beta_g-beta)/λ), apply U' = U + V/η, emit u_dev[a], shift U. */
+mppi_status mppi_shard_finish(mppi_handle *h, const float *records_dev, int n_records, float *u_dev, void *stream);
+/* Wait for the handle's own stream. */
+mppi_status mppi_synchronize(mppi_handle *h);
+
+/* ---- measurement (the reference only has a commented-out chrono loop, main.cpp:55-64) ------ */
+/* Bracket the rollout kernel and the finish kernel of the next <= max_steps steps with HIP
+ * events ON THE STREAM THEY ARE LAUNCHED ON. */
+mppi_status mppi_profile_begin(mppi_handle *h, int max_steps);
+/* Synchronise, stop recording, return average kernel durations in milliseconds over the
+ * n_steps recorded steps (any output may be NULL). */
+mppi_status mppi_profile_end(mppi_handle *h, float *rollout_ms_avg, float *finish_ms_avg, int *n_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPPI_C_H_ */

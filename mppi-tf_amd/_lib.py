@@ -1,0 +1,308 @@
+"""ctypes binding of libmppi_hip.so (include/mppi_c.h) — the only way Python reaches the kernels.
+
+There is no CPU fallback: a missing library or a missing GPU raises (MppiError / OSError).
+torch is imported before the library is loaded on purpose: torch's wheel bundles its own
+libamdhip64.so.7; loading it first makes our library bind to that same HIP runtime instance
+(same soname) instead of bringing a second runtime into the process.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libmppi_hip.so")
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_SINGULAR_SIGMA, ERR_ALLOC, ERR_IO = range(8)
+MODEL_POINT_MASS, MODEL_MLP = 0, 1
+ACTION_COST_CPP, ACTION_COST_PY = 0, 1
+DBG_COSTS, DBG_BETA, DBG_ETA, DBG_WEIGHTS, DBG_NOISE, DBG_U_UPDATED = range(6)
+
+FP = C.POINTER(C.c_float)
+
+
+class MppiError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("mppi status %d: %s" % (status, text))
+        self.status = status
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("widths", C.POINTER(C.c_int32)),
+                ("W", C.POINTER(FP)), ("b", C.POINTER(FP)),
+                ("xmean", FP), ("xstd", FP), ("ymean", FP), ("ystd", FP)]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("k", C.c_int32), ("tau", C.c_int32),
+                ("s_dim", C.c_int32), ("a_dim", C.c_int32), ("dt", C.c_float), ("mass", C.c_float),
+                ("lam", C.c_float), ("gamma", C.c_float), ("upsilon", C.c_float),
+                ("action_cost_kind", C.c_int32), ("normalize_cost", C.c_int32),
+                ("sigma", FP), ("goal", FP), ("Q", FP), ("q_is_full", C.c_int32),
+                ("seed", C.c_uint64), ("model_kind", C.c_int32), ("mlp", C.POINTER(MlpDesc)),
+                ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
+                ("flags", C.c_int32)]
+
+
+# name -> (restype, argtypes); must list EVERY symbol include/mppi_c.h declares
+# (tests/test_capi_symbols.py parses the header and compares).
+_H = C.c_void_p
+SIGNATURES = {
+    "mppi_abi_version": (C.c_int, []),
+    "mppi_version": (C.c_char_p, []),
+    "mppi_status_string": (C.c_char_p, [C.c_int]),
+    "mppi_device_count": (C.c_int, []),
+    "mppi_config_init": (C.c_int, [C.POINTER(Config), C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int]),
+    "mppi_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
+    "mppi_destroy": (None, [_H]),
+    "mppi_last_error": (C.c_char_p, [_H]),
+    "mppi_set_goal": (C.c_int, [_H, FP, C.c_int]),
+    "mppi_next": (C.c_int, [_H, FP, C.c_int, FP, C.c_int]),
+    "mppi_next_with_noise": (C.c_int, [_H, FP, C.c_int, FP, C.c_size_t, FP, C.c_int]),
+    "mppi_save_next": (C.c_int, [_H, FP, C.c_int]),
+    "mppi_to_csv": (C.c_int, [_H, C.c_char_p]),
+    "mppi_get_action_sequence": (C.c_int, [_H, FP, C.c_int]),
+    "mppi_set_action_sequence": (C.c_int, [_H, FP, C.c_int]),
+    "mppi_get_step_counter": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    "mppi_set_step_counter": (C.c_int, [_H, C.c_uint64]),
+    "mppi_debug_get": (C.c_int, [_H, C.c_int, FP, C.c_size_t]),
+    "mppi_model_step": (C.c_int, [_H, FP, C.c_int, FP, C.c_int, FP, FP, FP]),
+    "mppi_state_cost": (C.c_int, [_H, FP, C.c_int, FP]),
+    "mppi_action_cost": (C.c_int, [_H, FP, FP, C.c_int, FP]),
+    "mppi_step_cost": (C.c_int, [_H, FP, FP, FP, C.c_int, FP]),
+    "mppi_rollout_cost": (C.c_int, [_H, FP, FP, FP, FP]),
+    "mppi_update": (C.c_int, [_H, FP, FP, FP, FP, FP, FP, FP, FP, FP, FP]),
+    "mppi_get_new": (C.c_int, [FP, C.c_int, C.c_int, C.c_int, FP]),
+    "mppi_shift": (C.c_int, [FP, C.c_int, C.c_int, FP, C.c_int, C.c_int, FP]),
+    "mppi_record_size": (C.c_int, [_H]),
+    "mppi_local_samples": (C.c_int, [_H]),
+    "mppi_sample_offset": (C.c_int, [_H]),
+    "mppi_next_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mppi_shard_partial": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mppi_shard_finish": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mppi_synchronize": (C.c_int, [_H]),
+    "mppi_profile_begin": (C.c_int, [_H, C.c_int]),
+    "mppi_profile_end": (C.c_int, [_H, FP, FP, C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmppi_hip.so (built in-tree by build.py). Raises OSError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (one HIP runtime per process — see module docstring)
+    if not os.path.exists(SO_PATH):
+        raise OSError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.mppi_abi_version() != 1:
+        raise OSError("libmppi_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def f32(x, shape=None):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+    return a.reshape(shape) if shape is not None else a
+
+
+def fp(a):
+    return a.ctypes.data_as(FP) if a is not None else None
+
+
+class Handle:
+    """RAII wrapper of one mppi_handle (one controller on one GPU)."""
+
+    def __init__(self, k, tau, s_dim, a_dim, dt=0.1, mass=1.0, lam=1.0, gamma=1.0, upsilon=1.0,
+                 sigma=None, goal=None, Q=None, q_is_full=None, action_cost=ACTION_COST_CPP,
+                 normalize_cost=False, seed=1, device=0, shard_rank=0, shard_count=1):
+        lib = self.lib = load()
+        cfg = Config()
+        self._check(lib.mppi_config_init(C.byref(cfg), k, tau, dt, mass, s_dim, a_dim), None)
+        cfg.lam, cfg.gamma, cfg.upsilon = lam, gamma, upsilon
+        cfg.action_cost_kind, cfg.normalize_cost = action_cost, int(bool(normalize_cost))
+        cfg.seed, cfg.device, cfg.shard_rank, cfg.shard_count = seed, device, shard_rank, shard_count
+        keep = []
+        if sigma is not None:
+            keep.append(f32(sigma, (a_dim, a_dim)))
+            cfg.sigma = fp(keep[-1])
+        if goal is not None:
+            keep.append(f32(goal, (s_dim,)))
+            cfg.goal = fp(keep[-1])
+        if Q is not None:
+            q = f32(Q)
+            if q_is_full is None:
+                q_is_full = q.ndim == 2
+            keep.append(f32(q, (s_dim, s_dim) if q_is_full else (s_dim,)))
+            cfg.Q, cfg.q_is_full = fp(keep[-1]), int(q_is_full)
+        self.h = _H()
+        self.k, self.tau, self.s, self.a = k, tau, s_dim, a_dim
+        st = lib.mppi_create(C.byref(cfg), C.byref(self.h))
+        if st != OK:
+            self.h = _H()
+            self._check(st, None)
+        self.k_local = lib.mppi_local_samples(self.h)
+        self.k_offset = lib.mppi_sample_offset(self.h)
+        self.record_size = lib.mppi_record_size(self.h)
+
+    def _check(self, st, h=True):
+        if st != OK:
+            txt = self.lib.mppi_last_error(self.h if (h and self.h) else None) or b""
+            raise MppiError(st, "%s (%s)" % (txt.decode(), self.lib.mppi_status_string(st).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mppi_destroy(self.h)
+            self.h = _H()
+
+    __del__ = close
+
+    # ---- host loop -------------------------------------------------------------------
+    def set_goal(self, goal):
+        g = f32(goal).ravel()
+        self._check(self.lib.mppi_set_goal(self.h, fp(g), g.size))
+
+    def next(self, x):
+        x = f32(x).ravel()
+        u = np.zeros(self.a, np.float32)
+        self._check(self.lib.mppi_next(self.h, fp(x), x.size, fp(u), u.size))
+        return u
+
+    def next_with_noise(self, x, eps):
+        x, eps = f32(x).ravel(), f32(eps).ravel()
+        u = np.zeros(self.a, np.float32)
+        self._check(self.lib.mppi_next_with_noise(self.h, fp(x), x.size, fp(eps), eps.size, fp(u), u.size))
+        return u
+
+    def save_next(self, x_next):
+        x = f32(x_next).ravel()
+        self._check(self.lib.mppi_save_next(self.h, fp(x), x.size))
+
+    def to_csv(self, filename):
+        self._check(self.lib.mppi_to_csv(self.h, os.fsencode(filename)))
+
+    # ---- state -----------------------------------------------------------------------
+    def get_action_sequence(self):
+        U = np.zeros((self.tau, self.a), np.float32)
+        self._check(self.lib.mppi_get_action_sequence(self.h, fp(U), U.size))
+        return U
+
+    def set_action_sequence(self, U):
+        U = f32(U).ravel()
+        self._check(self.lib.mppi_set_action_sequence(self.h, fp(U), U.size))
+
+    def get_step_counter(self):
+        v = C.c_uint64(0)
+        self._check(self.lib.mppi_get_step_counter(self.h, C.byref(v)))
+        return int(v.value)
+
+    def set_step_counter(self, step):
+        self._check(self.lib.mppi_set_step_counter(self.h, step))
+
+    def debug_get(self, what):
+        n = {DBG_COSTS: self.k_local, DBG_BETA: 1, DBG_ETA: 1, DBG_WEIGHTS: self.k_local,
+             DBG_NOISE: self.k_local * self.tau * self.a, DBG_U_UPDATED: self.tau * self.a}[what]
+        out = np.zeros(n, np.float32)
+        self._check(self.lib.mppi_debug_get(self.h, what, fp(out), n))
+        if what == DBG_NOISE:
+            return out.reshape(self.k_local, self.tau, self.a)
+        if what == DBG_U_UPDATED:
+            return out.reshape(self.tau, self.a)
+        return out if n > 1 else out[0]
+
+    # ---- graph helpers ---------------------------------------------------------------
+    def model_step(self, x, v):
+        """-> (free [kx,s], action [k,s], next [k,s])"""
+        x, v = f32(x, (-1, self.s)), f32(v, (-1, self.a))
+        kx, k = x.shape[0], v.shape[0]
+        fr, ac, nx = np.zeros((kx, self.s), np.float32), np.zeros((k, self.s), np.float32), np.zeros((k, self.s), np.float32)
+        self._check(self.lib.mppi_model_step(self.h, fp(x), kx, fp(v), k, fp(fr), fp(ac), fp(nx)))
+        return fr, ac, nx
+
+    def state_cost(self, x):
+        x = f32(x, (-1, self.s))
+        out = np.zeros(x.shape[0], np.float32)
+        self._check(self.lib.mppi_state_cost(self.h, fp(x), x.shape[0], fp(out)))
+        return out
+
+    def action_cost(self, u, eps):
+        u, eps = f32(u, (self.a,)), f32(eps, (-1, self.a))
+        out = np.zeros(eps.shape[0], np.float32)
+        self._check(self.lib.mppi_action_cost(self.h, fp(u), fp(eps), eps.shape[0], fp(out)))
+        return out
+
+    def step_cost(self, x, u, eps):
+        x, u, eps = f32(x, (-1, self.s)), f32(u, (self.a,)), f32(eps, (-1, self.a))
+        out = np.zeros(x.shape[0], np.float32)
+        self._check(self.lib.mppi_step_cost(self.h, fp(x), fp(u), fp(eps), x.shape[0], fp(out)))
+        return out
+
+    def rollout_cost(self, x, U, eps):
+        x, U = f32(x, (self.s,)), f32(U, (self.tau, self.a))
+        eps = f32(eps, (self.k_local, self.tau, self.a))
+        out = np.zeros(self.k_local, np.float32)
+        self._check(self.lib.mppi_rollout_cost(self.h, fp(x), fp(U), fp(eps), fp(out)))
+        return out
+
+    def update(self, cost, eps, U):
+        """-> dict(beta, arg, exp, nabla, w, wn, Unew) (exp_arg is 'arg', weights 'w', weighted noise 'wn')"""
+        K = self.k_local
+        cost, U = f32(cost, (K,)), f32(U, (self.tau, self.a))
+        eps = f32(eps, (K, self.tau, self.a))
+        beta, nabla = np.zeros(1, np.float32), np.zeros(1, np.float32)
+        arg, e, w = (np.zeros(K, np.float32) for _ in range(3))
+        wn, Un = np.zeros((self.tau, self.a), np.float32), np.zeros((self.tau, self.a), np.float32)
+        self._check(self.lib.mppi_update(self.h, fp(cost), fp(eps), fp(U), fp(beta), fp(arg), fp(e), fp(nabla),
+                                         fp(w), fp(wn), fp(Un)))
+        return dict(beta=beta[0], arg=arg, exp=e, nabla=nabla[0], w=w, wn=wn, Unew=Un)
+
+    # ---- device-resident step (pointers are ints: tensor.data_ptr(), stream.cuda_stream) -----
+    def next_device(self, x_ptr, u_ptr, stream=0):
+        self._check(self.lib.mppi_next_device(self.h, x_ptr, u_ptr, stream))
+
+    def shard_partial(self, x_ptr, record_ptr, stream=0):
+        self._check(self.lib.mppi_shard_partial(self.h, x_ptr, record_ptr, stream))
+
+    def shard_finish(self, records_ptr, n_records, u_ptr, stream=0):
+        self._check(self.lib.mppi_shard_finish(self.h, records_ptr, n_records, u_ptr, stream))
+
+    def synchronize(self):
+        self._check(self.lib.mppi_synchronize(self.h))
+
+    def profile_begin(self, max_steps):
+        self._check(self.lib.mppi_profile_begin(self.h, max_steps))
+
+    def profile_end(self):
+        """-> (rollout kernel ms avg, finish kernel ms avg, steps recorded); HIP events on the launch stream."""
+        r, f, n = C.c_float(0), C.c_float(0), C.c_int(0)
+        self._check(self.lib.mppi_profile_end(self.h, C.byref(r), C.byref(f), C.byref(n)))
+        return r.value, f.value, n.value
+
+
+def get_new(U, nb):
+    lib = load()
+    U = f32(U)
+    tau, a = U.shape
+    out = np.zeros((nb, a), np.float32)
+    st = lib.mppi_get_new(fp(U), tau, a, nb, fp(out))
+    if st != OK:
+        raise MppiError(st, "mppi_get_new")
+    return out
+
+
+def shift(U, init, nb):
+    lib = load()
+    U = f32(U)
+    tau, a = U.shape
+    init = f32(init, (-1, a))
+    out = np.zeros((tau - nb + init.shape[0], a), np.float32)
+    st = lib.mppi_shift(fp(U), tau, a, fp(init), init.shape[0], nb, fp(out))
+    if st != OK:
+        raise MppiError(st, "mppi_shift")
+    return out

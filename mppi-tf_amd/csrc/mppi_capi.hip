@@ -1,0 +1,764 @@
+// mppi_capi.hip — host side of libmppi_hip.so: the C-ABI of include/mppi_c.h over the kernels
+// of mppi_kernels.hip.h.  No CPU compute path exists here: every numeric entry point launches
+// HIP kernels and fails with MPPI_ERR_NO_DEVICE / MPPI_ERR_HIP when it cannot.
+#include "mppi_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mppi;
+
+#define MPPI_VERSION_STRING "mppi-hip 0.1.0 (gfx950)"
+
+// ----------------------------------------------------------------------------------------
+struct mppi_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevConsts hc{};
+    DevConsts *dC = nullptr;
+    int K_global = 0, K_local = 0, k_offset = 0, shard_rank = 0, shard_count = 1;
+    int H = 0, s = 0, a = 0, HA = 0;
+    int R = 64, nb = 0;
+    size_t tile_lds = 0;
+    int normalize = 0;
+    float *d_x = nullptr, *d_U = nullptr, *d_u = nullptr, *d_cost = nullptr, *d_cost2 = nullptr;
+    float *d_part = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_Uupd = nullptr, *d_mm = nullptr;
+    float *d_eps = nullptr; // lazily allocated [K_local, H, a] for injected noise / debug export
+    unsigned long long *d_step = nullptr;
+    float *h_pin = nullptr; // pinned staging: x[s] | u[a]
+    std::string err;
+    // profiling: event pairs around the rollout / finish kernels (mppi_profile_begin/end)
+    std::vector<hipEvent_t> ev;   // 4 events per step: rollout begin/end, finish begin/end
+    int prof_cap = 0, prof_n = 0; // steps that can be / have been recorded
+    hipStream_t prof_stream = nullptr;
+    std::string no_rollout; // non-empty: why this handle cannot run rollouts (helpers still work)
+    // transition log (m_db of the reference: addX/addU/addNext/toCSV, data_base.cpp:29-71)
+    std::vector<float> log_x, log_u, log_next;
+};
+
+static thread_local std::string g_create_err;
+
+static mppi_status fail(mppi_handle *h, mppi_status st, const std::string &msg)
+{
+    if (h) h->err = msg; else g_create_err = msg;
+    return st;
+}
+
+#define HIP_TRY(h, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e == hipErrorNotSupported && (h) && !((mppi_handle *)(h))->no_rollout.empty())       \
+            return fail((h), MPPI_ERR_UNSUPPORTED, ((mppi_handle *)(h))->no_rollout);             \
+        if (_e != hipSuccess)                                                                     \
+            return fail((h), MPPI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+// ----------------------------------------------------------------------------------------
+extern "C" int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
+extern "C" const char *mppi_version(void) { return MPPI_VERSION_STRING; }
+
+extern "C" const char *mppi_status_string(mppi_status st)
+{
+    switch (st) {
+    case MPPI_OK: return "ok";
+    case MPPI_ERR_INVALID_ARG: return "invalid argument";
+    case MPPI_ERR_NO_DEVICE: return "no HIP device";
+    case MPPI_ERR_HIP: return "HIP runtime error";
+    case MPPI_ERR_UNSUPPORTED: return "unsupported shape or option";
+    case MPPI_ERR_SINGULAR_SIGMA: return "sigma is singular";
+    case MPPI_ERR_ALLOC: return "allocation failed";
+    case MPPI_ERR_IO: return "i/o error";
+    }
+    return "unknown status";
+}
+
+extern "C" int mppi_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" const char *mppi_last_error(const mppi_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" mppi_status mppi_config_init(mppi_config *cfg, int k, int tau, float dt, float mass, int s_dim, int a_dim)
+{
+    if (!cfg) return MPPI_ERR_INVALID_ARG;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (uint32_t)sizeof(*cfg);
+    cfg->k = k; cfg->tau = tau; cfg->s_dim = s_dim; cfg->a_dim = a_dim;
+    cfg->dt = dt; cfg->mass = mass;
+    cfg->lambda = 1.0f; cfg->gamma = 1.0f; cfg->upsilon = 1.0f; // controller_base.cpp:40-41
+    cfg->action_cost_kind = MPPI_ACTION_COST_CPP;
+    cfg->seed = 1; // RandomNormal::Seed(1.) controller_base.cpp:199
+    cfg->model_kind = MPPI_MODEL_POINT_MASS;
+    cfg->shard_count = 1;
+    return MPPI_OK;
+}
+
+// Σ⁻¹ (cost_base.cpp:39 MatrixInverse): Gauss-Jordan with partial pivoting in double.
+static bool invert(const float *S, int n, float *out)
+{
+    double M[kMaxA][2 * kMaxA];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) { M[i][j] = S[i * n + j]; M[i][n + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        for (int r = c + 1; r < n; ++r) if (std::fabs(M[r][c]) > std::fabs(M[p][c])) p = r;
+        if (std::fabs(M[p][c]) < 1e-300) return false;
+        if (p != c) for (int j = 0; j < 2 * n; ++j) std::swap(M[c][j], M[p][j]);
+        const double piv = M[c][c];
+        for (int j = 0; j < 2 * n; ++j) M[c][j] /= piv;
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = M[r][c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 2 * n; ++j) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) out[i * n + j] = (float)M[i][n + j];
+    return true;
+}
+
+static mppi_status upload_consts(mppi_handle *h)
+{
+    HIP_TRY(h, hipMemcpyAsync(h->dC, &h->hc, sizeof(DevConsts), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
+extern "C" void mppi_destroy(mppi_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    float *bufs[] = {h->d_x, h->d_U, h->d_u, h->d_cost, h->d_cost2, h->d_part, h->d_record, h->d_dbg,
+                     h->d_Uupd, h->d_mm, h->d_eps};
+    for (float *p : bufs) if (p) (void)hipFree(p);
+    if (h->d_step) (void)hipFree(h->d_step);
+    if (h->dC) (void)hipFree(h->dC);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
+{
+    if (!cfg || !out) return fail(nullptr, MPPI_ERR_INVALID_ARG, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(mppi_config)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_config.struct_size mismatch (use mppi_config_init)");
+    const int s = cfg->s_dim, a = cfg->a_dim;
+    if (cfg->k <= 0 || cfg->tau <= 0 || s <= 0 || a <= 0 || s > kMaxS || a > kMaxA)
+        return fail(nullptr, MPPI_ERR_INVALID_ARG, "k, tau, s_dim, a_dim out of range");
+    if (!(cfg->lambda > 0.0f) || !(cfg->upsilon != 0.0f)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "lambda must be > 0, upsilon != 0");
+    if (cfg->shard_count < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_count)
+        return fail(nullptr, MPPI_ERR_INVALID_ARG, "bad shard_rank/shard_count");
+    if (cfg->model_kind == MPPI_MODEL_POINT_MASS && !(cfg->mass != 0.0f)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "mass must be non-zero");
+    if (cfg->model_kind != MPPI_MODEL_POINT_MASS)
+        return fail(nullptr, MPPI_ERR_UNSUPPORTED, "model kind not implemented in this build");
+
+    int ndev = mppi_device_count();
+    if (ndev <= 0) return fail(nullptr, MPPI_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, MPPI_ERR_NO_DEVICE, "device ordinal out of range");
+
+    mppi_handle *h = new (std::nothrow) mppi_handle();
+    if (!h) return fail(nullptr, MPPI_ERR_ALLOC, "out of host memory");
+    h->device = cfg->device;
+    h->K_global = cfg->k; h->shard_rank = cfg->shard_rank; h->shard_count = cfg->shard_count;
+    // shard g owns [g*K/G, (g+1)*K/G)  
+    const long long lo = (long long)cfg->shard_rank * cfg->k / cfg->shard_count;
+    const long long hi = (long long)(cfg->shard_rank + 1) * cfg->k / cfg->shard_count;
+    h->k_offset = (int)lo; h->K_local = (int)(hi - lo);
+    if (h->K_local <= 0) { delete h; return fail(nullptr, MPPI_ERR_INVALID_ARG, "shard owns no samples"); }
+    h->H = cfg->tau; h->s = s; h->a = a; h->HA = cfg->tau * a;
+    h->normalize = cfg->normalize_cost;
+
+    DevConsts &c = h->hc;
+    c.K_local = h->K_local; c.k_offset = h->k_offset; c.H = h->H; c.s = s; c.a = a;
+    c.q_full = cfg->q_is_full ? 1 : 0;
+    c.action_cost_kind = cfg->action_cost_kind; c.model_kind = cfg->model_kind;
+    c.lambda = cfg->lambda; c.neg_inv_lambda = -1.0f / cfg->lambda;
+    c.gamma = cfg->gamma; c.upsilon = cfg->upsilon;
+    c.py_ncoef = cfg->lambda * (1.0f - 1.0f / cfg->upsilon);
+    c.dt = cfg->dt;
+    c.bp = ((cfg->dt * cfg->dt) / 2.0f) / cfg->mass; // model_base.cpp:72 then RealDiv :74-76
+    c.bq = cfg->dt / cfg->mass;
+    c.seed = cfg->seed;
+    for (int i = 0; i < s; ++i) c.goal[i] = cfg->goal ? cfg->goal[i] : ((i & 1) ? 0.0f : 1.0f);
+    float sig[kMaxA * kMaxA], inv[kMaxA * kMaxA];
+    for (int i = 0; i < a; ++i) for (int j = 0; j < a; ++j) sig[i * a + j] = cfg->sigma ? cfg->sigma[i * a + j] : (i == j ? 1.0f : 0.0f);
+    if (!invert(sig, a, inv)) { delete h; return fail(nullptr, MPPI_ERR_SINGULAR_SIGMA, "sigma is singular"); }
+    for (int i = 0; i < a; ++i) for (int j = 0; j < a; ++j) { c.sigma[i * kMaxA + j] = sig[i * a + j]; c.sigma_inv[i * kMaxA + j] = inv[i * a + j]; }
+    for (int i = 0; i < s; ++i) {
+        if (cfg->q_is_full) {
+            for (int j = 0; j < s; ++j) c.qfull[i * kMaxS + j] = cfg->Q ? cfg->Q[i * s + j] : (i == j ? 1.0f : 0.0f);
+            c.qdiag[i] = c.qfull[i * kMaxS + i];
+        } else {
+            c.qdiag[i] = cfg->Q ? cfg->Q[i] : 1.0f;
+            c.qfull[i * kMaxS + i] = c.qdiag[i];
+        }
+    }
+
+    // tile geometry: the largest R in {64,32,16} whose LDS image fits one CU (160 KiB), preferring
+    // <= ~53 KiB so three workgroups share a CU.
+    const size_t lds_cap = 160 * 1024;
+    int R = 64;
+    while (R > 16 && tile_lds_floats(h->HA, R) * 4 > lds_cap) R >>= 1;
+    // CostBase and ModelBase are separate classes in the reference (cost shapes such as s=4,a=3
+    // or s=13,a=6 appear in its tests): such a handle serves the cost/model helpers, and the
+    // rollout entry points answer MPPI_ERR_UNSUPPORTED with this reason.
+    if (s != 2 * a) h->no_rollout = "point-mass rollouts need s_dim == 2*a_dim (blockDiag of 2x2 / 2x1 blocks, model_base.cpp:59-82)";
+    else if (a > 4) h->no_rollout = "rollout kernels are instantiated for a_dim <= 4";
+    else if (tile_lds_floats(h->HA, R) * 4 > lds_cap) h->no_rollout = "tau*a_dim too large: the 16-rollout LDS tile exceeds 160 KiB";
+    h->R = R; h->nb = (h->K_local + R - 1) / R; h->tile_lds = tile_lds_floats(h->HA, R) * 4;
+
+    mppi_status st = MPPI_OK;
+    auto body = [&]() -> mppi_status {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipMalloc((void **)&h->dC, sizeof(DevConsts)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_x, sizeof(float) * kMaxS));
+        HIP_TRY(h, hipMalloc((void **)&h->d_U, sizeof(float) * h->HA));
+        HIP_TRY(h, hipMalloc((void **)&h->d_u, sizeof(float) * kMaxA));
+        HIP_TRY(h, hipMalloc((void **)&h->d_cost, sizeof(float) * h->K_local));
+        HIP_TRY(h, hipMalloc((void **)&h->d_cost2, sizeof(float) * h->K_local));
+        HIP_TRY(h, hipMalloc((void **)&h->d_part, sizeof(float) * (size_t)h->nb * (2 + h->HA)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_record, sizeof(float) * (2 + h->HA)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_dbg, sizeof(float) * 8));
+        HIP_TRY(h, hipMalloc((void **)&h->d_Uupd, sizeof(float) * h->HA));
+        HIP_TRY(h, hipMalloc((void **)&h->d_mm, sizeof(float) * 2));
+        HIP_TRY(h, hipMalloc((void **)&h->d_step, sizeof(unsigned long long)));
+        HIP_TRY(h, hipHostMalloc((void **)&h->h_pin, sizeof(float) * (kMaxS + kMaxA), hipHostMallocDefault));
+        HIP_TRY(h, hipMemsetAsync(h->d_U, 0, sizeof(float) * h->HA, h->stream)); // U0 = 0
+        HIP_TRY(h, hipMemsetAsync(h->d_step, 0, sizeof(unsigned long long), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_dbg, 0, sizeof(float) * 8, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_cost, 0, sizeof(float) * h->K_local, h->stream));
+        return upload_consts(h);
+    };
+    st = body();
+    if (st != MPPI_OK) { g_create_err = h->err; mppi_destroy(h); return st; }
+    *out = h;
+    return MPPI_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// kernel dispatch
+template <int A, int R, bool QFULL, int SRC, int MODE>
+static hipError_t launch_tile_inst(mppi_handle *h, hipStream_t st, const float *x_dev, const float *U_dev,
+                                   const float *eps, float *cost, float *part, float *noise_out)
+{
+    auto kern = k_rollout_tile<A, R, QFULL, SRC, MODE>;
+    static thread_local size_t attr_set = 0; // raise the dynamic-LDS ceiling above 64 KiB once per size
+    if (h->tile_lds > 48 * 1024 && attr_set < h->tile_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tile_lds);
+        if (e != hipSuccess) return e;
+        attr_set = h->tile_lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(h->nb), dim3(kThreads), h->tile_lds, st, h->dC, x_dev, U_dev, eps, h->d_step, cost, part, noise_out);
+    return hipGetLastError();
+}
+
+template <int A, int R, bool QFULL>
+static hipError_t launch_tile_ar(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
+                                 const float *eps, float *cost, float *part, float *noise_out)
+{
+#define MPPI_TILE_CASE(SRC, MODE) \
+    if (src == SRC && mode == MODE) return launch_tile_inst<A, R, QFULL, SRC, MODE>(h, st, x_dev, U_dev, eps, cost, part, noise_out);
+    MPPI_TILE_CASE(SRC_PHILOX, MODE_ROLLOUT)
+    MPPI_TILE_CASE(SRC_HBM, MODE_ROLLOUT)
+    MPPI_TILE_CASE(SRC_PHILOX, MODE_COSTS_GIVEN)
+    MPPI_TILE_CASE(SRC_HBM, MODE_COSTS_GIVEN)
+    MPPI_TILE_CASE(SRC_PHILOX, MODE_COST_ONLY)
+    MPPI_TILE_CASE(SRC_HBM, MODE_COST_ONLY)
+#undef MPPI_TILE_CASE
+    return hipErrorInvalidValue;
+}
+
+template <int A>
+static hipError_t launch_tile_a(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
+                                const float *eps, float *cost, float *part, float *noise_out)
+{
+    const bool qf = h->hc.q_full != 0;
+#define MPPI_R_CASE(RR)                                                                                       \
+    if (h->R == RR) return qf ? launch_tile_ar<A, RR, true>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out) \
+                              : launch_tile_ar<A, RR, false>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
+    MPPI_R_CASE(64)
+    MPPI_R_CASE(32)
+    MPPI_R_CASE(16)
+#undef MPPI_R_CASE
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_tile(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
+                              const float *eps, float *cost, float *part, float *noise_out)
+{
+    if (!h->no_rollout.empty()) return hipErrorNotSupported;
+    switch (h->a) {
+    case 1: return launch_tile_a<1>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
+    case 2: return launch_tile_a<2>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
+    case 3: return launch_tile_a<3>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
+    case 4: return launch_tile_a<4>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *recs, int nb, float *U, float *u_out,
+                                float *record_out, int apply, float *U_updated)
+{
+    // a profiled step = the rollout kernel + the finish that applies the update
+    const bool prof = apply && h->prof_n < h->prof_cap;
+    if (prof) { hipError_t e = hipEventRecord(h->ev[4 * h->prof_n + 2], st); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), finish_lds_bytes(h->HA), st, h->dC, recs, nb, U, u_out,
+                       record_out, apply, h->d_step, h->d_dbg, U_updated);
+    hipError_t e = hipGetLastError();
+    if (prof && e == hipSuccess) { e = hipEventRecord(h->ev[4 * h->prof_n + 3], st); h->prof_stream = st; h->prof_n++; }
+    return e;
+}
+
+// rollouts of this shard -> partial records (d_part, nb of them). Handles normalizeCost.
+static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, const float *x_dev, const float *eps, float *noise_out)
+{
+    if (!h->normalize) {
+        const bool prof = h->prof_n < h->prof_cap;
+        if (prof) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 0], st));
+        HIP_TRY(h, launch_tile(h, st, src, MODE_ROLLOUT, x_dev, h->d_U, eps, h->d_cost, h->d_part, noise_out));
+        if (prof) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 1], st));
+        return MPPI_OK;
+    }
+    if (h->shard_count != 1) return fail(h, MPPI_ERR_UNSUPPORTED, "normalize_cost needs the global max cost: unsharded handles only");
+    // Py normalizeCost (controller_base.py:468-474): costs, global min/max, then the update on
+    // c' = (c-min)/(max-min) with the SAME noise (regenerated from the same Philox counters).
+    HIP_TRY(h, launch_tile(h, st, src, MODE_COST_ONLY, x_dev, h->d_U, eps, h->d_cost, h->d_part, noise_out));
+    hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(kFinishThreads), 0, st, h->d_cost, h->K_local, h->d_mm);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(k_cost_normalize, dim3((h->K_local + 255) / 256), dim3(256), 0, st, h->d_cost, h->K_local, h->d_mm, h->d_cost2);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, launch_tile(h, st, src, MODE_COSTS_GIVEN, x_dev, h->d_U, eps, h->d_cost2, h->d_part, nullptr));
+    return MPPI_OK;
+}
+
+static mppi_status ensure_eps(mppi_handle *h)
+{
+    if (!h->d_eps) HIP_TRY(h, hipMalloc((void **)&h->d_eps, sizeof(float) * (size_t)h->K_local * h->HA));
+    return MPPI_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+extern "C" int mppi_record_size(const mppi_handle *h) { return h ? 2 + h->HA : 0; }
+extern "C" int mppi_local_samples(const mppi_handle *h) { return h ? h->K_local : 0; }
+extern "C" int mppi_sample_offset(const mppi_handle *h) { return h ? h->k_offset : 0; }
+
+extern "C" mppi_status mppi_synchronize(mppi_handle *h)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_profile_begin(mppi_handle *h, int max_steps)
+{
+    if (!h || max_steps <= 0 || max_steps > (1 << 20)) return h ? fail(h, MPPI_ERR_INVALID_ARG, "max_steps out of range") : MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    while ((int)h->ev.size() < 4 * max_steps) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    h->prof_n = 0;
+    h->prof_cap = max_steps;
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_profile_end(mppi_handle *h, float *rollout_ms_avg, float *finish_ms_avg, int *n_steps)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = h->prof_n;
+    h->prof_cap = 0;
+    double tr = 0.0, tf = 0.0;
+    if (n > 0) {
+        HIP_TRY(h, hipEventSynchronize(h->ev[4 * (n - 1) + 3]));
+        for (int i = 0; i < n; ++i) {
+            float a = 0.f, b = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&a, h->ev[4 * i + 0], h->ev[4 * i + 1]));
+            HIP_TRY(h, hipEventElapsedTime(&b, h->ev[4 * i + 2], h->ev[4 * i + 3]));
+            tr += a; tf += b;
+        }
+    }
+    if (rollout_ms_avg) *rollout_ms_avg = n ? (float)(tr / n) : 0.f;
+    if (finish_ms_avg) *finish_ms_avg = n ? (float)(tf / n) : 0.f;
+    if (n_steps) *n_steps = n;
+    h->prof_n = 0;
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_set_goal(mppi_handle *h, const float *goal, int n)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (!goal || n != h->s) // "Wrong goal size, it should match the state dimension" controller_base.cpp:127-130
+        return fail(h, MPPI_ERR_INVALID_ARG, "wrong goal size, it should match the state dimension");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int i = 0; i < n; ++i) h->hc.goal[i] = goal[i];
+    return upload_consts(h);
+}
+
+extern "C" mppi_status mppi_next_device(mppi_handle *h, const float *x_dev, float *u_dev, void *stream)
+{
+    if (!h || !x_dev || !u_dev) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL device pointer") : MPPI_ERR_INVALID_ARG;
+    if (h->shard_count != 1) return fail(h, MPPI_ERR_INVALID_ARG, "sharded handle: use mppi_shard_partial / mppi_shard_finish");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr);
+    if (s != MPPI_OK) return s;
+    HIP_TRY(h, launch_finish(h, st, h->d_part, h->nb, h->d_U, u_dev, nullptr, 1, h->d_Uupd));
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_shard_partial(mppi_handle *h, const float *x_dev, float *record_dev, void *stream)
+{
+    if (!h || !x_dev || !record_dev) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL device pointer") : MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr);
+    if (s != MPPI_OK) return s;
+    HIP_TRY(h, launch_finish(h, st, h->d_part, h->nb, h->d_U, h->d_u, record_dev, 0, nullptr));
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_shard_finish(mppi_handle *h, const float *records_dev, int n_records, float *u_dev, void *stream)
+{
+    if (!h || !records_dev || !u_dev || n_records <= 0) return h ? fail(h, MPPI_ERR_INVALID_ARG, "bad records/u pointer or count") : MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    HIP_TRY(h, launch_finish(h, st, records_dev, n_records, h->d_U, u_dev, nullptr, 1, h->d_Uupd));
+    return MPPI_OK;
+}
+
+// host-pointer step shared by mppi_next / mppi_next_with_noise
+static mppi_status step_host(mppi_handle *h, const float *x, int n_x, const float *eps, size_t n_eps, float *u_out, int n_u)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (!x || !u_out || n_x != h->s || n_u != h->a) return fail(h, MPPI_ERR_INVALID_ARG, "x must have s_dim floats and u_out a_dim floats");
+    if (h->shard_count != 1) return fail(h, MPPI_ERR_INVALID_ARG, "sharded handle: use mppi_shard_partial / mppi_shard_finish");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int src = SRC_PHILOX;
+    if (eps) {
+        if (n_eps != (size_t)h->K_local * h->HA) return fail(h, MPPI_ERR_INVALID_ARG, "eps must hold K_local*tau*a floats");
+        mppi_status s = ensure_eps(h);
+        if (s != MPPI_OK) return s;
+        HIP_TRY(h, hipMemcpyAsync(h->d_eps, eps, sizeof(float) * n_eps, hipMemcpyHostToDevice, h->stream));
+        src = SRC_HBM;
+    }
+    std::memcpy(h->h_pin, x, sizeof(float) * h->s);
+    HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_pin, sizeof(float) * h->s, hipMemcpyHostToDevice, h->stream));
+    mppi_status s = enqueue_partials(h, h->stream, src, h->d_x, h->d_eps, nullptr);
+    if (s != MPPI_OK) return s;
+    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, h->nb, h->d_U, h->d_u, nullptr, 1, h->d_Uupd));
+    HIP_TRY(h, hipMemcpyAsync(h->h_pin + kMaxS, h->d_u, sizeof(float) * h->a, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::memcpy(u_out, h->h_pin + kMaxS, sizeof(float) * h->a);
+    // m_db.addX(s); m_db.addU(out_tensor[1])  controller_base.cpp:146-147
+    h->log_x.insert(h->log_x.end(), x, x + h->s);
+    h->log_u.insert(h->log_u.end(), u_out, u_out + h->a);
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_next(mppi_handle *h, const float *x, int n_x, float *u_out, int n_u)
+{
+    return step_host(h, x, n_x, nullptr, 0, u_out, n_u);
+}
+
+extern "C" mppi_status mppi_next_with_noise(mppi_handle *h, const float *x, int n_x, const float *eps, size_t n_eps, float *u_out, int n_u)
+{
+    if (h && !eps) return fail(h, MPPI_ERR_INVALID_ARG, "eps is NULL");
+    return step_host(h, x, n_x, eps, n_eps, u_out, n_u);
+}
+
+extern "C" mppi_status mppi_save_next(mppi_handle *h, const float *x_next, int n)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (!x_next || n != h->s) return fail(h, MPPI_ERR_INVALID_ARG, "x_next must have s_dim floats");
+    h->log_next.insert(h->log_next.end(), x_next, x_next + n); // m_db.addNext controller_base.cpp:159-163
+    return MPPI_OK;
+}
+
+// data_base.cpp:52-71 toCSV: one row per transition, columns x | u | x_next.
+extern "C" mppi_status mppi_to_csv(mppi_handle *h, const char *filename)
+{
+    if (!h || !filename) return h ? fail(h, MPPI_ERR_INVALID_ARG, "filename is NULL") : MPPI_ERR_INVALID_ARG;
+    FILE *f = std::fopen(filename, "w");
+    if (!f) return fail(h, MPPI_ERR_IO, std::string("cannot open ") + filename);
+    const size_t n = std::min(h->log_x.size() / h->s, std::min(h->log_u.size() / h->a, h->log_next.size() / h->s));
+    for (int i = 0; i < h->s; ++i) std::fprintf(f, "x%d,", i);
+    for (int i = 0; i < h->a; ++i) std::fprintf(f, "u%d,", i);
+    for (int i = 0; i < h->s; ++i) std::fprintf(f, "x_next%d%s", i, i + 1 < h->s ? "," : "\n");
+    for (size_t r = 0; r < n; ++r) {
+        for (int i = 0; i < h->s; ++i) std::fprintf(f, "%.9g,", h->log_x[r * h->s + i]);
+        for (int i = 0; i < h->a; ++i) std::fprintf(f, "%.9g,", h->log_u[r * h->a + i]);
+        for (int i = 0; i < h->s; ++i) std::fprintf(f, "%.9g%s", h->log_next[r * h->s + i], i + 1 < h->s ? "," : "\n");
+    }
+    std::fclose(f);
+    return MPPI_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+extern "C" mppi_status mppi_get_action_sequence(mppi_handle *h, float *U, int n)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (!U || n != h->HA) return fail(h, MPPI_ERR_INVALID_ARG, "U must hold tau*a floats");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(U, h->d_U, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_set_action_sequence(mppi_handle *h, const float *U, int n)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (!U || n != h->HA) return fail(h, MPPI_ERR_INVALID_ARG, "U must hold tau*a floats");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->d_U, U, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_get_step_counter(mppi_handle *h, uint64_t *step)
+{
+    if (!h || !step) return MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    unsigned long long v = 0;
+    HIP_TRY(h, hipMemcpyAsync(&v, h->d_step, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *step = v;
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_set_step_counter(mppi_handle *h, uint64_t step)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    unsigned long long v = step;
+    HIP_TRY(h, hipMemcpyAsync(h->d_step, &v, sizeof(v), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_debug_get(mppi_handle *h, int what, float *out, size_t n)
+{
+    if (!h || !out) return h ? fail(h, MPPI_ERR_INVALID_ARG, "out is NULL") : MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t K = (size_t)h->K_local;
+    const float *src = nullptr;
+    size_t need = 0;
+    float *tmp = nullptr;
+    switch (what) {
+    case MPPI_DBG_COSTS: src = h->d_cost; need = K; break;
+    case MPPI_DBG_BETA: src = h->d_dbg; need = 1; break;
+    case MPPI_DBG_ETA: src = h->d_dbg + 1; need = 1; break;
+    case MPPI_DBG_U_UPDATED: src = h->d_Uupd; need = (size_t)h->HA; break;
+    case MPPI_DBG_WEIGHTS: {
+        need = K;
+        if (n != need) return fail(h, MPPI_ERR_INVALID_ARG, "wrong output size");
+        HIP_TRY(h, hipMalloc((void **)&tmp, sizeof(float) * K));
+        hipLaunchKernelGGL(k_weights, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, h->stream, h->dC,
+                           h->normalize ? h->d_cost2 : h->d_cost, (int)K, h->d_dbg, (float *)nullptr, (float *)nullptr, tmp);
+        src = tmp;
+        break;
+    }
+    case MPPI_DBG_NOISE: {
+        // regenerate the noise of the LAST step from its Philox counters (step-1)
+        need = K * (size_t)h->HA;
+        if (n != need) return fail(h, MPPI_ERR_INVALID_ARG, "wrong output size");
+        mppi_status s = ensure_eps(h);
+        if (s != MPPI_OK) return s;
+        unsigned long long cur = 0;
+        HIP_TRY(h, hipMemcpyAsync(&cur, h->d_step, sizeof(cur), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (cur == 0) return fail(h, MPPI_ERR_INVALID_ARG, "no step has run yet");
+        unsigned long long prev = cur - 1;
+        HIP_TRY(h, hipMemcpyAsync(h->d_step, &prev, sizeof(prev), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, launch_tile(h, h->stream, SRC_PHILOX, MODE_COST_ONLY, h->d_x, h->d_U, nullptr, h->d_cost2, h->d_part, h->d_eps));
+        HIP_TRY(h, hipMemcpyAsync(h->d_step, &cur, sizeof(cur), hipMemcpyHostToDevice, h->stream));
+        src = h->d_eps;
+        break;
+    }
+    default: return fail(h, MPPI_ERR_INVALID_ARG, "unknown debug item");
+    }
+    if (n != need) { if (tmp) (void)hipFree(tmp); return fail(h, MPPI_ERR_INVALID_ARG, "wrong output size"); }
+    hipError_t e = hipMemcpyAsync(out, src, sizeof(float) * need, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (tmp) (void)hipFree(tmp);
+    HIP_TRY(h, e);
+    return MPPI_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// helpers: scratch device buffers for the host-pointer helper entry points
+struct DevBuf {
+    float *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, sizeof(float) * (n ? n : 1)); }
+    hipError_t up(const float *src, size_t n, hipStream_t st) { return hipMemcpyAsync(p, src, sizeof(float) * n, hipMemcpyHostToDevice, st); }
+    hipError_t down(float *dst, size_t n, hipStream_t st) const { return hipMemcpyAsync(dst, p, sizeof(float) * n, hipMemcpyDeviceToHost, st); }
+};
+
+extern "C" mppi_status mppi_model_step(mppi_handle *h, const float *x, int kx, const float *v, int k,
+                                       float *out_free, float *out_action, float *out_next)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (!x || !v || k <= 0 || (kx != k && kx != 1)) return fail(h, MPPI_ERR_INVALID_ARG, "x is [kx,s] with kx in {1,k}; v is [k,a]");
+    if (h->hc.model_kind != MPPI_MODEL_POINT_MASS) return fail(h, MPPI_ERR_UNSUPPORTED, "free/action split exists for the point-mass model only");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int s = h->s, a = h->a;
+    DevBuf dx, dv, df, da, dn;
+    HIP_TRY(h, dx.alloc((size_t)kx * s)); HIP_TRY(h, dv.alloc((size_t)k * a));
+    HIP_TRY(h, df.alloc((size_t)kx * s)); HIP_TRY(h, da.alloc((size_t)k * s)); HIP_TRY(h, dn.alloc((size_t)k * s));
+    HIP_TRY(h, dx.up(x, (size_t)kx * s, h->stream)); HIP_TRY(h, dv.up(v, (size_t)k * a, h->stream));
+    const dim3 g((k + 255) / 256), b(256);
+#define MPPI_MS_CASE(AA) case AA: hipLaunchKernelGGL(k_model_step<AA>, g, b, 0, h->stream, h->dC, dx.p, kx, dv.p, k, s, a, df.p, da.p, dn.p); break;
+    switch (a) {
+        MPPI_MS_CASE(1) MPPI_MS_CASE(2) MPPI_MS_CASE(3) MPPI_MS_CASE(4)
+    default: hipLaunchKernelGGL(k_model_step<kMaxA>, g, b, 0, h->stream, h->dC, dx.p, kx, dv.p, k, s, a, df.p, da.p, dn.p); break;
+    }
+#undef MPPI_MS_CASE
+    HIP_TRY(h, hipGetLastError());
+    if (out_free) HIP_TRY(h, df.down(out_free, (size_t)kx * s, h->stream));
+    if (out_action) HIP_TRY(h, da.down(out_action, (size_t)k * s, h->stream));
+    if (out_next) HIP_TRY(h, dn.down(out_next, (size_t)k * s, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
+template <int S, int A>
+static void launch_costs_sa(mppi_handle *h, const float *x, const float *u, const float *eps, int k, float *os, float *oa, float *ot)
+{
+    const dim3 g((k + 255) / 256), b(256);
+    if (h->hc.q_full) hipLaunchKernelGGL((k_costs<S, A, true>), g, b, 0, h->stream, h->dC, x, u, eps, k, h->s, h->a, os, oa, ot);
+    else hipLaunchKernelGGL((k_costs<S, A, false>), g, b, 0, h->stream, h->dC, x, u, eps, k, h->s, h->a, os, oa, ot);
+}
+
+// state / action / step cost of k samples; x may be NULL (action cost only), u/eps may be NULL (state only)
+static mppi_status costs_host(mppi_handle *h, const float *x, const float *u, const float *eps, int k,
+                              float *out_state, float *out_action, float *out_step)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (k <= 0 || (!x && !u) || ((u == nullptr) != (eps == nullptr))) return fail(h, MPPI_ERR_INVALID_ARG, "bad cost arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int s = h->s, a = h->a;
+    DevBuf dx, du, de, ds, da, dt;
+    HIP_TRY(h, dx.alloc((size_t)k * s)); HIP_TRY(h, du.alloc(a)); HIP_TRY(h, de.alloc((size_t)k * a));
+    HIP_TRY(h, ds.alloc(k)); HIP_TRY(h, da.alloc(k)); HIP_TRY(h, dt.alloc(k));
+    if (x) HIP_TRY(h, dx.up(x, (size_t)k * s, h->stream));
+    if (u) { HIP_TRY(h, du.up(u, a, h->stream)); HIP_TRY(h, de.up(eps, (size_t)k * a, h->stream)); }
+    const float *px = x ? dx.p : nullptr, *pu = u ? du.p : nullptr, *pe = u ? de.p : nullptr;
+    // shapes of the reference's own tests + the point-mass family run exact instances
+    if (s == 2 && a == 1) launch_costs_sa<2, 1>(h, px, pu, pe, k, ds.p, da.p, dt.p);
+    else if (s == 2 && a == 2) launch_costs_sa<2, 2>(h, px, pu, pe, k, ds.p, da.p, dt.p);
+    else if (s == 4 && a == 2) launch_costs_sa<4, 2>(h, px, pu, pe, k, ds.p, da.p, dt.p);
+    else if (s == 4 && a == 3) launch_costs_sa<4, 3>(h, px, pu, pe, k, ds.p, da.p, dt.p);
+    else if (s == 6 && a == 3) launch_costs_sa<6, 3>(h, px, pu, pe, k, ds.p, da.p, dt.p);
+    else if (s == 8 && a == 4) launch_costs_sa<8, 4>(h, px, pu, pe, k, ds.p, da.p, dt.p);
+    else launch_costs_sa<kMaxS, kMaxA>(h, px, pu, pe, k, ds.p, da.p, dt.p);
+    HIP_TRY(h, hipGetLastError());
+    if (out_state) HIP_TRY(h, ds.down(out_state, k, h->stream));
+    if (out_action) HIP_TRY(h, da.down(out_action, k, h->stream));
+    if (out_step) HIP_TRY(h, dt.down(out_step, k, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_state_cost(mppi_handle *h, const float *x, int k, float *out)
+{
+    if (h && (!x || !out)) return fail(h, MPPI_ERR_INVALID_ARG, "NULL pointer");
+    return costs_host(h, x, nullptr, nullptr, k, out, nullptr, nullptr);
+}
+
+extern "C" mppi_status mppi_action_cost(mppi_handle *h, const float *u, const float *eps, int k, float *out)
+{
+    if (h && (!u || !eps || !out)) return fail(h, MPPI_ERR_INVALID_ARG, "NULL pointer");
+    return costs_host(h, nullptr, u, eps, k, nullptr, out, nullptr);
+}
+
+extern "C" mppi_status mppi_step_cost(mppi_handle *h, const float *x, const float *u, const float *eps, int k, float *out)
+{
+    if (h && (!x || !u || !eps || !out)) return fail(h, MPPI_ERR_INVALID_ARG, "NULL pointer");
+    return costs_host(h, x, u, eps, k, nullptr, nullptr, out);
+}
+
+extern "C" mppi_status mppi_rollout_cost(mppi_handle *h, const float *x, const float *U, const float *eps, float *cost_out)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (!x || !U || !eps || !cost_out) return fail(h, MPPI_ERR_INVALID_ARG, "NULL pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    mppi_status s = ensure_eps(h);
+    if (s != MPPI_OK) return s;
+    DevBuf dx, dU, dc;
+    HIP_TRY(h, dx.alloc(h->s)); HIP_TRY(h, dU.alloc(h->HA)); HIP_TRY(h, dc.alloc(h->K_local));
+    HIP_TRY(h, dx.up(x, h->s, h->stream)); HIP_TRY(h, dU.up(U, h->HA, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_eps, eps, sizeof(float) * (size_t)h->K_local * h->HA, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, launch_tile(h, h->stream, SRC_HBM, MODE_COST_ONLY, dx.p, dU.p, h->d_eps, dc.p, h->d_part, nullptr));
+    HIP_TRY(h, dc.down(cost_out, h->K_local, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_update(mppi_handle *h, const float *cost, const float *eps, const float *U,
+                                   float *beta, float *exp_arg, float *exp_out, float *nabla, float *weights,
+                                   float *weighted_noise, float *U_new)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (!cost || !eps || !U) return fail(h, MPPI_ERR_INVALID_ARG, "NULL pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    mppi_status s = ensure_eps(h);
+    if (s != MPPI_OK) return s;
+    const int K = h->K_local, HA = h->HA;
+    DevBuf dU, dc, drec, darg, dexp, dw, dUn, du;
+    HIP_TRY(h, dU.alloc(HA)); HIP_TRY(h, dc.alloc(K)); HIP_TRY(h, drec.alloc(2 + HA));
+    HIP_TRY(h, darg.alloc(K)); HIP_TRY(h, dexp.alloc(K)); HIP_TRY(h, dw.alloc(K)); HIP_TRY(h, dUn.alloc(HA)); HIP_TRY(h, du.alloc(kMaxA));
+    HIP_TRY(h, dU.up(U, HA, h->stream)); HIP_TRY(h, dc.up(cost, K, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_eps, eps, sizeof(float) * (size_t)K * HA, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, launch_tile(h, h->stream, SRC_HBM, MODE_COSTS_GIVEN, h->d_x, dU.p, h->d_eps, dc.p, h->d_part, nullptr));
+    // record = (beta, eta, V); then U' on a scratch copy of U (apply shifts it, so read U_updated)
+    unsigned long long step_before = 0;
+    HIP_TRY(h, hipMemcpyAsync(&step_before, h->d_step, sizeof(step_before), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, h->nb, dU.p, du.p, drec.p, 1, dUn.p));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_step, &step_before, sizeof(step_before), hipMemcpyHostToDevice, h->stream)); // stateless call
+    hipLaunchKernelGGL(k_weights, dim3((K + 255) / 256), dim3(256), 0, h->stream, h->dC, dc.p, K, drec.p, darg.p, dexp.p, dw.p);
+    HIP_TRY(h, hipGetLastError());
+    std::vector<float> rec(2 + HA), Un(HA);
+    HIP_TRY(h, drec.down(rec.data(), 2 + HA, h->stream));
+    HIP_TRY(h, dUn.down(Un.data(), HA, h->stream));
+    if (exp_arg) HIP_TRY(h, darg.down(exp_arg, K, h->stream));
+    if (exp_out) HIP_TRY(h, dexp.down(exp_out, K, h->stream));
+    if (weights) HIP_TRY(h, dw.down(weights, K, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (beta) *beta = rec[0];
+    if (nabla) *nabla = rec[1];
+    if (weighted_noise) for (int c = 0; c < HA; ++c) weighted_noise[c] = (float)((double)rec[2 + c] / (double)rec[1]);
+    if (U_new) std::memcpy(U_new, Un.data(), sizeof(float) * HA);
+    return MPPI_OK;
+}
+
+// mGetNew (controller_base.cpp:326-329) / mShift (:314-324): pure slices, host side.
+extern "C" mppi_status mppi_get_new(const float *U, int tau, int a, int nb, float *out)
+{
+    if (!U || (!out && nb > 0) || nb < 0 || nb > tau || a <= 0) return MPPI_ERR_INVALID_ARG;
+    for (int i = 0; i < nb * a; ++i) out[i] = U[i];
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_shift(const float *U, int tau, int a, const float *init, int nb_init, int nb, float *out)
+{
+    if (!U || !out || nb < 0 || nb > tau || nb_init < 0 || a <= 0) return MPPI_ERR_INVALID_ARG;
+    int o = 0;
+    for (int i = nb * a; i < tau * a; ++i) out[o++] = U[i];
+    for (int i = 0; i < nb_init * a; ++i) out[o++] = init ? init[i] : 0.0f; // mInit0: zeros
+    return MPPI_OK;
+}

@@ -1,0 +1,309 @@
+// mppi_kernels.hip.h — the HIP kernels of the MPPI control step (gfx950). See mppi_device.hip.h
+// for the arithmetic and DESIGN.md §3 for the data layout and the roofline of each kernel.
+#pragma once
+
+#include "mppi_device.hip.h"
+
+namespace mppi {
+
+enum NoiseSrc { SRC_PHILOX = 0, SRC_HBM = 1 };
+enum TileMode {
+    MODE_ROLLOUT = 0,     // phase A + B (costs) + C (tile soft-min record)
+    MODE_COSTS_GIVEN = 1, // phase A + C with costs read from `cost` (mUpdate on given costs; normalize pass 2)
+    MODE_COST_ONLY = 2    // phase A + B, no record (mBuildModelGraph alone; normalize pass 1)
+};
+
+// LDS floats a tile needs: eps[HA][R+1] (padded: lane-per-rollout reads AND lane-per-column reads
+// are both conflict-free on the 32-bank ds_read_b32 path), w[R], U[HA], 8 scratch.
+__host__ __device__ inline size_t tile_lds_floats(int HA, int R) { return (size_t)HA * (R + 1) + R + HA + 8; }
+
+// ----------------------------------------------------------------------------------------
+// k_rollout_tile: rows A3–A9 of SURVEY §8a fused (mPrepareAction/mPrepareNoise slicing,
+// model step, step cost, terminal cost, tile-local min/exp/sum and weighted noise).
+// grid = ceil(K_local / R) workgroups of 256 threads; dynamic LDS = tile_lds_floats(H*A, R)*4.
+// Tiles are independent and share no HBM operand but x[s] and U[H,a] (≤ 1.5 KB), so the
+// blockIdx→tile map needs no XCD remap.
+template <int A, int R, bool QFULL, int SRC, int MODE>
+__global__ __launch_bounds__(kThreads) void k_rollout_tile(
+    const DevConsts *__restrict__ C, const float *__restrict__ x_dev, const float *__restrict__ U_dev,
+    const float *__restrict__ eps_hbm, const unsigned long long *__restrict__ step_ctr,
+    float *__restrict__ cost, float *__restrict__ partials, float *__restrict__ noise_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int S = 2 * A;
+    constexpr int RP = R + 1;
+    const int H = C->H;
+    const int HA = H * A;
+    const int K = C->K_local;
+    float *eps_s = smem;
+    float *w_s = eps_s + (size_t)HA * RP;
+    float *U_s = w_s + R;
+    float *red_s = U_s + HA;
+
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * R;
+
+    for (int i = tid; i < HA; i += kThreads) U_s[i] = U_dev[i];
+
+    // ---- phase A: the tile's noise -> LDS, eps_s[(t*A+j)*RP + kl] --------------------------
+    if (SRC == SRC_PHILOX) {
+        constexpr int TQ = kThreads / R; // horizon slots generated concurrently per rollout
+        const int kl = tid % R;
+        const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)(k0 + kl);
+        const unsigned long long base = step_ctr[0] * (unsigned long long)H;
+        const unsigned long long seed = C->seed;
+        for (int t = tid / R; t < H; t += TQ) {
+            float z[A], e[A];
+            normals_at<A>(seed, gk, base + (unsigned long long)t, z);
+            scale_noise<A>(C, z, e);
+#pragma unroll
+            for (int j = 0; j < A; ++j) eps_s[(t * A + j) * RP + kl] = e[j];
+        }
+    } else {
+        // injected noise: coalesced dword read of the tile's contiguous [R, H*A] slab
+        const size_t slab = (size_t)k0 * HA;
+        const int n = R * HA;
+        for (int i = tid; i < n; i += kThreads) {
+            const int kl = i / HA, c = i - kl * HA;
+            eps_s[c * RP + kl] = (k0 + kl < K) ? eps_hbm[slab + i] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    if (noise_out != nullptr) { // debug export (MPPI_DBG_NOISE): the noise this step used
+        const size_t slab = (size_t)k0 * HA;
+        const int n = R * HA;
+        for (int i = tid; i < n; i += kThreads) {
+            const int kl = i / HA, c = i - kl * HA;
+            if (k0 + kl < K) noise_out[slab + i] = eps_s[c * RP + kl];
+        }
+    }
+
+    // ---- phase B: one lane per rollout, wave 0 ---------------------------------------------
+    if (tid < 64) {
+        const bool valid = (tid < R) && (k0 + tid < K);
+        const int kl = tid < R ? tid : R - 1;
+        float c = 0.0f;
+        if (MODE != MODE_COSTS_GIVEN) {
+            float x[S];
+#pragma unroll
+            for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+            for (int t = 0; t < H; ++t) {
+                float u[A], e[A], v[A];
+#pragma unroll
+                for (int j = 0; j < A; ++j) {
+                    u[j] = U_s[t * A + j];              // mPrepareAction  controller_base.cpp:205-208
+                    e[j] = eps_s[(t * A + j) * RP + kl]; // mPrepareNoise   controller_base.cpp:210-213
+                    v[j] = u[j] + e[j];                  // to_apply        controller_base.cpp:258
+                }
+                pm_step<A>(C, x, v);
+                const float sc = state_cost<S, QFULL>(C, x);  // cost on the POST-step state
+                const float ac = action_cost<A>(C, u, e);
+                const float tmp = sc + ac;                    // Step_cost_result cost_base.cpp:49
+                c = c + tmp;                                  // path_cost        controller_base.cpp:268
+            }
+            c = c + state_cost<S, QFULL>(C, x); // terminal: x_H counted a second time, :271-272
+            if (valid) cost[k0 + tid] = c;
+        } else {
+            c = valid ? cost[k0 + tid] : 0.0f;
+        }
+        if (MODE != MODE_COST_ONLY) {
+            // tile-local mBeta / mExpArg / mExp / mNabla (controller_base.cpp:166-182)
+            const float beta = wave_min(valid ? c : INFINITY);
+            const float arg = C->neg_inv_lambda * (c - beta);
+            const float ek = valid ? expf(arg) : 0.0f;
+            const float eta = wave_sum(ek);
+            if (tid < R) w_s[tid] = ek;
+            if (tid == 0) { red_s[0] = beta; red_s[1] = eta; }
+        }
+    }
+    if (MODE == MODE_COST_ONLY) return;
+    __syncthreads();
+
+    // ---- phase C: V_b[c] = Σ_k e_k·eps[k,c] in fixed k order (mWeightedNoise, :188-192) -----
+    float *rec = partials + (size_t)blockIdx.x * (2 + HA);
+    if (tid == 0) { rec[0] = red_s[0]; rec[1] = red_s[1]; }
+    for (int c = tid; c < HA; c += kThreads) {
+        const float *row = eps_s + (size_t)c * RP;
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int kl = 0; kl < R; ++kl) acc = acc + w_s[kl] * row[kl];
+        rec[2 + c] = acc;
+    }
+}
+
+__host__ __device__ inline size_t finish_lds_bytes(int HA) { return (size_t)(kFinishThreads + HA + 1) * 8 + 64; }
+
+// ----------------------------------------------------------------------------------------
+// k_finish: fixed-order combine of nb records (beta_b, eta_b, V_b[HA]) laid out [nb, 2+HA]:
+//   beta = min_b beta_b ; r_b = exp(-(beta_b-beta)/λ) ; eta = Σ r_b eta_b ; V = Σ r_b V_b
+// then either emit ONE record (beta, eta, V) for the shard exchange, and/or
+// apply  U' = U + V/eta ; u = U'[0] ; U <- concat(U'[1:], 0)   (mBuildUpdateGraph :223,
+// mGetNew :326-329, mShift+mInit0 :310-324) and advance the Philox step counter.
+// The sums run in double: nb·(HA+1) adds, negligible next to the rollouts.
+// One workgroup of 1024 threads; dynamic LDS = finish_lds_bytes(HA).
+__global__ __launch_bounds__(kFinishThreads) void k_finish(
+    const DevConsts *__restrict__ C, const float *__restrict__ recs, int nb,
+    float *__restrict__ U, float *__restrict__ u_out, float *__restrict__ record_out, int apply,
+    unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg, float *__restrict__ U_updated)
+{
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    const int HA = C->H * C->a;
+    const int a = C->a;
+    const int ncol = HA + 1; // column 0 = eta, columns 1..HA = V
+    const int stride = 2 + HA;
+    double *part_s = fsm;                  // [kFinishThreads]
+    double *tot_s = fsm + kFinishThreads;  // [ncol]
+    float *beta_s = reinterpret_cast<float *>(tot_s + ncol); // [kFinishThreads/64]
+    const int tid = threadIdx.x;
+
+    float bmin = INFINITY;
+    for (int b = tid; b < nb; b += kFinishThreads) bmin = fminf(bmin, recs[(size_t)b * stride]);
+    bmin = wave_min(bmin);
+    if ((tid & 63) == 0) beta_s[tid >> 6] = bmin;
+    __syncthreads();
+    float beta = beta_s[0];
+#pragma unroll
+    for (int w = 1; w < kFinishThreads / 64; ++w) beta = fminf(beta, beta_s[w]);
+
+    const float nil = C->neg_inv_lambda;
+    for (int col0 = 0; col0 < ncol; col0 += kFinishThreads) {
+        const int ncp = min(ncol - col0, kFinishThreads); // columns in this pass
+        const int G = kFinishThreads / ncp;               // record groups summed concurrently
+        const int col = tid % ncp, g = tid / ncp;
+        double acc = 0.0;
+        if (g < G) {
+            for (int b = g; b < nb; b += G) {
+                const float *r = recs + (size_t)b * stride;
+                const float rb = expf(nil * (r[0] - beta));
+                acc += (double)rb * (double)r[1 + col0 + col];
+            }
+        }
+        part_s[tid] = acc;
+        __syncthreads();
+        if (g == 0) {
+            double t = part_s[col];
+            for (int gg = 1; gg < G; ++gg) t += part_s[gg * ncp + col];
+            tot_s[col0 + col] = t;
+        }
+        __syncthreads();
+    }
+
+    const double eta = tot_s[0];
+    if (record_out != nullptr) {
+        if (tid == 0) { record_out[0] = beta; record_out[1] = (float)eta; }
+        for (int c = tid; c < HA; c += kFinishThreads) record_out[2 + c] = (float)tot_s[1 + c];
+    }
+    if (dbg != nullptr && tid == 0) { dbg[0] = beta; dbg[1] = (float)eta; }
+    if (apply) {
+        // every thread reads its U'[c] before anyone writes the shifted sequence
+        for (int c0 = 0; c0 < HA; c0 += kFinishThreads) {
+            const int c = c0 + tid;
+            float un = 0.0f;
+            if (c < HA) {
+                const float wn = (float)(tot_s[1 + c] / eta);
+                un = U[c] + wn;
+                if (U_updated != nullptr) U_updated[c] = un;
+            }
+            __syncthreads();
+            if (c < HA) {
+                if (c < a) u_out[c] = un; else U[c - a] = un;
+                if (c >= HA - a) U[c] = 0.0f;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) step_ctr[0] = step_ctr[0] + 1ull;
+    }
+}
+
+// min / max of the costs (Py normalizeCost, controller_base.py:468-474): out[0]=min, out[1]=max-min
+__global__ __launch_bounds__(kFinishThreads) void k_cost_minmax(const float *__restrict__ cost, int K, float *__restrict__ out)
+{
+    __shared__ float mn_s[kFinishThreads / 64], mx_s[kFinishThreads / 64];
+    const int tid = threadIdx.x;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = tid; i < K; i += kFinishThreads) { const float c = cost[i]; mn = fminf(mn, c); mx = fmaxf(mx, c); }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if ((tid & 63) == 0) { mn_s[tid >> 6] = mn; mx_s[tid >> 6] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kFinishThreads / 64; ++w) { mn = fminf(mn, mn_s[w]); mx = fmaxf(mx, mx_s[w]); }
+        out[0] = mn; out[1] = mx - mn;
+    }
+}
+
+// c' = (c - min)/(max - min)  (norm_arg with normalize=True, controller_base.py:468-474)
+__global__ void k_cost_normalize(const float *__restrict__ cost, int K, const float *__restrict__ mm, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) out[i] = (cost[i] - mm[0]) / mm[1];
+}
+
+// Per-sample intermediates of the update for inspection (mExpArg, mExp, mWeights :170-186)
+__global__ void k_weights(const DevConsts *__restrict__ C, const float *__restrict__ cost, int K,
+                          const float *__restrict__ beta_eta, float *__restrict__ arg_out,
+                          float *__restrict__ exp_out, float *__restrict__ w_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const float arg = C->neg_inv_lambda * (cost[i] - beta_eta[0]);
+    const float e = expf(arg);
+    if (arg_out) arg_out[i] = arg;
+    if (exp_out) exp_out[i] = e;
+    if (w_out) w_out[i] = e / beta_eta[1];
+}
+
+// ----------------------------------------------------------------------------------------
+// The reference's public graph helpers as kernels (one thread per sample) — the SAME device
+// functions the tile kernel runs, so the reference's known-answer vectors exercise them.
+// Shapes outside the instantiated set run the zero-padded <kMaxS,kMaxA> instance (adding
+// exact zeros does not change any sum).
+template <int A>
+__global__ void k_model_step(const DevConsts *__restrict__ C, const float *__restrict__ x, int kx,
+                             const float *__restrict__ v, int k, int s, int a,
+                             float *__restrict__ out_free, float *__restrict__ out_action, float *__restrict__ out_next)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    constexpr int S = 2 * A;
+    float xs[S], vs[A], fr[S], ac[S];
+    const float *xi = x + (size_t)(kx == 1 ? 0 : i) * s;
+#pragma unroll
+    for (int j = 0; j < S; ++j) xs[j] = j < s ? xi[j] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < A; ++j) vs[j] = j < a ? v[(size_t)i * a + j] : 0.0f;
+    pm_free_step<A>(C, xs, fr);
+    pm_action_step<A>(C, vs, ac);
+    for (int j = 0; j < s; ++j) {
+        if (out_free && (kx != 1 || i == 0)) out_free[(size_t)(kx == 1 ? 0 : i) * s + j] = fr[j];
+        if (out_action) out_action[(size_t)i * s + j] = ac[j];
+        if (out_next) out_next[(size_t)i * s + j] = fr[j] + ac[j];
+    }
+}
+
+template <int S, int A, bool QFULL>
+__global__ void k_costs(const DevConsts *__restrict__ C, const float *__restrict__ x, const float *__restrict__ u,
+                        const float *__restrict__ eps, int k, int s, int a,
+                        float *__restrict__ out_state, float *__restrict__ out_action, float *__restrict__ out_step)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    float sc = 0.0f, ac = 0.0f;
+    if (x != nullptr) {
+        float xs[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) xs[j] = j < s ? x[(size_t)i * s + j] : 0.0f;
+        sc = state_cost<S, QFULL>(C, xs);
+    }
+    if (u != nullptr) {
+        float us[A], es[A];
+#pragma unroll
+        for (int j = 0; j < A; ++j) { us[j] = j < a ? u[j] : 0.0f; es[j] = j < a ? eps[(size_t)i * a + j] : 0.0f; }
+        ac = action_cost<A>(C, us, es);
+    }
+    if (out_state) out_state[i] = sc;
+    if (out_action) out_action[i] = ac;
+    if (out_step) out_step[i] = sc + ac;
+}
+
+} // namespace mppi

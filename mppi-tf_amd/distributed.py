@@ -1,0 +1,76 @@
+"""K-sharding of the MPPI step across GPUs: one process per GPU, ONE collective per control step.
+
+SURVEY.md §8e (new work — the reference is single-device): rank g owns samples
+[g·K/G, (g+1)·K/G); x, U, goal, Σ⁻¹ are replicated; Philox counters use the GLOBAL sample index,
+so results do not depend on G.  Per control step each rank
+  1. rolls its shard and reduces it to one record (β_g, η_g, V_g[tau·a])       (HIP kernels)
+  2. all-gathers the records: G·(2+tau·a) floats, e.g. 8 × 386 × 4 B = 12.4 KB (RCCL over xGMI;
+     latency-bound, far below any per-link bandwidth limit)
+  3. combines them in rank order with r_g = exp(-(β_g-β)/λ) and applies U' = U + V/η, shift —
+     replicated on every rank, bit-identical across ranks (same inputs, same fixed order).
+torch is plumbing here: device buffers, the current stream, and torch.distributed (backend
+"nccl" is RCCL on ROCm; "gloo" drives the CPU test of this file's logic with a test backend).
+"""
+import torch
+import torch.distributed as dist
+
+
+class HipShardBackend:
+    """The product backend: this rank's shard on its GPU through the C-ABI (mppi_shard_partial /
+    mppi_shard_finish). Fails loudly when the HIP library or the GPU is missing."""
+
+    def __init__(self, rank, world, device_index=0, **cfg):
+        from ._lib import Handle
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipShardBackend needs a GPU: there is no CPU fallback")
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        self.h = Handle(shard_rank=rank, shard_count=world, device=device_index, **cfg)
+        self.record_size, self.a = self.h.record_size, self.h.a
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def partial(self, x, record):
+        self.h.shard_partial(x.data_ptr(), record.data_ptr(), self._stream())
+
+    def finish(self, records, n_records, u):
+        self.h.shard_finish(records.data_ptr(), n_records, u.data_ptr(), self._stream())
+
+    def action_sequence(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        return torch.from_numpy(self.h.get_action_sequence())
+
+
+class ShardedController:
+    """next(x) on every rank of `group` = one MPPI control step over all K samples.
+
+    backend: an object with .device, .record_size, .a, .partial(x, record), .finish(records, n, u)
+    (default: HipShardBackend built from cfg; tests inject a CPU test double over gloo).
+    """
+
+    def __init__(self, backend=None, group=None, device_index=0, **cfg):
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.backend = backend if backend is not None else HipShardBackend(self.rank, self.world, device_index, **cfg)
+        dev, n = self.backend.device, self.backend.record_size
+        self.record = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.records = torch.zeros(self.world * n, dtype=torch.float32, device=dev)
+        self.u = torch.zeros(self.backend.a, dtype=torch.float32, device=dev)
+
+    def next(self, x):
+        """x: float32 tensor [s] on the backend's device (replicated on every rank). Returns u [a]
+        (device tensor, valid in stream order; identical on every rank)."""
+        self.backend.partial(x, self.record)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.records, self.record, group=self.group)
+            self.backend.finish(self.records, self.world, self.u)
+        else:
+            self.backend.finish(self.record, 1, self.u)
+        return self.u
+
+
+def shard_bounds(k, rank, world):
+    """[lo, hi) of the samples rank owns — the same integer arithmetic as mppi_create."""
+    return rank * k // world, (rank + 1) * k // world

@@ -1,0 +1,82 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/mppi_c.h declares, the ctypes binding covers them all, and the product fails loudly
+(no CPU fallback) when there is no GPU. No compute calls."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "mppi_c.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mppi_[a-z_0-9]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__
+    __graft_entry__.build()
+    import mppi_tf_amd
+    return mppi_tf_amd
+
+
+def test_header_declares_the_reference_surface():
+    names = declared_functions()
+    for must in ("mppi_create", "mppi_destroy", "mppi_next", "mppi_next_with_noise", "mppi_set_goal",
+                 "mppi_save_next", "mppi_to_csv", "mppi_rollout_cost", "mppi_update", "mppi_shard_partial",
+                 "mppi_shard_finish"):
+        assert must in names
+    assert len(names) >= 30
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load()
+    from mppi_tf_amd import _lib
+    names = declared_functions()
+    for n in names:
+        assert hasattr(lib, n), "libmppi_hip.so does not export " + n
+    assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
+    assert lib.mppi_abi_version() == 1
+    assert b"gfx950" in lib.mppi_version()
+    assert lib.mppi_status_string(4) == b"unsupported shape or option"
+
+
+def test_shared_object_is_in_tree_and_has_gfx950_code(pkg):
+    from mppi_tf_amd import _lib
+    assert os.path.dirname(_lib.SO_PATH) == os.path.join(ROOT, "mppi-tf_amd")
+    blob = open(_lib.SO_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_rollout_tile" in blob and b"k_finish" in blob
+
+
+def test_product_never_references_the_oracle():
+    """The oracle is test infrastructure: nothing under mppi-tf_amd/ or include/ may name it."""
+    for base in ("mppi-tf_amd", "include"):
+        for d, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
+                    txt = open(os.path.join(d, f), errors="ignore").read()
+                    assert "oracle" not in txt.lower(), os.path.join(d, f)
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_a_gpu(pkg):
+    with pytest.raises(pkg.MppiError) as e:
+        pkg.Handle(k=8, tau=4, s_dim=2, a_dim=1)
+    assert e.value.status == 2 and "no CPU path" in str(e.value)
+    with pytest.raises(pkg.MppiError):
+        pkg.PointMassModel(1.0, 0.1, 2, 1)
+
+
+def test_host_side_slices_need_no_gpu(pkg):
+    """mGetNew / mShift are host-side slices in the C-ABI (controller_base.cpp:310-329)."""
+    import numpy as np
+    from conftest import load_golden
+    from mppi_tf_amd import _lib
+    g = load_golden("controller_getnew_shift")
+    for nb, exp in g["getnew"].items():
+        np.testing.assert_array_equal(_lib.get_new(g["action"], int(nb)), np.asarray(exp, np.float32).reshape(int(nb), 2))
+    for case in g["shift"]:
+        np.testing.assert_array_equal(_lib.shift(g["action"], case["init"], case["nb"]), np.asarray(case["expected"], np.float32))

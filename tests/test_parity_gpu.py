@@ -1,0 +1,366 @@
+"""Parity of the HIP path (through the C-ABI, libmppi_hip.so) against the CPU oracle and the
+reference's golden vectors. Needs an MI355X: every test is marked `gpu`.
+
+Bars (BASELINE.json north_star): control-update numerics within 1e-5 of the reference path on
+identical noise; sample costs are additionally required to be BIT-IDENTICAL to the oracle's
+unfused fp32 evaluation (both sides are compiled without FMA contraction).
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_float_eq, load_golden
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+F32 = np.float32
+U_TOL = 1e-5  # stated fp32 tolerance on the control update (absolute, on U' and u)
+
+
+@pytest.fixture(scope="module")
+def m():
+    import mppi_tf_amd
+    assert mppi_tf_amd.load().mppi_device_count() >= 1, "no GPU visible to libmppi_hip.so"
+    return mppi_tf_amd
+
+
+GOAL3 = [1, 0, .5, 0, .75, 0]  # position = MuJoCo target site, velocity 0
+
+
+def make_pair(m, K, H, a, dt=0.1, mass=1.0, lam=1.0, sigma=None, goal=None, Q=None, q_full=False,
+              action_cost=0, gamma=1.0, upsilon=1.0, normalize=False, seed=1, **kw):
+    s = 2 * a
+    sigma = np.eye(a) * 0.25 if sigma is None else sigma
+    goal = (GOAL3[:s] if goal is None else goal)
+    Q = np.ones(s) if Q is None else Q
+    h = m.Handle(k=K, tau=H, s_dim=s, a_dim=a, dt=dt, mass=mass, lam=lam, sigma=sigma, goal=goal, Q=Q,
+                 q_is_full=q_full, action_cost=action_cost, gamma=gamma, upsilon=upsilon,
+                 normalize_cost=normalize, seed=seed, **kw)
+    p = orc.Problem(tau=H, s=s, a=a, dt=dt, mass=mass, lam=lam, sigma=sigma, goal=goal, Q=Q,
+                    action_cost=action_cost, gamma=gamma, upsilon=upsilon, threads=0)
+    return h, p
+
+
+# =============================================================== golden vectors through the C-ABI
+@pytest.mark.parametrize("idx", range(4))
+def test_golden_model_step_cpp(m, idx):
+    """test/test_model.cpp:120-255 (StepTesting1/2, LargeTesting, InitTest) on the device."""
+    sc = load_golden("model_cpp")["scenarios"][idx]
+    mod = m.PointMassModel(sc["mass"], sc["dt"], sc["s"], sc["a"])
+    st, ac = np.asarray(sc["state"])[..., None], np.asarray(sc["action"])[..., None]
+    free = mod.build_free_step_graph("", st)
+    assert free.shape == (len(sc["exp_free"]), sc["s"], 1)
+    assert_float_eq(free, sc["exp_free"], what="free")
+    assert_float_eq(mod.build_action_step_graph("", ac), sc["exp_action"], what="action")
+    res = mod.build_step_graph("", st, ac)
+    assert res.shape == (len(sc["action"]), sc["s"], 1)
+    assert_float_eq(res, sc["exp_result"], what="result")
+
+
+def test_golden_model_step_py(m):
+    """scripts/test.py:43-218 incl. the 3-step recurrence; fp32 device vs fp64 expectations."""
+    g = load_golden("model_py")
+    for sc in g["scenarios"]:
+        mod = m.PointMassModel(sc["mass"], sc["dt"], sc["s"], sc["a"])
+        st, ac = np.asarray(sc["state"])[..., None], np.asarray(sc["action"])[..., None]
+        np.testing.assert_allclose(mod.build_step_graph("", st, ac)[..., 0], sc["exp_result"], rtol=1e-6, atol=1e-6)
+    sc = g["step3"]
+    mod = m.PointMassModel(sc["mass"], sc["dt"], sc["s"], sc["a"])
+    x, ac = np.asarray(sc["state"])[..., None], np.asarray(sc["action"])[..., None]
+    for _ in range(sc["n_steps"]):
+        x = mod.build_step_graph("", x, ac)
+    np.testing.assert_allclose(x[..., 0], sc["exp_result"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_golden_cost_cpp(m, idx):
+    """test/test_cost.cpp:169-239 StateCost / StepCost."""
+    sc = load_golden("cost_cpp")["scenarios"][idx]
+    h = m.Handle(k=1, tau=1, s_dim=sc["s"], a_dim=sc["a"], lam=sc["lam"], sigma=sc["sigma"], goal=sc["goal"],
+                 Q=sc["q_diag"], q_is_full=False)
+    assert_float_eq(h.state_cost(sc["state"]), sc["exp_state"], what="state")
+    assert_float_eq(h.step_cost(sc["state"], sc["action"], sc["eps"]), sc["exp_step"], what="step")
+
+
+def test_golden_cost_py(m):
+    """scripts/test.py:685-1096 TestCost / TestStaticCost through the mirrored classes."""
+    g = load_golden("cost_py")
+    for sc in g["action_cost"]:
+        c = m.CostBase(sc["lam"], sc["gamma"], sc["upsilon"], np.asarray(sc["sigma"]))
+        with pytest.raises(NotImplementedError):
+            c.state_cost("", np.zeros((1, 2, 1)))
+        got = c.action_cost("", np.asarray(sc["action"])[:, None], np.asarray(sc["noise"])[..., None])
+        assert got.shape == (len(sc["noise"]), 1, 1)
+        np.testing.assert_allclose(got.ravel(), sc["exp_action"], rtol=2e-6, atol=2e-6)
+    for sc in g["static_cost"]:
+        c = m.StaticCost(sc["lam"], sc["gamma"], sc["upsilon"], np.asarray(sc["sigma"]),
+                         np.asarray(sc["goal"])[:, None], np.asarray(sc["Q"]))
+        a, n, s = np.asarray(sc["action"])[:, None], np.asarray(sc["noise"])[..., None], np.asarray(sc["state"])[..., None]
+        np.testing.assert_allclose(c.action_cost("", a, n).ravel(), sc["exp_action"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(c.state_cost("", s).ravel(), sc["exp_state"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(c.build_step_cost_graph("", s, a, n).ravel(), sc["exp_step"], rtol=2e-6, atol=2e-6)
+
+
+def test_golden_update_chain(m):
+    """test/test_controller.cpp:109-167 testUpdate: beta, exp_arg, exp, nabla, weights, Σwε, Σw=1."""
+    g = load_golden("controller_update_k5_tau3_a2")
+    h = m.Handle(k=g["k"], tau=g["tau"], s_dim=4, a_dim=g["a"], lam=g["lam"], dt=0.01)
+    r = h.update(g["cost"], g["noise"], g["action"])
+    assert_float_eq(r["beta"], g["beta"], what="beta")
+    assert_float_eq(r["arg"], g["exp_arg"], what="exp_arg")
+    assert_float_eq(r["exp"], g["exp"], what="exp")
+    assert_float_eq(r["nabla"], g["nabla"], what="nabla")
+    assert_float_eq(r["w"], g["weights"], what="weights")
+    assert_float_eq(r["wn"], g["weighted_noise"], what="weighted noise")
+    assert_float_eq(np.sum(r["w"], dtype=F32), 1.0, what="sum w")
+    assert_float_eq(r["Unew"], np.asarray(g["action"], F32) + np.asarray(g["weighted_noise"], F32), what="U'")
+    assert h.get_step_counter() == 0 and not h.get_action_sequence().any()  # stateless helper
+
+
+def test_golden_getnew_shift(m):
+    """test/test_controller.cpp:169-222 testNew / testShiftAndInit."""
+    from mppi_tf_amd import _lib
+    g = load_golden("controller_getnew_shift")
+    for nb, exp in g["getnew"].items():
+        out = _lib.get_new(g["action"], int(nb))
+        assert out.shape == (int(nb), 2)
+        assert_float_eq(out, np.asarray(exp, F32).reshape(int(nb), 2), ulps=0)
+    for case in g["shift"]:
+        assert_float_eq(_lib.shift(g["action"], case["init"], case["nb"]), case["expected"], ulps=0)
+
+
+# =============================================================== A7: the H-step rollout cost
+ROLLOUT_CASES = [
+    dict(K=128, H=32, a=1),                                   # C1 point_mass1d
+    dict(K=4096, H=64, a=2),                                  # C2 point_mass2d
+    dict(K=65536, H=64, a=3),                                 # C3 point_mass3d, full size
+    dict(K=1000, H=50, a=3, mass=5.0, lam=0.5),               # authors' default-ish, ragged last tile
+    dict(K=1, H=1, a=1),                                      # degenerate
+    dict(K=63, H=7, a=2, dt=0.01, mass=1.5),                  # less than one tile
+    dict(K=65, H=3, a=4),                                     # one sample into the second tile
+    dict(K=257, H=128, a=3),                                  # H=128: R=64 tile is 98 KB of LDS
+    dict(K=300, H=256, a=3),                                  # forces the R=32 tile
+    dict(K=100, H=600, a=4),                                  # forces the R=16 tile
+    dict(K=513, H=20, a=3, q_full=True),                      # dense Q (Py StaticCost)
+    dict(K=513, H=20, a=3, action_cost=1, gamma=2.0, upsilon=3.0, lam=10.0),  # Py γ/υ action cost
+    dict(K=200, H=16, a=2, sigma=[[0.5, 0.1], [0.0, 0.25]]),  # non-diagonal Σ
+]
+
+
+@pytest.mark.parametrize("case", ROLLOUT_CASES, ids=lambda c: "K%d_H%d_a%d" % (c["K"], c["H"], c["a"]))
+def test_rollout_cost_bit_exact(m, case):
+    case = dict(case)
+    K, H, a = case.pop("K"), case.pop("H"), case.pop("a")
+    s = 2 * a
+    rng = np.random.default_rng(K + H)
+    if case.pop("q_full", False):
+        B = rng.standard_normal((s, s))
+        case["Q"], case["q_full"] = (B @ B.T / s + np.eye(s)).astype(F32), True
+    h, p = make_pair(m, K, H, a, **case)
+    x0 = rng.standard_normal(s).astype(F32)
+    U = (0.3 * rng.standard_normal((H, a))).astype(F32)
+    eps = (0.5 * rng.standard_normal((K, H, a))).astype(F32)
+    got = h.rollout_cost(x0, U, eps)
+    np.testing.assert_array_equal(got, p.rollout_cost(x0, U, eps))
+    assert np.isfinite(got).all()
+
+
+# =============================================================== A1: next() with injected noise
+NEXT_CASES = [
+    dict(K=128, H=32, a=1), dict(K=4096, H=64, a=2), dict(K=65536, H=64, a=3),
+    dict(K=1000, H=50, a=3, mass=5.0), dict(K=70, H=5, a=2, lam=0.1), dict(K=3000, H=50, a=3, lam=10.0),
+]
+
+
+@pytest.mark.parametrize("case", NEXT_CASES, ids=lambda c: "K%d_H%d_a%d" % (c["K"], c["H"], c["a"]))
+def test_next_with_noise_matches_oracle(m, case):
+    case = dict(case)
+    K, H, a = case.pop("K"), case.pop("H"), case.pop("a")
+    s = 2 * a
+    h, p = make_pair(m, K, H, a, **case)
+    rng = np.random.default_rng(7)
+    x = np.zeros(s, F32)
+    U = np.zeros((H, a), F32)
+    n_steps = 3 if K * H <= 300000 else 2
+    for step in range(n_steps):
+        eps = (0.25 * rng.standard_normal((K, H, a))).astype(F32)
+        u_gpu = h.next_with_noise(x, eps)
+        u_ref, U, c_ref = p.next_with_noise(x, U, eps)
+        np.testing.assert_array_equal(h.debug_get(m.DBG_COSTS), c_ref)
+        np.testing.assert_allclose(u_gpu, u_ref, rtol=0, atol=U_TOL)
+        np.testing.assert_allclose(h.get_action_sequence(), U, rtol=0, atol=U_TOL)
+        assert not h.get_action_sequence()[-1].any()  # mInit0 zeros appended
+        w = h.debug_get(m.DBG_WEIGHTS)
+        assert abs(float(w.astype(np.float64).sum()) - 1.0) < 1e-5  # Σw = 1 (test_controller.cpp:166)
+        assert h.debug_get(m.DBG_BETA) == c_ref.min()
+        # plant step on the host (same point mass), closed loop
+        x = orc.model_step(p.A, p.B, x[None], u_ref[None])[0]
+    assert h.get_step_counter() == n_steps
+
+
+def test_next_with_noise_normalize_cost(m):
+    """Py normalizeCost=True (controller_base.py:468-474)."""
+    K, H, a = 2000, 20, 3
+    h, p = make_pair(m, K, H, a, normalize=True, lam=0.05)
+    rng = np.random.default_rng(3)
+    eps = (0.25 * rng.standard_normal((K, H, a))).astype(F32)
+    x = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
+    u_ref, U_ref, _ = p.next_with_noise(x, np.zeros((H, a), F32), eps, normalize=True)
+    np.testing.assert_allclose(h.next_with_noise(x, eps), u_ref, rtol=0, atol=U_TOL)
+    np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=U_TOL)
+
+
+# =============================================================== A2: on-device noise
+def test_device_noise_matches_oracle_restatement(m):
+    """Philox4x32-10 counters are restated bit-exactly by the oracle; Box-Muller differs only through
+    the device's fast sin/cos/log (rocRAND's __sincosf path) -> small absolute tolerance."""
+    K, H, a = 1024, 16, 3
+    sig = np.array([[0.5, 0.1, 0], [0, 0.25, 0], [0.2, 0, 1.0]], F32)
+    h, _ = make_pair(m, K, H, a, sigma=sig, seed=1234567890123)
+    x = np.zeros(6, F32)
+    for step in range(2):
+        h.next(x)
+        got = h.debug_get(m.DBG_NOISE)
+        ref = orc.noise(1234567890123, step, 0, K, H, a, sig)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=5e-6)
+    z = got @ np.linalg.inv(sig).T
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+
+
+def test_next_equals_next_with_its_own_noise(m):
+    """The fused Philox step == the injected-noise step fed with the exported noise (regeneration
+    consistency) == the oracle on that noise."""
+    K, H, a = 4096, 64, 3
+    h1, p = make_pair(m, K, H, a, seed=5)
+    h2, _ = make_pair(m, K, H, a, seed=99)
+    x = np.array([0.2, 0.1, -0.3, 0, 0.5, -0.1], F32)
+    U = np.zeros((H, a), F32)
+    for _ in range(3):
+        u1 = h1.next(x)
+        eps = h1.debug_get(m.DBG_NOISE)
+        u2 = h2.next_with_noise(x, eps)
+        np.testing.assert_array_equal(h1.debug_get(m.DBG_COSTS), h2.debug_get(m.DBG_COSTS))
+        np.testing.assert_array_equal(u1, u2)
+        np.testing.assert_array_equal(h1.get_action_sequence(), h2.get_action_sequence())
+        u_ref, U, _ = p.next_with_noise(x, U, eps)
+        np.testing.assert_allclose(u1, u_ref, rtol=0, atol=U_TOL)
+        np.testing.assert_allclose(h1.get_action_sequence(), U, rtol=0, atol=U_TOL)
+
+
+def test_replay_is_deterministic(m):
+    """Controller state = (U, Philox step): restoring both replays the same controls bit for bit."""
+    K, H, a = 2048, 32, 2
+    h, _ = make_pair(m, K, H, a, seed=11)
+    x = np.array([0.0, 0.0, 0.3, 0.0], F32)
+    h.next(x)
+    U1, st = h.get_action_sequence(), h.get_step_counter()
+    seq_a = [h.next(x) for _ in range(3)]
+    h.set_action_sequence(U1)
+    h.set_step_counter(st)
+    seq_b = [h.next(x) for _ in range(3)]
+    np.testing.assert_array_equal(seq_a, seq_b)
+    h2, _ = make_pair(m, K, H, a, seed=12)
+    assert not np.array_equal(h2.next(x), make_pair(m, K, H, a, seed=11)[0].next(x))
+
+
+# =============================================================== §8e: K-sharding records
+@pytest.mark.parametrize("shards", [2, 8])
+def test_sharded_records_combine_to_the_unsharded_step(m, shards):
+    import torch
+    K, H, a = 8192, 64, 3
+    full, _ = make_pair(m, K, H, a, seed=21)
+    x = np.array([0.2, 0.1, -0.3, 0, 0.5, -0.1], F32)
+    xd = torch.tensor(x, device="cuda")
+    hs = [make_pair(m, K, H, a, seed=21, shard_rank=g, shard_count=shards)[0] for g in range(shards)]
+    assert sum(h.k_local for h in hs) == K and [h.k_offset for h in hs] == [g * K // shards for g in range(shards)]
+    n = hs[0].record_size
+    assert n == 2 + H * a
+    recs = torch.zeros(shards * n, device="cuda")
+    u = [torch.zeros(a, device="cuda") for _ in range(shards)]
+    for step in range(2):
+        u_full = full.next(x)
+        for g, h in enumerate(hs):
+            h.shard_partial(xd.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
+            h.synchronize()
+        for g, h in enumerate(hs):
+            h.shard_finish(recs.data_ptr(), shards, u[g].data_ptr())
+            h.synchronize()
+        for g, h in enumerate(hs):
+            np.testing.assert_array_equal(u[g].cpu().numpy(), u[0].cpu().numpy())  # replicated, bit-identical
+            np.testing.assert_allclose(u[g].cpu().numpy(), u_full, rtol=0, atol=2e-6)
+            np.testing.assert_allclose(h.get_action_sequence(), full.get_action_sequence(), rtol=0, atol=2e-6)
+        # shard costs are the corresponding slice of the unsharded costs (global-k Philox counters)
+        c_full = full.debug_get(m.DBG_COSTS)
+        for h in hs:
+            np.testing.assert_array_equal(h.debug_get(m.DBG_COSTS), c_full[h.k_offset:h.k_offset + h.k_local])
+
+
+# =============================================================== full-size properties (C3)
+def test_full_size_properties_point_mass3d(m):
+    K, H, a = 65536, 64, 3
+    h, p = make_pair(m, K, H, a, seed=1)
+    x = np.zeros(6, F32)
+    u = h.next(x)
+    w = h.debug_get(m.DBG_WEIGHTS).astype(np.float64)
+    assert abs(w.sum() - 1) < 1e-5 and (w >= 0).all()
+    eps = h.debug_get(m.DBG_NOISE)
+    Uupd = h.debug_get(m.DBG_U_UPDATED)
+    # U' - U is a convex combination of the noise rows; recompute it in fp64 from the exported pieces
+    wn = np.tensordot(w, eps.astype(np.float64), axes=(0, 0))
+    np.testing.assert_allclose(Uupd, wn, rtol=0, atol=U_TOL)  # U was 0
+    np.testing.assert_allclose(u, wn[0], rtol=0, atol=U_TOL)
+    assert (np.abs(Uupd) <= np.abs(eps).max(0) + 1e-6).all()
+    np.testing.assert_array_equal(h.debug_get(m.DBG_COSTS), p.rollout_cost(x, np.zeros((H, a), F32), eps))
+    # closed loop drives the plant toward the goal
+    goal = np.asarray(GOAL3, F32)
+    d0 = np.linalg.norm(x - goal)
+    for _ in range(60):
+        x = orc.model_step(p.A, p.B, x[None], u[None])[0]
+        u = h.next(x)
+    assert np.linalg.norm(x - goal) < 0.5 * d0
+
+
+# =============================================================== the C++ constructor / host loop
+def test_cpp_constructor_defaults_and_host_loop(m, tmp_path):
+    """ControllerBase(k,tau,dt,mass,s_dim,a_dim) defaults (controller_base.cpp:37-69) + the host loop of
+    src/main.cpp:36-45 (next / saveNext / toCSV) + setGoal's size check (:126-133)."""
+    c = m.ControllerBaseCpp(256, 16, 0.1, 1.0, 2, 1)
+    p = orc.Problem(tau=16, s=2, a=1, dt=0.1, mass=1.0)  # oracle defaults are the same ctor defaults
+    assert c.setGoal([1.0, 0.0, 3.0]) is False
+    x = np.zeros(2, F32)
+    U = np.zeros((16, 1), F32)
+    for _ in range(4):
+        u = c.next(x.tolist())
+        assert isinstance(u, list) and len(u) == 1
+        eps = c._h.debug_get(m.DBG_NOISE)
+        u_ref, U, _ = p.next_with_noise(x, U, eps)
+        np.testing.assert_allclose(u, u_ref, rtol=0, atol=U_TOL)
+        x = orc.model_step(p.A, p.B, x[None], np.asarray(u, F32)[None])[0]
+        c.saveNext(x.tolist())
+    f = tmp_path / "data.csv"
+    c.toCSV(str(f))
+    rows = f.read_text().strip().splitlines()
+    assert rows[0] == "x0,x1,u0,x_next0,x_next1" and len(rows) == 5
+    assert c.setGoal([0.5, 0.0]) is True
+    c.next(x.tolist())
+    assert abs(c._h.debug_get(m.DBG_COSTS).min()) >= 0
+
+
+def test_error_behaviour(m):
+    with pytest.raises(m.MppiError) as e:
+        m.Handle(k=0, tau=4, s_dim=2, a_dim=1)
+    assert e.value.status == 1
+    with pytest.raises(m.MppiError) as e:
+        m.Handle(k=8, tau=4, s_dim=2, a_dim=1, sigma=[[0.0]])
+    assert e.value.status == 5
+    h = m.Handle(k=8, tau=4, s_dim=2, a_dim=1)
+    with pytest.raises(m.MppiError) as e:
+        h.next([0.0, 0.0, 0.0])
+    assert e.value.status == 1
+    with pytest.raises(m.MppiError) as e:
+        h.next_with_noise([0.0, 0.0], np.zeros(5))
+    assert e.value.status == 1
+    hc = m.Handle(k=8, tau=4, s_dim=4, a_dim=3)  # a cost-only shape (test_cost.cpp scenario 3)
+    with pytest.raises(m.MppiError) as e:
+        hc.next(np.zeros(4))
+    assert e.value.status == 4 and "2*a_dim" in str(e.value)
