@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libmppi_hip.so")
+# MPPI_SO_PATH selects a variant build of the SAME library (tools/ablate.py); never a different backend.
+SO_PATH = os.environ.get("MPPI_SO_PATH") or os.path.join(HERE, "libmppi_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_SINGULAR_SIGMA, ERR_ALLOC, ERR_IO = range(8)
 MODEL_POINT_MASS, MODEL_MLP = 0, 1

@@ -46,5 +46,14 @@ def build(force=False, verbose=False):
     return SO
 
 
+def build_variant(name, defines=(), extra=()):
+    """Timing-only variant builds for ablation (tools/ablate.py) -> build/variants/libmppi_hip_<name>.so"""
+    d = os.path.join(ROOT, "build", "variants")
+    os.makedirs(d, exist_ok=True)
+    out = os.path.join(d, "libmppi_hip_%s.so" % name)
+    subprocess.check_call(command(out, ["-D" + x for x in defines] + list(extra)))
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

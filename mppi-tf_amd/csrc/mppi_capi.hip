@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,8 +26,10 @@ struct mppi_handle {
     int R = 64, nb = 0;
     size_t tile_lds = 0;
     int normalize = 0;
+    int sigma_diag = 0; // Σ and Σ⁻¹ are exactly diagonal (the DIAG kernel instances are bit-identical then)
+    int force_tile = 0; // MPPI_FORCE_TILE_KERNEL=1: run the LDS-tile kernel instead of the producer/consumer one (A/B timing)
     float *d_x = nullptr, *d_U = nullptr, *d_u = nullptr, *d_cost = nullptr, *d_cost2 = nullptr;
-    float *d_part = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_Uupd = nullptr, *d_mm = nullptr;
+    float *d_part = nullptr, *d_part2 = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_Uupd = nullptr, *d_mm = nullptr;
     float *d_eps = nullptr; // lazily allocated [K_local, H, a] for injected noise / debug export
     unsigned long long *d_step = nullptr;
     float *h_pin = nullptr; // pinned staging: x[s] | u[a]
@@ -137,7 +140,7 @@ extern "C" void mppi_destroy(mppi_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    float *bufs[] = {h->d_x, h->d_U, h->d_u, h->d_cost, h->d_cost2, h->d_part, h->d_record, h->d_dbg,
+    float *bufs[] = {h->d_x, h->d_U, h->d_u, h->d_cost, h->d_cost2, h->d_part, h->d_part2, h->d_record, h->d_dbg,
                      h->d_Uupd, h->d_mm, h->d_eps};
     for (float *p : bufs) if (p) (void)hipFree(p);
     if (h->d_step) (void)hipFree(h->d_step);
@@ -177,6 +180,7 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     if (h->K_local <= 0) { delete h; return fail(nullptr, MPPI_ERR_INVALID_ARG, "shard owns no samples"); }
     h->H = cfg->tau; h->s = s; h->a = a; h->HA = cfg->tau * a;
     h->normalize = cfg->normalize_cost;
+    { const char *e = std::getenv("MPPI_FORCE_TILE_KERNEL"); h->force_tile = (e && e[0] == '1') ? 1 : 0; }
 
     DevConsts &c = h->hc;
     c.K_local = h->K_local; c.k_offset = h->k_offset; c.H = h->H; c.s = s; c.a = a;
@@ -193,7 +197,11 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     float sig[kMaxA * kMaxA], inv[kMaxA * kMaxA];
     for (int i = 0; i < a; ++i) for (int j = 0; j < a; ++j) sig[i * a + j] = cfg->sigma ? cfg->sigma[i * a + j] : (i == j ? 1.0f : 0.0f);
     if (!invert(sig, a, inv)) { delete h; return fail(nullptr, MPPI_ERR_SINGULAR_SIGMA, "sigma is singular"); }
-    for (int i = 0; i < a; ++i) for (int j = 0; j < a; ++j) { c.sigma[i * kMaxA + j] = sig[i * a + j]; c.sigma_inv[i * kMaxA + j] = inv[i * a + j]; }
+    h->sigma_diag = 1;
+    for (int i = 0; i < a; ++i) for (int j = 0; j < a; ++j) {
+        c.sigma[i * kMaxA + j] = sig[i * a + j]; c.sigma_inv[i * kMaxA + j] = inv[i * a + j];
+        if (i != j && (sig[i * a + j] != 0.0f || inv[i * a + j] != 0.0f)) h->sigma_diag = 0;
+    }
     for (int i = 0; i < s; ++i) {
         if (cfg->q_is_full) {
             for (int j = 0; j < s; ++j) c.qfull[i * kMaxS + j] = cfg->Q ? cfg->Q[i * s + j] : (i == j ? 1.0f : 0.0f);
@@ -228,6 +236,7 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         HIP_TRY(h, hipMalloc((void **)&h->d_cost, sizeof(float) * h->K_local));
         HIP_TRY(h, hipMalloc((void **)&h->d_cost2, sizeof(float) * h->K_local));
         HIP_TRY(h, hipMalloc((void **)&h->d_part, sizeof(float) * (size_t)h->nb * (2 + h->HA)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_part2, sizeof(float) * (size_t)((h->nb + kGroup - 1) / kGroup) * (2 + h->HA)));
         HIP_TRY(h, hipMalloc((void **)&h->d_record, sizeof(float) * (2 + h->HA)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dbg, sizeof(float) * 8));
         HIP_TRY(h, hipMalloc((void **)&h->d_Uupd, sizeof(float) * h->HA));
@@ -307,12 +316,44 @@ static hipError_t launch_tile(mppi_handle *h, hipStream_t st, int src, int mode,
     return hipErrorInvalidValue;
 }
 
+// the hot configuration: producer/consumer kernel (k_rollout_pc) when the horizon fits its register file
+template <int A, int NSLOT>
+static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_dev)
+{
+    const size_t lds = pc_lds_floats(A) * 4;
+    const int nb = (h->K_local + 63) / 64;
+#define MPPI_PC_LAUNCH(QF, DG) hipLaunchKernelGGL((k_rollout_pc<A, NSLOT, QF, DG>), dim3(nb), dim3(kThreads), lds, st, h->dC, x_dev, h->d_U, h->d_step, h->d_cost, h->d_part)
+    if (h->hc.q_full) { if (h->sigma_diag) MPPI_PC_LAUNCH(true, true); else MPPI_PC_LAUNCH(true, false); }
+    else { if (h->sigma_diag) MPPI_PC_LAUNCH(false, true); else MPPI_PC_LAUNCH(false, false); }
+#undef MPPI_PC_LAUNCH
+    return hipGetLastError();
+}
+
+static bool pc_eligible(const mppi_handle *h) { return h->no_rollout.empty() && h->R == 64 && h->H <= 132 && !h->force_tile; }
+
+static hipError_t launch_pc(mppi_handle *h, hipStream_t st, const float *x_dev)
+{
+    const bool small = h->H <= 72;
+#define MPPI_PC_CASE(AA) case AA: return small ? launch_pc_inst<AA, 6>(h, st, x_dev) : launch_pc_inst<AA, 11>(h, st, x_dev);
+    switch (h->a) { MPPI_PC_CASE(1) MPPI_PC_CASE(2) MPPI_PC_CASE(3) MPPI_PC_CASE(4) }
+#undef MPPI_PC_CASE
+    return hipErrorInvalidValue;
+}
+
 static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *recs, int nb, float *U, float *u_out,
                                 float *record_out, int apply, float *U_updated)
 {
     // a profiled step = the rollout kernel + the finish that applies the update
     const bool prof = apply && h->prof_n < h->prof_cap;
     if (prof) { hipError_t e = hipEventRecord(h->ev[4 * h->prof_n + 2], st); if (e != hipSuccess) return e; }
+    if (nb > 4 * kGroup && recs == h->d_part) { // two-level record tree (see k_combine_group)
+        const int ng = (nb + kGroup - 1) / kGroup;
+        hipLaunchKernelGGL(k_combine_group, dim3(ng), dim3(kThreads), 0, st, h->dC, recs, nb, h->d_part2);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        recs = h->d_part2;
+        nb = ng;
+    }
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), finish_lds_bytes(h->HA), st, h->dC, recs, nb, U, u_out,
                        record_out, apply, h->d_step, h->d_dbg, U_updated);
     hipError_t e = hipGetLastError();
@@ -326,7 +367,8 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
     if (!h->normalize) {
         const bool prof = h->prof_n < h->prof_cap;
         if (prof) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 0], st));
-        HIP_TRY(h, launch_tile(h, st, src, MODE_ROLLOUT, x_dev, h->d_U, eps, h->d_cost, h->d_part, noise_out));
+        if (src == SRC_PHILOX && noise_out == nullptr && pc_eligible(h)) HIP_TRY(h, launch_pc(h, st, x_dev));
+        else HIP_TRY(h, launch_tile(h, st, src, MODE_ROLLOUT, x_dev, h->d_U, eps, h->d_cost, h->d_part, noise_out));
         if (prof) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 1], st));
         return MPPI_OK;
     }

@@ -65,35 +65,44 @@ struct PhiloxAt : rocrand_device::philox4x32_10_engine {
     __device__ uint4 block() const { return m_state.result; }
 };
 
-// z[0..A) standard normals of (global sample gk, control step `step`, horizon index t).
-// Counter layout: subsequence = gk, block = (step*H + t)*ceil(A/4) + q  — a function of the
-// GLOBAL sample index only, so results do not depend on how K is sharded over GPUs.
+// Standard normals of one GROUP of 4 consecutive horizon steps of one sample.
+// Counter layout (noise of sample gk, control step `step`, horizon steps 4g..4g+3):
+//   subsequence = gk (the GLOBAL sample index: results do not depend on how K is sharded)
+//   Philox block = (step*ceil(H/4) + g)*A + q , q = 0..A-1   -> 4A uniforms -> 4A normals
+//   normal m = 4q+{0,1,2,3} (Box-Muller pairs (x,y),(z,w) of block q) is z[t = 4g + m/A][j = m%A]
+// Every Philox output word is used (A blocks per 4 steps instead of 4).
 template <int A>
-__device__ __forceinline__ void normals_at(unsigned long long seed, unsigned long long gk,
-                                           unsigned long long step_h_plus_t, float (&z)[A])
+__device__ __forceinline__ void normals_group(unsigned long long seed, unsigned long long gk,
+                                              unsigned long long group_index, float (&z)[4 * A])
 {
-    constexpr int A4 = (A + 3) / 4;
 #pragma unroll
-    for (int q = 0; q < A4; ++q) {
-        PhiloxAt eng(seed, gk, 4ull * (step_h_plus_t * A4 + q));
+    for (int q = 0; q < A; ++q) {
+        PhiloxAt eng(seed, gk, 4ull * (group_index * A + q));
         const float4 n = rocrand_device::detail::normal_distribution4(eng.block());
-        if (4 * q + 0 < A) z[4 * q + 0] = n.x;
-        if (4 * q + 1 < A) z[4 * q + 1] = n.y;
-        if (4 * q + 2 < A) z[4 * q + 2] = n.z;
-        if (4 * q + 3 < A) z[4 * q + 3] = n.w;
+        z[4 * q + 0] = n.x;
+        z[4 * q + 1] = n.y;
+        z[4 * q + 2] = n.z;
+        z[4 * q + 3] = n.w;
     }
 }
 
-// eps = Σ · z   (controller_base.cpp:201 BatchMatMulV2(sigma, rng): Σ multiplies z directly)
-template <int A>
+// eps = Σ · z   (controller_base.cpp:201 BatchMatMulV2(sigma, rng): Σ multiplies z directly).
+// DIAG: Σ (and Σ⁻¹) are diagonal — the reference's default Σ = c·I. The dense row sum then adds
+// exact zeros (0·z_j) to ONE non-zero product, so evaluating only that product is bit-identical
+// (up to the sign of a zero) and saves 2(A²-A) operations per (k,t).
+template <int A, bool DIAG = false>
 __device__ __forceinline__ void scale_noise(const DevConsts *__restrict__ C, const float (&z)[A], float (&e)[A])
 {
 #pragma unroll
     for (int i = 0; i < A; ++i) {
-        float acc = 0.0f;
+        if (DIAG) {
+            e[i] = C->sigma[i * kMaxA + i] * z[i];
+        } else {
+            float acc = 0.0f;
 #pragma unroll
-        for (int j = 0; j < A; ++j) acc = acc + C->sigma[i * kMaxA + j] * z[j];
-        e[i] = acc;
+            for (int j = 0; j < A; ++j) acc = acc + C->sigma[i * kMaxA + j] * z[j];
+            e[i] = acc;
+        }
     }
 }
 
@@ -157,16 +166,20 @@ __device__ __forceinline__ float state_cost(const DevConsts *__restrict__ C, con
 }
 
 // cost_base.cpp:63-68 (C++: λ·uᵀ(Σ⁻¹ε), u = NOMINAL action) or cost_base.py:114-170 (γ/υ form).
-template <int A>
+template <int A, bool DIAG = false>
 __device__ __forceinline__ float action_cost(const DevConsts *__restrict__ C, const float (&u)[A], const float (&e)[A])
 {
     float rhsN[A];
 #pragma unroll
     for (int i = 0; i < A; ++i) {
-        float acc = 0.0f;
+        if (DIAG) { // see scale_noise: the off-diagonal terms are exact zeros
+            rhsN[i] = C->sigma_inv[i * kMaxA + i] * e[i];
+        } else {
+            float acc = 0.0f;
 #pragma unroll
-        for (int j = 0; j < A; ++j) acc = acc + C->sigma_inv[i * kMaxA + j] * e[j];
-        rhsN[i] = acc;
+            for (int j = 0; j < A; ++j) acc = acc + C->sigma_inv[i * kMaxA + j] * e[j];
+            rhsN[i] = acc;
+        }
     }
     float mix = 0.0f;
 #pragma unroll
@@ -176,10 +189,14 @@ __device__ __forceinline__ float action_cost(const DevConsts *__restrict__ C, co
     float rhsA[A];
 #pragma unroll
     for (int i = 0; i < A; ++i) {
-        float acc = 0.0f;
+        if (DIAG) {
+            rhsA[i] = C->sigma_inv[i * kMaxA + i] * u[i];
+        } else {
+            float acc = 0.0f;
 #pragma unroll
-        for (int j = 0; j < A; ++j) acc = acc + C->sigma_inv[i * kMaxA + j] * u[j];
-        rhsA[i] = acc;
+            for (int j = 0; j < A; ++j) acc = acc + C->sigma_inv[i * kMaxA + j] * u[j];
+            rhsA[i] = acc;
+        }
     }
     mix = 2.0f * mix;
     float n = 0.0f, ac = 0.0f;
@@ -219,6 +236,98 @@ __device__ __forceinline__ double wave_sum_d(double v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = v + __shfl_xor(v, off, 64);
     return v;
+}
+
+// DPP butterflies (no LDS crossbar): quad swaps, half-row and row mirrors, then the four row
+// sums through readlane. Fixed association -> deterministic; every lane returns the total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    v = v + dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
+    v = v + dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
+    v = v + dpp_mov<0x141>(v); // row_half_mirror
+    v = v + dpp_mov<0x140>(v); // row_mirror
+    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (s0 + s1) + (s2 + s3);
+}
+
+// ----------------------------------------------------------------------------------------
+// Transposing butterfly: sums N per-lane values ACROSS the 64 lanes for N independent columns
+// at once. Each level pairs lanes (l, l^p) and halves the live registers: the lane whose role
+// bit is 0 keeps the even register of a pair, the other keeps the odd one, each adds its
+// partner's copy. After 6 levels lane l holds, in out[m], the 64-lane total of column
+//   n = 64*m + r0 + 2 r1 + 4 r2 + 8 r3 + 16 r4 + 32 r5
+// with role bits r0=b0^b2, r1=b1^b2, r2=b2^b3, r3=b3, r4=b4, r5=b5 of its lane id (the roles
+// follow from the DPP partners 1, 2, 7 (row_half_mirror), 15 (row_mirror): a partner must keep
+// the same roles at all earlier levels). ~3 instructions per pair instead of a full 11-instruction
+// reduction per column. Fixed association -> deterministic.
+template <int LEVEL>
+__device__ __forceinline__ float lane_xchg(float v)
+{
+    if (LEVEL == 0) return dpp_mov<0xB1>(v);  // l ^ 1
+    if (LEVEL == 1) return dpp_mov<0x4E>(v);  // l ^ 2
+    if (LEVEL == 2) return dpp_mov<0x141>(v); // l ^ 7
+    if (LEVEL == 3) return dpp_mov<0x140>(v); // l ^ 15
+    if (LEVEL == 4) return __shfl_xor(v, 16, 64);
+    return __shfl_xor(v, 32, 64);
+}
+
+__device__ __forceinline__ int lane_role(int lane, int level)
+{
+    const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1;
+    switch (level) {
+    case 0: return (lane & 1) ^ b2;
+    case 1: return ((lane >> 1) & 1) ^ b2;
+    case 2: return b2 ^ b3;
+    case 3: return b3;
+    case 4: return (lane >> 4) & 1;
+    default: return (lane >> 5) & 1;
+    }
+}
+
+// column index a lane ends up owning in out[m] (see above)
+__device__ __forceinline__ int lane_column(int lane)
+{
+    int n = 0;
+#pragma unroll
+    for (int lv = 0; lv < 6; ++lv) n |= lane_role(lane, lv) << lv;
+    return n;
+}
+
+template <int N, int LEVEL>
+__device__ __forceinline__ void tfold(const float (&in)[N], float (&out)[(N + 1) / 2], int lane)
+{
+    const bool role = lane_role(lane, LEVEL) != 0;
+#pragma unroll
+    for (int j = 0; j < (N + 1) / 2; ++j) {
+        const float lo = in[2 * j];
+        const float hi = (2 * j + 1 < N) ? in[2 * j + 1] : 0.0f;
+        const float send = role ? lo : hi;
+        const float keep = role ? hi : lo;
+        out[j] = keep + lane_xchg<LEVEL>(send);
+    }
+}
+
+// in[N] per lane -> out[ceil(N/64)] per lane, out[m] = total of column 64*m + lane_column(lane)
+template <int N>
+__device__ __forceinline__ void wave_transpose_sum(const float (&in)[N], float (&out)[(N + 63) / 64], int lane)
+{
+    constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2, N6 = (N5 + 1) / 2;
+    static_assert(N6 == (N + 63) / 64, "ceil-halving six times equals ceil(N/64)");
+    float a1[N1], a2[N2], a3[N3], a4[N4], a5[N5];
+    tfold<N, 0>(in, a1, lane);
+    tfold<N1, 1>(a1, a2, lane);
+    tfold<N2, 2>(a2, a3, lane);
+    tfold<N3, 3>(a3, a4, lane);
+    tfold<N4, 4>(a4, a5, lane);
+    tfold<N5, 5>(a5, out, lane);
 }
 
 } // namespace mppi

@@ -4,6 +4,8 @@
 
 #include "mppi_device.hip.h"
 
+#include <type_traits>
+
 namespace mppi {
 
 enum NoiseSrc { SRC_PHILOX = 0, SRC_HBM = 1 };
@@ -47,17 +49,32 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
 
     // ---- phase A: the tile's noise -> LDS, eps_s[(t*A+j)*RP + kl] --------------------------
     if (SRC == SRC_PHILOX) {
-        constexpr int TQ = kThreads / R; // horizon slots generated concurrently per rollout
+        constexpr int TQ = kThreads / R; // groups (of 4 horizon steps) generated concurrently per rollout
         const int kl = tid % R;
+        const int NG = (H + 3) / 4;
         const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)(k0 + kl);
-        const unsigned long long base = step_ctr[0] * (unsigned long long)H;
+        const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
         const unsigned long long seed = C->seed;
-        for (int t = tid / R; t < H; t += TQ) {
-            float z[A], e[A];
-            normals_at<A>(seed, gk, base + (unsigned long long)t, z);
-            scale_noise<A>(C, z, e);
+        for (int g = tid / R; g < NG; g += TQ) {
+            float z[4 * A];
+#if defined(MPPI_ABLATE_PHILOX) // timing-only build: cheap stand-in for Philox + Box-Muller (tools/ablate.py)
 #pragma unroll
-            for (int j = 0; j < A; ++j) eps_s[(t * A + j) * RP + kl] = e[j];
+            for (int j = 0; j < 4 * A; ++j) z[j] = (float)((int)((gk * 2654435761ull + (base + g) * 40503ull + j) & 1023) - 512) * (1.0f / 512.0f);
+#else
+            normals_group<A>(seed, gk, base + (unsigned long long)g, z);
+#endif
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                const int t = 4 * g + tl;
+                if (t < H) {
+                    float zz[A], e[A];
+#pragma unroll
+                    for (int j = 0; j < A; ++j) zz[j] = z[tl * A + j];
+                    scale_noise<A>(C, zz, e);
+#pragma unroll
+                    for (int j = 0; j < A; ++j) eps_s[(t * A + j) * RP + kl] = e[j];
+                }
+            }
         }
     } else {
         // injected noise: coalesced dword read of the tile's contiguous [R, H*A] slab
@@ -88,7 +105,11 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
             float x[S];
 #pragma unroll
             for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+#if defined(MPPI_ABLATE_ROLLOUT) // timing-only build: one step instead of H
+            for (int t = 0; t < 1; ++t) {
+#else
             for (int t = 0; t < H; ++t) {
+#endif
                 float u[A], e[A], v[A];
 #pragma unroll
                 for (int j = 0; j < A; ++j) {
@@ -123,7 +144,11 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
     // ---- phase C: V_b[c] = Σ_k e_k·eps[k,c] in fixed k order (mWeightedNoise, :188-192) -----
     float *rec = partials + (size_t)blockIdx.x * (2 + HA);
     if (tid == 0) { rec[0] = red_s[0]; rec[1] = red_s[1]; }
+#if defined(MPPI_ABLATE_WSUM) // timing-only build: no weighted-noise sum
+    for (int c = tid; c < 1; c += kThreads) {
+#else
     for (int c = tid; c < HA; c += kThreads) {
+#endif
         const float *row = eps_s + (size_t)c * RP;
         float acc = 0.0f;
 #pragma unroll 8
@@ -132,7 +157,201 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// k_rollout_pc: the hot configuration (Philox noise, rollout + tile record) as a
+// producer/consumer pipeline inside one workgroup of 4 wavefronts that owns 64 rollouts:
+//   waves 1..3 (producers): lane = rollout. Producer p draws the noise of horizon groups
+//       g = 3i+p (4 steps per group, A Philox blocks), keeps eps in REGISTERS for the weighted
+//       sum, and hands the consumer per step the perturbed action v = u_t+eps and the action
+//       cost (both depend on nothing but (u_t, eps)) through a double-buffered LDS chunk;
+//   wave 0 (consumer): lane = rollout, runs the sequential H-step recurrence + state cost out
+//       of the LDS chunks (12 steps per chunk, one s_barrier per chunk), then the tile soft-min;
+//   producers finish with V_b[t,j] = Σ_k e_k·eps[k,t,j] straight from registers (DPP butterflies).
+// Why: with the noise parked in LDS for the weighted sum a tile costs 50 KB, so only 3 tiles fit
+// a CU while K=65536 gives every CU exactly 4; and the recurrence ran on 1 of 4 waves while the
+// other 3 idled at the barrier (22 of 45 µs). Here LDS is 26 KB/tile, registers ~110/lane ->
+// 4 workgroups (16 waves) per CU in one round, all waves busy.
+// Arithmetic per (k,t) is the same op sequence as k_rollout_tile: sample costs stay bit-identical.
+// NSLOT = max horizon groups per producer = ceil(ceil(H/4)/3)  (6 for H<=72, 11 for H<=132).
+constexpr int kPcChunkSteps = 12; // 3 producers x 4 steps
+
+// compile-time loop: the slot index must be a constant so that eps_r[slot] stays in registers
+// (a rolled loop would index the array dynamically and push it to scratch).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+__host__ __device__ inline size_t pc_lds_floats(int A) { return (size_t)2 * kPcChunkSteps * (A + 1) * 65 + 64 + 8; }
+
+template <int A, int NSLOT, bool QFULL, bool DIAG>
+__global__ __launch_bounds__(kThreads, (NSLOT * 4 * A <= 80 ? 4 : 2)) void k_rollout_pc(
+    const DevConsts *__restrict__ C, const float *__restrict__ x_dev, const float *__restrict__ U_dev,
+    const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int S = 2 * A;
+    constexpr int RP = 65;
+    constexpr int CH = kPcChunkSteps * (A + 1) * RP; // floats per chunk buffer
+    constexpr int NREG = NSLOT * 4 * A;              // noise values a producer lane keeps
+    const int H = C->H;
+    const int HA = H * A;
+    const int K = C->K_local;
+    const int NG = (H + 3) / 4;          // horizon groups
+    const int nch = (NG + 2) / 3;        // chunks (3 groups each)
+    float *buf = smem;                   // [2][12][(A+1)][RP]
+    float *w_s = smem + 2 * CH;          // [64]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // SGPR: scalar branches + scalar loads of U
+    const int lane = tid & 63;
+    const int k0 = blockIdx.x * 64;
+    const bool valid = (k0 + lane) < K;
+    float *rec = partials + (size_t)blockIdx.x * (2 + HA);
+
+    if (wave != 0) {
+        // ------------------------------------------------------------------ producers
+        const int p = wave - 1;
+        const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)(k0 + lane);
+        const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
+        const unsigned long long seed = C->seed;
+        float eps_r[NREG];
+        static_for<0, NSLOT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int g = 3 * i + p;
+            if (i < nch) { // chunk i exists (wave-uniform)
+                float *cb = buf + (i & 1) * CH + (size_t)(4 * p) * (A + 1) * RP;
+                if (g < NG) {
+                    float z[4 * A];
+#if defined(MPPI_ABLATE_PHILOX)
+#pragma unroll
+                    for (int j = 0; j < 4 * A; ++j) z[j] = (float)((int)((gk * 2654435761ull + (base + g) * 40503ull + j) & 1023) - 512) * (1.0f / 512.0f);
+#else
+                    normals_group<A>(seed, gk, base + (unsigned long long)g, z);
+#endif
+#pragma unroll
+                    for (int tl = 0; tl < 4; ++tl) {
+                        const int t = 4 * g + tl;
+                        float zz[A], e[A], u[A];
+#pragma unroll
+                        for (int j = 0; j < A; ++j) zz[j] = z[tl * A + j];
+                        scale_noise<A, DIAG>(C, zz, e);
+                        const int tt = t < H ? t : H - 1; // steps past the horizon are never consumed
+#pragma unroll
+                        for (int j = 0; j < A; ++j) {
+                            u[j] = U_dev[tt * A + j];                // mPrepareAction controller_base.cpp:205-208 (scalar load)
+                            eps_r[(i * 4 + tl) * A + j] = t < H ? e[j] : 0.0f;
+                            cb[(tl * (A + 1) + j) * RP + lane] = u[j] + e[j]; // to_apply, :258
+                        }
+                        cb[(tl * (A + 1) + A) * RP + lane] = action_cost<A, DIAG>(C, u, e);
+                    }
+                }
+                __syncthreads(); // chunk i published
+            }
+            if (!(i < nch && g < NG)) {
+#pragma unroll
+                for (int r = 0; r < 4 * A; ++r) eps_r[i * 4 * A + r] = 0.0f;
+            }
+        });
+        __syncthreads(); // weights published by the consumer
+        // phase C from registers: V_b[t,j] = Σ_k e_k·eps[k,t,j]  (mWeightedNoise, controller_base.cpp:188-192)
+        const float w = w_s[lane];
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) eps_r[r] = w * eps_r[r];
+        float tot[(NREG + 63) / 64];
+#if defined(MPPI_ABLATE_WSUM)
+#pragma unroll
+        for (int m = 0; m < (NREG + 63) / 64; ++m) tot[m] = eps_r[m];
+#else
+        wave_transpose_sum<NREG>(eps_r, tot, lane);
+#endif
+        const int colbase = lane_column(lane);
+#pragma unroll
+        for (int m = 0; m < (NREG + 63) / 64; ++m) {
+            const int n = 64 * m + colbase;        // register index this lane owns the total of
+            const int i = n / (4 * A), rem = n - i * (4 * A);
+            const int tl = rem / A, j = rem - tl * A;
+            const int t = 4 * (3 * i + p) + tl;
+            if (n < NREG && t < H) rec[2 + t * A + j] = tot[m];
+        }
+    } else {
+        // ------------------------------------------------------------------ consumer
+        float x[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+        float c = 0.0f;
+        __syncthreads(); // chunk 0 published
+        for (int ch = 0; ch < nch; ++ch) {
+            const float *cb = buf + (ch & 1) * CH;
+            const int tend = min(kPcChunkSteps, H - ch * kPcChunkSteps);
+#if defined(MPPI_ABLATE_ROLLOUT)
+            for (int tl = 0; tl < (ch == 0 ? 1 : 0); ++tl) {
+#else
+            for (int tl = 0; tl < tend; ++tl) {
+#endif
+                float v[A];
+#pragma unroll
+                for (int j = 0; j < A; ++j) v[j] = cb[(tl * (A + 1) + j) * RP + lane];
+                const float ac = cb[(tl * (A + 1) + A) * RP + lane];
+                pm_step<A>(C, x, v);
+                const float sc = state_cost<S, QFULL>(C, x); // cost on the POST-step state
+                const float tmp = sc + ac;                    // Step_cost_result cost_base.cpp:49
+                c = c + tmp;                                  // path_cost        controller_base.cpp:268
+            }
+            if (ch + 1 < nch) __syncthreads(); // chunk ch consumed / chunk ch+1 published
+        }
+        c = c + state_cost<S, QFULL>(C, x); // terminal: x_H counted a second time, :271-272
+        if (valid) cost[k0 + lane] = c;
+        // tile-local mBeta / mExpArg / mExp / mNabla (controller_base.cpp:166-182)
+        const float beta = wave_min(valid ? c : INFINITY);
+        const float arg = C->neg_inv_lambda * (c - beta);
+        const float ek = valid ? expf(arg) : 0.0f;
+        const float eta = wave_sum(ek);
+        w_s[lane] = ek;
+        if (lane == 0) { rec[0] = beta; rec[1] = eta; }
+        __syncthreads(); // weights published
+    }
+}
+
 __host__ __device__ inline size_t finish_lds_bytes(int HA) { return (size_t)(kFinishThreads + HA + 1) * 8 + 64; }
+
+// ----------------------------------------------------------------------------------------
+// k_combine_group: first level of the record tree. Workgroup j folds records
+// [j*kGroup, (j+1)*kGroup) into ONE record with the same (beta, eta, V) algebra as k_finish:
+//   beta_j = min beta_b ; r_b = exp(-(beta_b-beta_j)/λ) ; eta_j = Σ r_b eta_b ; V_j = Σ r_b V_b
+// in fixed b order. A single-workgroup combine of ~1000 tile records is a chain of ~200
+// dependent L2 round trips per thread (measured 76 µs at K=65536); this level runs on
+// ceil(nb/kGroup) CUs with kGroup independent loads in flight per thread instead.
+constexpr int kGroup = 16;
+__global__ __launch_bounds__(kThreads) void k_combine_group(
+    const DevConsts *__restrict__ C, const float *__restrict__ recs, int nb, float *__restrict__ out)
+{
+    __shared__ float r_s[kGroup];
+    const int HA = C->H * C->a;
+    const int stride = 2 + HA;
+    const int b0 = blockIdx.x * kGroup;
+    const int n = min(kGroup, nb - b0);
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const float bb = tid < n ? recs[(size_t)(b0 + tid) * stride] : INFINITY;
+        const float beta = wave_min(bb);
+        if (tid < kGroup) r_s[tid] = tid < n ? expf(C->neg_inv_lambda * (bb - beta)) : 0.0f;
+        if (tid == 0) out[(size_t)blockIdx.x * stride] = beta;
+    }
+    __syncthreads();
+    for (int col = tid; col < HA + 1; col += kThreads) {
+        float v[kGroup];
+#pragma unroll
+        for (int b = 0; b < kGroup; ++b) v[b] = b < n ? recs[(size_t)(b0 + b) * stride + 1 + col] : 0.0f;
+        double acc = 0.0;
+#pragma unroll
+        for (int b = 0; b < kGroup; ++b) acc += (double)r_s[b] * (double)v[b];
+        out[(size_t)blockIdx.x * stride + 1 + col] = (float)acc;
+    }
+}
 
 // ----------------------------------------------------------------------------------------
 // k_finish: fixed-order combine of nb records (beta_b, eta_b, V_b[HA]) laid out [nb, 2+HA]:

@@ -37,6 +37,10 @@ class HipShardBackend:
     def finish(self, records, n_records, u):
         self.h.shard_finish(records.data_ptr(), n_records, u.data_ptr(), self._stream())
 
+    def step(self, x, u):
+        """unsharded whole step (mppi_next_device): no record round trip"""
+        self.h.next_device(x.data_ptr(), u.data_ptr(), self._stream())
+
     def action_sequence(self):
         torch.cuda.current_stream(self.device).synchronize()
         return torch.from_numpy(self.h.get_action_sequence())
@@ -62,12 +66,13 @@ class ShardedController:
     def next(self, x):
         """x: float32 tensor [s] on the backend's device (replicated on every rank). Returns u [a]
         (device tensor, valid in stream order; identical on every rank)."""
+        if self.world == 1 and hasattr(self.backend, "step"):
+            self.backend.step(x, self.u)
+            return self.u
         self.backend.partial(x, self.record)
         if self.world > 1:
             dist.all_gather_into_tensor(self.records, self.record, group=self.group)
-            self.backend.finish(self.records, self.world, self.u)
-        else:
-            self.backend.finish(self.record, 1, self.u)
+        self.backend.finish(self.records if self.world > 1 else self.record, self.world, self.u)
         return self.u
 
 

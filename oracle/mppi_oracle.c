@@ -55,24 +55,27 @@ void orc_box_muller(uint32_t x, uint32_t y, float *n0, float *n1)
 
 void orc_normals(uint64_t seed, uint64_t step, uint64_t k_offset, int k, int tau, int a, float *z_out)
 {
-    const int a4 = (a + 3) / 4;
+    const int ng = (tau + 3) / 4; /* groups of 4 horizon steps */
     const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
 #if defined(_OPENMP)
 #pragma omp parallel for schedule(static)
 #endif
     for (int i = 0; i < k; ++i) {
         const uint64_t gk = k_offset + (uint64_t)i;
-        for (int t = 0; t < tau; ++t) {
-            for (int q = 0; q < a4; ++q) {
-                const uint64_t o = (step * (uint64_t)tau + (uint64_t)t) * (uint64_t)a4 + (uint64_t)q;
+        for (int g = 0; g < ng; ++g) {
+            for (int q = 0; q < a; ++q) {
+                const uint64_t o = (step * (uint64_t)ng + (uint64_t)g) * (uint64_t)a + (uint64_t)q;
                 const uint32_t ctr[4] = {(uint32_t)o, (uint32_t)(o >> 32), (uint32_t)gk, (uint32_t)(gk >> 32)};
                 uint32_t r[4];
                 float n[4];
                 orc_philox4x32_10(ctr, key, r);
                 orc_box_muller(r[0], r[1], &n[0], &n[1]);
                 orc_box_muller(r[2], r[3], &n[2], &n[3]);
-                for (int j = 0; j < 4 && 4 * q + j < a; ++j)
-                    z_out[((size_t)i * tau + t) * a + 4 * q + j] = n[j];
+                for (int w = 0; w < 4; ++w) {
+                    const int m = 4 * q + w;          /* normal m of the group */
+                    const int t = 4 * g + m / a, j = m % a;
+                    if (t < tau) z_out[((size_t)i * tau + t) * a + j] = n[w];
+                }
             }
         }
     }

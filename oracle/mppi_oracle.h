@@ -62,11 +62,12 @@ extern "C" {
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* rocRAND box_muller(x, y) -> (n0, n1). */
 void orc_box_muller(uint32_t x, uint32_t y, float *n0, float *n1);
-/* Standard normals z[k, tau, a] of the product's counter layout:
+/* Standard normals z[k, tau, a] of the product's counter layout (groups of 4 horizon steps):
  *   key = seed ; counter = {lo(o), hi(o), lo(gk), hi(gk)} with gk = k_offset + k (the GLOBAL
- *   sample index: results do not depend on how K is sharded) and
- *   o = (step*tau + t)*ceil(a/4) + q ; the 4 words → box_muller(x,y), box_muller(z,w)
- *   give z[4q..4q+3]. Identical to rocrand_init(seed, gk, 4*o) + rocrand_normal4(). */
+ *   sample index: results do not depend on how K is sharded) and, for group g = t/4,
+ *   o = (step*ceil(tau/4) + g)*a + q, q = 0..a-1 ; the 4 words of block q -> box_muller(x,y),
+ *   box_muller(z,w) = normals m = 4q..4q+3 of the group ; normal m is z[t = 4g + m/a][j = m%a].
+ *   Identical to rocrand_init(seed, gk, 4*o) + rocrand_normal4(). */
 void orc_normals(uint64_t seed, uint64_t step, uint64_t k_offset, int k, int tau, int a, float *z_out);
 /* ε = Σ · z per (k,t)  (controller_base.cpp:196-201: BatchMatMulV2(sigma, rng)). */
 void orc_noise(uint64_t seed, uint64_t step, uint64_t k_offset, int k, int tau, int a,
