@@ -348,14 +348,14 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
     if (prof) { hipError_t e = hipEventRecord(h->ev[4 * h->prof_n + 2], st); if (e != hipSuccess) return e; }
     if (nb > 4 * kGroup && recs == h->d_part) { // two-level record tree (see k_combine_group)
         const int ng = (nb + kGroup - 1) / kGroup;
-        hipLaunchKernelGGL(k_combine_group, dim3(ng), dim3(kThreads), 0, st, h->dC, recs, nb, h->d_part2);
+        hipLaunchKernelGGL(k_combine_group, dim3(ng), dim3(kThreads), 0, st, recs, nb, h->HA, h->hc.neg_inv_lambda, h->d_part2);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         recs = h->d_part2;
         nb = ng;
     }
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), finish_lds_bytes(h->HA), st, h->dC, recs, nb, U, u_out,
-                       record_out, apply, h->d_step, h->d_dbg, U_updated);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), finish_lds_bytes(h->HA), st, recs, nb, h->HA, h->a,
+                       h->hc.neg_inv_lambda, U, u_out, record_out, apply, h->d_step, h->d_dbg, U_updated);
     hipError_t e = hipGetLastError();
     if (prof && e == hipSuccess) { e = hipEventRecord(h->ev[4 * h->prof_n + 3], st); h->prof_stream = st; h->prof_n++; }
     return e;

@@ -206,7 +206,13 @@ __global__ __launch_bounds__(kThreads, (NSLOT * 4 * A <= 80 ? 4 : 2)) void k_rol
     float *w_s = smem + 2 * CH;          // [64]
 
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // SGPR: scalar branches + scalar loads of U
+    // Role rotation: a workgroup's 4 waves land on the CU's 4 SIMDs, and the 4 workgroups that
+    // share a CU (observed dispatch: block b -> XCD b%8, CU (b/8)%32, so they differ in b/256) would
+    // otherwise all put their light consumer wave on the same SIMD and their producers on the
+    // other three (measured: 3 SIMDs saturated, 1 at ~35 %). Rotating the consumer by b/256 gives
+    // every SIMD one consumer and three producers. Placement only affects speed, never results.
+    const int wave_hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = (wave_hw + 4 - (int)((blockIdx.x >> 8) & 3)) & 3; // SGPR: scalar branches + scalar loads of U
     const int lane = tid & 63;
     const int k0 = blockIdx.x * 64;
     const bool valid = (k0 + lane) < K;
@@ -316,7 +322,6 @@ __global__ __launch_bounds__(kThreads, (NSLOT * 4 * A <= 80 ? 4 : 2)) void k_rol
     }
 }
 
-__host__ __device__ inline size_t finish_lds_bytes(int HA) { return (size_t)(kFinishThreads + HA + 1) * 8 + 64; }
 
 // ----------------------------------------------------------------------------------------
 // k_combine_group: first level of the record tree. Workgroup j folds records
@@ -326,32 +331,42 @@ __host__ __device__ inline size_t finish_lds_bytes(int HA) { return (size_t)(kFi
 // dependent L2 round trips per thread (measured 76 µs at K=65536); this level runs on
 // ceil(nb/kGroup) CUs with kGroup independent loads in flight per thread instead.
 constexpr int kGroup = 16;
+// Scalars arrive as kernel arguments (SGPRs at wave start) rather than through DevConsts: these
+// kernels are a chain of dependent memory round trips, and every hop removed is ~0.5-1 µs.
 __global__ __launch_bounds__(kThreads) void k_combine_group(
-    const DevConsts *__restrict__ C, const float *__restrict__ recs, int nb, float *__restrict__ out)
+    const float *__restrict__ recs, int nb, int HA, float neg_inv_lambda, float *__restrict__ out)
 {
-    __shared__ float r_s[kGroup];
-    const int HA = C->H * C->a;
     const int stride = 2 + HA;
     const int b0 = blockIdx.x * kGroup;
     const int n = min(kGroup, nb - b0);
     const int tid = threadIdx.x;
-    if (tid < 64) {
-        const float bb = tid < n ? recs[(size_t)(b0 + tid) * stride] : INFINITY;
-        const float beta = wave_min(bb);
-        if (tid < kGroup) r_s[tid] = tid < n ? expf(C->neg_inv_lambda * (bb - beta)) : 0.0f;
-        if (tid == 0) out[(size_t)blockIdx.x * stride] = beta;
+    // every thread reads the group's betas itself (wave-uniform addresses -> scalar loads): no LDS, no barrier
+    float bb[kGroup], r[kGroup];
+    float beta = INFINITY;
+    // loads are UNCONDITIONAL on clamped indices and masked afterwards: a load under a runtime
+    // predicate makes hipcc branch around it and wait per element (16 serial round trips, measured 6 µs)
+#pragma unroll
+    for (int b = 0; b < kGroup; ++b) bb[b] = recs[(size_t)(b0 + min(b, n - 1)) * stride];
+#pragma unroll
+    for (int b = 0; b < kGroup; ++b) {
+        bb[b] = b < n ? bb[b] : INFINITY;
+        beta = fminf(beta, bb[b]);
     }
-    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < kGroup; ++b) r[b] = b < n ? expf(neg_inv_lambda * (bb[b] - beta)) : 0.0f;
+    if (tid == 0) out[(size_t)blockIdx.x * stride] = beta;
     for (int col = tid; col < HA + 1; col += kThreads) {
         float v[kGroup];
 #pragma unroll
-        for (int b = 0; b < kGroup; ++b) v[b] = b < n ? recs[(size_t)(b0 + b) * stride + 1 + col] : 0.0f;
+        for (int b = 0; b < kGroup; ++b) v[b] = recs[(size_t)(b0 + min(b, n - 1)) * stride + 1 + col];
         double acc = 0.0;
 #pragma unroll
-        for (int b = 0; b < kGroup; ++b) acc += (double)r_s[b] * (double)v[b];
+        for (int b = 0; b < kGroup; ++b) acc += (double)r[b] * (double)v[b]; // r[b] = 0 beyond n
         out[(size_t)blockIdx.x * stride + 1 + col] = (float)acc;
     }
 }
+
+__host__ __device__ inline size_t finish_lds_bytes(int HA) { return (size_t)(kFinishThreads + HA + 1) * 8 + 64 + 4 * kFinishThreads; }
 
 // ----------------------------------------------------------------------------------------
 // k_finish: fixed-order combine of nb records (beta_b, eta_b, V_b[HA]) laid out [nb, 2+HA]:
@@ -361,41 +376,61 @@ __global__ __launch_bounds__(kThreads) void k_combine_group(
 // mGetNew :326-329, mShift+mInit0 :310-324) and advance the Philox step counter.
 // The sums run in double: nb·(HA+1) adds, negligible next to the rollouts.
 // One workgroup of 1024 threads; dynamic LDS = finish_lds_bytes(HA).
+constexpr int kFinishBatch = 16; // record values a thread keeps in flight
 __global__ __launch_bounds__(kFinishThreads) void k_finish(
-    const DevConsts *__restrict__ C, const float *__restrict__ recs, int nb,
+    const float *__restrict__ recs, int nb, int HA, int a, float neg_inv_lambda,
     float *__restrict__ U, float *__restrict__ u_out, float *__restrict__ record_out, int apply,
     unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg, float *__restrict__ U_updated)
 {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    const int HA = C->H * C->a;
-    const int a = C->a;
     const int ncol = HA + 1; // column 0 = eta, columns 1..HA = V
     const int stride = 2 + HA;
     double *part_s = fsm;                  // [kFinishThreads]
     double *tot_s = fsm + kFinishThreads;  // [ncol]
     float *beta_s = reinterpret_cast<float *>(tot_s + ncol); // [kFinishThreads/64]
+    float *r_s = beta_s + kFinishThreads / 64;                 // [kFinishThreads] rescale factors of the first 1024 records
     const int tid = threadIdx.x;
 
-    float bmin = INFINITY;
-    for (int b = tid; b < nb; b += kFinishThreads) bmin = fminf(bmin, recs[(size_t)b * stride]);
+    // the first pass's record values are requested before anything waits on the betas
+    const int ncp0 = min(ncol, kFinishThreads);
+    const int G0 = kFinishThreads / ncp0;
+    const int col_0 = tid % ncp0, g_0 = tid / ncp0;
+    float v0[kFinishBatch];
+#pragma unroll
+    for (int i = 0; i < kFinishBatch; ++i) // unconditional loads on clamped indices (see k_combine_group)
+        v0[i] = recs[(size_t)min(g_0 + i * G0, nb - 1) * stride + 1 + col_0];
+    const float u_old0 = U[min(tid, HA - 1)];
+    float my_beta = recs[(size_t)min(tid, nb - 1) * stride];
+    my_beta = tid < nb ? my_beta : INFINITY;
+    float bmin = my_beta;
+    for (int b = tid + kFinishThreads; b < nb; b += kFinishThreads) bmin = fminf(bmin, recs[(size_t)b * stride]);
     bmin = wave_min(bmin);
     if ((tid & 63) == 0) beta_s[tid >> 6] = bmin;
     __syncthreads();
     float beta = beta_s[0];
 #pragma unroll
     for (int w = 1; w < kFinishThreads / 64; ++w) beta = fminf(beta, beta_s[w]);
+    r_s[tid] = tid < nb ? expf(neg_inv_lambda * (my_beta - beta)) : 0.0f;
+    __syncthreads();
 
-    const float nil = C->neg_inv_lambda;
     for (int col0 = 0; col0 < ncol; col0 += kFinishThreads) {
         const int ncp = min(ncol - col0, kFinishThreads); // columns in this pass
         const int G = kFinishThreads / ncp;               // record groups summed concurrently
         const int col = tid % ncp, g = tid / ncp;
         double acc = 0.0;
         if (g < G) {
-            for (int b = g; b < nb; b += G) {
-                const float *r = recs + (size_t)b * stride;
-                const float rb = expf(nil * (r[0] - beta));
-                acc += (double)rb * (double)r[1 + col0 + col];
+            int b = g;
+            if (col0 == 0) { // the prefetched batch
+#pragma unroll
+                for (int i = 0; i < kFinishBatch; ++i) {
+                    const int bi = g + i * G;
+                    if (bi < nb) acc += (double)r_s[bi] * (double)v0[i];
+                }
+                b = g + kFinishBatch * G;
+            }
+            for (; b < nb; b += G) {
+                const float rb = b < kFinishThreads ? r_s[b] : expf(neg_inv_lambda * (recs[(size_t)b * stride] - beta));
+                acc += (double)rb * (double)recs[(size_t)b * stride + 1 + col0 + col];
             }
         }
         part_s[tid] = acc;
@@ -421,7 +456,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(
             float un = 0.0f;
             if (c < HA) {
                 const float wn = (float)(tot_s[1 + c] / eta);
-                un = U[c] + wn;
+                un = (c0 == 0 ? u_old0 : U[c]) + wn;
                 if (U_updated != nullptr) U_updated[c] = un;
             }
             __syncthreads();
