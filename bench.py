@@ -163,12 +163,14 @@ def main():
                        "K_global": k_global, "K_per_gpu": K_PER_GPU, "H": H, "s_dim": S, "a_dim": A,
                        "lambda": 1.0, "sigma": "0.25*I", "dt": 0.1, "mass": 1.0,
                        "parallelism": "K-shard x%d, one all-gather of %d floats per step" % (world, h.record_size)},
-            "roofline": {"bound": "hbm", "kernel": "k_rollout_tile<3,64,false,PHILOX,ROLLOUT>",
+            "roofline": {"bound": "hbm", "kernel": "mppi::k_rollout_pc<3, 6, false, true>",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_flop_per_launch": FLOP_PER_STATE_STEP * state_steps,
-                         "kernel_ms_avg": roll_ms, "finish_kernel_ms_avg": fin_ms, "launches_timed": n_prof,
+                         "kernel_ms_avg": roll_ms, "record_tree_kernels_ms_avg": fin_ms, "launches_timed": n_prof,
+                         "timing": "HIP events on the launch stream around each launch (dispatch latency included; "
+                                   "rocprofv3 begin-to-end durations in profiles/ are ~2 us shorter)",
                          "note": "noise is generated and consumed on-chip (LDS), so physical HBM traffic is far below "
                                  "the 12a B/state-step materialised-noise model; the true limiter is VALU "
                                  "(Philox4x32-10 + Box-Muller). See DESIGN.md §4."},

@@ -1,0 +1,71 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo runs of the product's ShardedController give the
+same controls as the unsharded run, and every rank holds bit-identical results.
+Run with `-m "not gpu"`; finishes in seconds."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+CFG = dict(k=1000, tau=12, s_dim=4, a_dim=2, sigma=[[0.25, 0.0], [0.0, 0.25]], goal=[1.0, 0.0, 0.5, 0.0], lam=1.0, seed=7)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(world, tmp_path, steps=3):
+    out = str(tmp_path / ("res_w%d" % world))
+    env = dict(os.environ, MPPI_TEST_CFG=json.dumps(CFG), MPPI_TEST_OUT=out, MPPI_TEST_STEPS=str(steps),
+               OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [json.load(open("%s.%d" % (out, g))) for g in range(world)]
+
+
+@pytest.fixture(scope="module")
+def unsharded():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker
+    return dist_worker.run(CFG, 3)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_control_loop_matches_unsharded(world, tmp_path, unsharded):
+    res = launch(world, tmp_path)
+    # partition: contiguous, exhaustive, the integer arithmetic of mppi_create
+    assert [r["lo"] for r in res] == [g * CFG["k"] // world for g in range(world)]
+    assert res[-1]["hi"] == CFG["k"] and all(res[g]["hi"] == res[g + 1]["lo"] for g in range(world - 1))
+    for r in res[1:]:  # replicated finish: bit-identical on every rank
+        assert r["u"] == res[0]["u"] and r["U"] == res[0]["U"]
+    np.testing.assert_allclose(res[0]["u"], unsharded["u"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(res[0]["U"], unsharded["U"], rtol=0, atol=2e-6)
+
+
+def test_shard_bounds_cover_everything():
+    from mppi_tf_amd.distributed import shard_bounds
+    for k in (1, 7, 64, 65536, 524288, 1000003):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(k, g, world) for g in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == k
+            assert all(b[g][1] == b[g + 1][0] for g in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_product_backend_fails_loudly_without_gpu():
+    import torch
+    from mppi_tf_amd.distributed import HipShardBackend
+    if torch.cuda.is_available():
+        pytest.skip("checks the no-GPU failure mode")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HipShardBackend(0, 1, k=64, tau=4, s_dim=2, a_dim=1)

@@ -398,3 +398,21 @@ def test_error_behaviour(m):
     with pytest.raises(m.MppiError) as e:
         hc.next(np.zeros(4))
     assert e.value.status == 4 and "2*a_dim" in str(e.value)
+
+
+# =============================================================== the C++ host side over the C-ABI
+def test_cpp_facade_reference_vectors_and_host_loop(m):
+    """include/mppi/*.hpp (ControllerBase/CostBase/ModelBase re-created over the C-ABI) against the
+    reference's gtest vectors, and the reference-shaped host loop (src/main.cpp:30-64), as native binaries."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "test_reference_vectors")
+    loop = os.path.join(ROOT, "examples", "host_loop")
+    assert os.path.exists(exe) and os.path.exists(loop), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all reference vectors pass" in r.stdout
+    r = subprocess.run([loop, "4096", "32", "2", "80"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Execution time" in r.stdout
