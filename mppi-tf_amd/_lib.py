@@ -122,7 +122,9 @@ class Handle:
 
     def __init__(self, k, tau, s_dim, a_dim, dt=0.1, mass=1.0, lam=1.0, gamma=1.0, upsilon=1.0,
                  sigma=None, goal=None, Q=None, q_is_full=None, action_cost=ACTION_COST_CPP,
-                 normalize_cost=False, seed=1, device=0, shard_rank=0, shard_count=1):
+                 normalize_cost=False, seed=1, device=0, shard_rank=0, shard_count=1, mlp=None):
+        """mlp: dict(W=[W1,W2,W3], b=[b1,b2,b3], xmean=, xstd=, ymean=, ystd=) selects the learned
+        model_base (Dense(256,relu) x2 + Dense(s_dim); Keras [in x out] kernels)."""
         lib = self.lib = load()
         cfg = Config()
         self._check(lib.mppi_config_init(C.byref(cfg), k, tau, dt, mass, s_dim, a_dim), None)
@@ -142,6 +144,22 @@ class Handle:
                 q_is_full = q.ndim == 2
             keep.append(f32(q, (s_dim, s_dim) if q_is_full else (s_dim,)))
             cfg.Q, cfg.q_is_full = fp(keep[-1]), int(q_is_full)
+        if mlp is not None:
+            Ws = [f32(w) for w in mlp["W"]]
+            bs = [f32(b).ravel() for b in mlp["b"]]
+            keep += Ws + bs
+            desc = MlpDesc()
+            desc.n_layers = len(Ws)
+            widths = (C.c_int32 * len(Ws))(*[w.shape[1] for w in Ws])
+            Wp = (FP * len(Ws))(*[fp(w) for w in Ws])
+            bp = (FP * len(bs))(*[fp(b) for b in bs])
+            desc.widths, desc.W, desc.b = widths, Wp, bp
+            for name, n in (("xmean", s_dim + a_dim), ("xstd", s_dim + a_dim), ("ymean", s_dim), ("ystd", s_dim)):
+                if mlp.get(name) is not None:
+                    keep.append(f32(mlp[name], (n,)))
+                    setattr(desc, name, fp(keep[-1]))
+            keep += [desc, widths, Wp, bp]
+            cfg.model_kind, cfg.mlp = MODEL_MLP, C.pointer(desc)
         self.h = _H()
         self.k, self.tau, self.s, self.a = k, tau, s_dim, a_dim
         st = lib.mppi_create(C.byref(cfg), C.byref(self.h))
@@ -218,6 +236,13 @@ class Handle:
         return out if n > 1 else out[0]
 
     # ---- graph helpers ---------------------------------------------------------------
+    def model_next(self, x, v):
+        """next state only (works for the learned model too) -> [k,s]"""
+        x, v = f32(x, (-1, self.s)), f32(v, (-1, self.a))
+        nx = np.zeros((v.shape[0], self.s), np.float32)
+        self._check(self.lib.mppi_model_step(self.h, fp(x), x.shape[0], fp(v), v.shape[0], None, None, fp(nx)))
+        return nx
+
     def model_step(self, x, v):
         """-> (free [kx,s], action [k,s], next [k,s])"""
         x, v = f32(x, (-1, self.s)), f32(v, (-1, self.a))

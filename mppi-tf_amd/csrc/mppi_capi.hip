@@ -23,7 +23,11 @@ struct mppi_handle {
     DevConsts *dC = nullptr;
     int K_global = 0, K_local = 0, k_offset = 0, shard_rank = 0, shard_count = 1;
     int H = 0, s = 0, a = 0, HA = 0;
-    int R = 64, nb = 0;
+    int R = 64, nb = 0;   // tile size / record count of the point-mass tile kernels
+    int nb_mlp = 0;       // record count of the MLP rollout kernel (32 rollouts per workgroup)
+    MlpDev hm{};          // learned model: device pointers + normalisation (host copy)
+    MlpDev *dM = nullptr;
+    float *d_mlp_w = nullptr; // one allocation holding W1,b1,W2,b2,W3,b3
     size_t tile_lds = 0;
     int normalize = 0;
     int sigma_diag = 0; // Σ and Σ⁻¹ are exactly diagonal (the DIAG kernel instances are bit-identical then)
@@ -144,6 +148,8 @@ extern "C" void mppi_destroy(mppi_handle *h)
                      h->d_Uupd, h->d_mm, h->d_eps};
     for (float *p : bufs) if (p) (void)hipFree(p);
     if (h->d_step) (void)hipFree(h->d_step);
+    if (h->dM) (void)hipFree(h->dM);
+    if (h->d_mlp_w) (void)hipFree(h->d_mlp_w);
     if (h->dC) (void)hipFree(h->dC);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -162,8 +168,16 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     if (cfg->shard_count < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_count)
         return fail(nullptr, MPPI_ERR_INVALID_ARG, "bad shard_rank/shard_count");
     if (cfg->model_kind == MPPI_MODEL_POINT_MASS && !(cfg->mass != 0.0f)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "mass must be non-zero");
-    if (cfg->model_kind != MPPI_MODEL_POINT_MASS)
-        return fail(nullptr, MPPI_ERR_UNSUPPORTED, "model kind not implemented in this build");
+    if (cfg->model_kind != MPPI_MODEL_POINT_MASS && cfg->model_kind != MPPI_MODEL_MLP)
+        return fail(nullptr, MPPI_ERR_INVALID_ARG, "unknown model kind");
+    if (cfg->model_kind == MPPI_MODEL_MLP) {
+        const mppi_mlp_desc *d = cfg->mlp;
+        if (!d || !d->widths || !d->W || !d->b) return fail(nullptr, MPPI_ERR_INVALID_ARG, "MLP model needs cfg.mlp with widths, W, b");
+        if (d->n_layers != 3 || d->widths[0] != kHid || d->widths[1] != kHid || d->widths[2] != s)
+            return fail(nullptr, MPPI_ERR_UNSUPPORTED, "the MLP kernels implement Dense(256,relu) x2 + Dense(s_dim): widths must be {256,256,s_dim}");
+        for (int l = 0; l < 3; ++l) if (!d->W[l] || !d->b[l]) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NULL MLP weight pointer");
+        if (s != 2 * a || a > 4) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "MLP rollouts are instantiated for s_dim == 2*a_dim, a_dim <= 4");
+    }
 
     int ndev = mppi_device_count();
     if (ndev <= 0) return fail(nullptr, MPPI_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
@@ -224,6 +238,7 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     else if (a > 4) h->no_rollout = "rollout kernels are instantiated for a_dim <= 4";
     else if (tile_lds_floats(h->HA, R) * 4 > lds_cap) h->no_rollout = "tau*a_dim too large: the 16-rollout LDS tile exceeds 160 KiB";
     h->R = R; h->nb = (h->K_local + R - 1) / R; h->tile_lds = tile_lds_floats(h->HA, R) * 4;
+    h->nb_mlp = cfg->model_kind == MPPI_MODEL_MLP ? (h->K_local + kMlpR - 1) / kMlpR : 0;
 
     mppi_status st = MPPI_OK;
     auto body = [&]() -> mppi_status {
@@ -235,8 +250,30 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         HIP_TRY(h, hipMalloc((void **)&h->d_u, sizeof(float) * kMaxA));
         HIP_TRY(h, hipMalloc((void **)&h->d_cost, sizeof(float) * h->K_local));
         HIP_TRY(h, hipMalloc((void **)&h->d_cost2, sizeof(float) * h->K_local));
-        HIP_TRY(h, hipMalloc((void **)&h->d_part, sizeof(float) * (size_t)h->nb * (2 + h->HA)));
-        HIP_TRY(h, hipMalloc((void **)&h->d_part2, sizeof(float) * (size_t)((h->nb + kGroup - 1) / kGroup) * (2 + h->HA)));
+        const int nrec = std::max(h->nb, h->nb_mlp);
+        HIP_TRY(h, hipMalloc((void **)&h->d_part, sizeof(float) * (size_t)nrec * (2 + h->HA)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_part2, sizeof(float) * (size_t)((nrec + kGroup - 1) / kGroup) * (2 + h->HA)));
+        if (cfg->model_kind == MPPI_MODEL_MLP) {
+            const mppi_mlp_desc *d = cfg->mlp;
+            const int nin = s + a;
+            const size_t n1 = (size_t)nin * kHid, n2 = (size_t)kHid * kHid, n3 = (size_t)kHid * s;
+            const size_t total = n1 + kHid + n2 + kHid + n3 + s;
+            HIP_TRY(h, hipMalloc((void **)&h->d_mlp_w, sizeof(float) * total));
+            HIP_TRY(h, hipMalloc((void **)&h->dM, sizeof(MlpDev)));
+            float *p = h->d_mlp_w;
+            const float *src[6] = {d->W[0], d->b[0], d->W[1], d->b[1], d->W[2], d->b[2]};
+            const size_t len[6] = {n1, (size_t)kHid, n2, (size_t)kHid, n3, (size_t)s};
+            const float **dst[6] = {&h->hm.W1, &h->hm.b1, &h->hm.W2, &h->hm.b2, &h->hm.W3, &h->hm.b3};
+            for (int i = 0; i < 6; ++i) {
+                HIP_TRY(h, hipMemcpyAsync(p, src[i], sizeof(float) * len[i], hipMemcpyHostToDevice, h->stream));
+                *dst[i] = p;
+                p += len[i];
+            }
+            for (int i = 0; i < nin; ++i) { h->hm.xmean[i] = d->xmean ? d->xmean[i] : 0.f; h->hm.xstd[i] = d->xstd ? d->xstd[i] : 1.f; }
+            for (int i = 0; i < s; ++i) { h->hm.ymean[i] = d->ymean ? d->ymean[i] : 0.f; h->hm.ystd[i] = d->ystd ? d->ystd[i] : 1.f; }
+            HIP_TRY(h, hipMemcpyAsync(h->dM, &h->hm, sizeof(MlpDev), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
         HIP_TRY(h, hipMalloc((void **)&h->d_record, sizeof(float) * (2 + h->HA)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dbg, sizeof(float) * 8));
         HIP_TRY(h, hipMalloc((void **)&h->d_Uupd, sizeof(float) * h->HA));
@@ -340,6 +377,41 @@ static hipError_t launch_pc(mppi_handle *h, hipStream_t st, const float *x_dev)
     return hipErrorInvalidValue;
 }
 
+// learned-model rollouts (k_rollout_mlp): 32 rollouts per workgroup of 8 waves
+template <int A>
+static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
+                               const float *eps, float *cost)
+{
+    const size_t lds = mlp_lds_floats(2 * A) * 4;
+    const dim3 g(h->nb_mlp), b(kMlpThreads);
+#define MPPI_MLP_L(QF, DG, SRC, MODE) hipLaunchKernelGGL((k_rollout_mlp<A, QF, DG, SRC, MODE>), g, b, lds, st, h->dC, h->dM, x_dev, U_dev, eps, h->d_step, cost, h->d_part)
+#define MPPI_MLP_SM(QF, DG)                                                                     \
+    do {                                                                                        \
+        if (src == SRC_PHILOX && mode == MODE_ROLLOUT) MPPI_MLP_L(QF, DG, SRC_PHILOX, MODE_ROLLOUT);          \
+        else if (src == SRC_HBM && mode == MODE_ROLLOUT) MPPI_MLP_L(QF, DG, SRC_HBM, MODE_ROLLOUT);           \
+        else if (src == SRC_PHILOX && mode == MODE_COST_ONLY) MPPI_MLP_L(QF, DG, SRC_PHILOX, MODE_COST_ONLY); \
+        else if (src == SRC_HBM && mode == MODE_COST_ONLY) MPPI_MLP_L(QF, DG, SRC_HBM, MODE_COST_ONLY);       \
+        else return hipErrorInvalidValue;                                                       \
+    } while (0)
+    if (h->hc.q_full) { if (h->sigma_diag) MPPI_MLP_SM(true, true); else MPPI_MLP_SM(true, false); }
+    else { if (h->sigma_diag) MPPI_MLP_SM(false, true); else MPPI_MLP_SM(false, false); }
+#undef MPPI_MLP_SM
+#undef MPPI_MLP_L
+    return hipGetLastError();
+}
+
+static hipError_t launch_mlp(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
+                             const float *eps, float *cost)
+{
+    switch (h->a) {
+    case 1: return launch_mlp_a<1>(h, st, src, mode, x_dev, U_dev, eps, cost);
+    case 2: return launch_mlp_a<2>(h, st, src, mode, x_dev, U_dev, eps, cost);
+    case 3: return launch_mlp_a<3>(h, st, src, mode, x_dev, U_dev, eps, cost);
+    case 4: return launch_mlp_a<4>(h, st, src, mode, x_dev, U_dev, eps, cost);
+    }
+    return hipErrorInvalidValue;
+}
+
 static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *recs, int nb, float *U, float *u_out,
                                 float *record_out, int apply, float *U_updated)
 {
@@ -361,13 +433,16 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
     return e;
 }
 
-// rollouts of this shard -> partial records (d_part, nb of them). Handles normalizeCost.
-static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, const float *x_dev, const float *eps, float *noise_out)
+// rollouts of this shard -> partial records in d_part; *nrec = how many. Handles normalizeCost.
+static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, const float *x_dev, const float *eps, float *noise_out, int *nrec)
 {
+    const bool mlp = h->hc.model_kind == MPPI_MODEL_MLP;
+    *nrec = mlp ? h->nb_mlp : h->nb;
     if (!h->normalize) {
         const bool prof = h->prof_n < h->prof_cap;
         if (prof) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 0], st));
-        if (src == SRC_PHILOX && noise_out == nullptr && pc_eligible(h)) HIP_TRY(h, launch_pc(h, st, x_dev));
+        if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_ROLLOUT, x_dev, h->d_U, eps, h->d_cost));
+        else if (src == SRC_PHILOX && noise_out == nullptr && pc_eligible(h)) HIP_TRY(h, launch_pc(h, st, x_dev));
         else HIP_TRY(h, launch_tile(h, st, src, MODE_ROLLOUT, x_dev, h->d_U, eps, h->d_cost, h->d_part, noise_out));
         if (prof) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 1], st));
         return MPPI_OK;
@@ -375,12 +450,14 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
     if (h->shard_count != 1) return fail(h, MPPI_ERR_UNSUPPORTED, "normalize_cost needs the global max cost: unsharded handles only");
     // Py normalizeCost (controller_base.py:468-474): costs, global min/max, then the update on
     // c' = (c-min)/(max-min) with the SAME noise (regenerated from the same Philox counters).
-    HIP_TRY(h, launch_tile(h, st, src, MODE_COST_ONLY, x_dev, h->d_U, eps, h->d_cost, h->d_part, noise_out));
+    if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_COST_ONLY, x_dev, h->d_U, eps, h->d_cost));
+    else HIP_TRY(h, launch_tile(h, st, src, MODE_COST_ONLY, x_dev, h->d_U, eps, h->d_cost, h->d_part, noise_out));
     hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(kFinishThreads), 0, st, h->d_cost, h->K_local, h->d_mm);
     HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(k_cost_normalize, dim3((h->K_local + 255) / 256), dim3(256), 0, st, h->d_cost, h->K_local, h->d_mm, h->d_cost2);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, launch_tile(h, st, src, MODE_COSTS_GIVEN, x_dev, h->d_U, eps, h->d_cost2, h->d_part, nullptr));
+    *nrec = h->nb;
     return MPPI_OK;
 }
 
@@ -456,9 +533,10 @@ extern "C" mppi_status mppi_next_device(mppi_handle *h, const float *x_dev, floa
     if (h->shard_count != 1) return fail(h, MPPI_ERR_INVALID_ARG, "sharded handle: use mppi_shard_partial / mppi_shard_finish");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr);
+    int nrec = 0;
+    mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr, &nrec);
     if (s != MPPI_OK) return s;
-    HIP_TRY(h, launch_finish(h, st, h->d_part, h->nb, h->d_U, u_dev, nullptr, 1, h->d_Uupd));
+    HIP_TRY(h, launch_finish(h, st, h->d_part, nrec, h->d_U, u_dev, nullptr, 1, h->d_Uupd));
     return MPPI_OK;
 }
 
@@ -467,9 +545,10 @@ extern "C" mppi_status mppi_shard_partial(mppi_handle *h, const float *x_dev, fl
     if (!h || !x_dev || !record_dev) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL device pointer") : MPPI_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr);
+    int nrec = 0;
+    mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr, &nrec);
     if (s != MPPI_OK) return s;
-    HIP_TRY(h, launch_finish(h, st, h->d_part, h->nb, h->d_U, h->d_u, record_dev, 0, nullptr));
+    HIP_TRY(h, launch_finish(h, st, h->d_part, nrec, h->d_U, h->d_u, record_dev, 0, nullptr));
     return MPPI_OK;
 }
 
@@ -499,9 +578,10 @@ static mppi_status step_host(mppi_handle *h, const float *x, int n_x, const floa
     }
     std::memcpy(h->h_pin, x, sizeof(float) * h->s);
     HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_pin, sizeof(float) * h->s, hipMemcpyHostToDevice, h->stream));
-    mppi_status s = enqueue_partials(h, h->stream, src, h->d_x, h->d_eps, nullptr);
+    int nrec = 0;
+    mppi_status s = enqueue_partials(h, h->stream, src, h->d_x, h->d_eps, nullptr, &nrec);
     if (s != MPPI_OK) return s;
-    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, h->nb, h->d_U, h->d_u, nullptr, 1, h->d_Uupd));
+    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, nrec, h->d_U, h->d_u, nullptr, 1, h->d_Uupd));
     HIP_TRY(h, hipMemcpyAsync(h->h_pin + kMaxS, h->d_u, sizeof(float) * h->a, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::memcpy(u_out, h->h_pin + kMaxS, sizeof(float) * h->a);
@@ -655,9 +735,19 @@ extern "C" mppi_status mppi_model_step(mppi_handle *h, const float *x, int kx, c
 {
     if (!h) return MPPI_ERR_INVALID_ARG;
     if (!x || !v || k <= 0 || (kx != k && kx != 1)) return fail(h, MPPI_ERR_INVALID_ARG, "x is [kx,s] with kx in {1,k}; v is [k,a]");
-    if (h->hc.model_kind != MPPI_MODEL_POINT_MASS) return fail(h, MPPI_ERR_UNSUPPORTED, "free/action split exists for the point-mass model only");
     HIP_TRY(h, hipSetDevice(h->device));
     const int s = h->s, a = h->a;
+    if (h->hc.model_kind == MPPI_MODEL_MLP) {
+        if (out_free || out_action) return fail(h, MPPI_ERR_UNSUPPORTED, "the free/action split exists for the point-mass model only");
+        DevBuf dx, dv, dn, ds;
+        HIP_TRY(h, dx.alloc((size_t)kx * s)); HIP_TRY(h, dv.alloc((size_t)k * a)); HIP_TRY(h, dn.alloc((size_t)k * s)); HIP_TRY(h, ds.alloc((size_t)k * 2 * kHid));
+        HIP_TRY(h, dx.up(x, (size_t)kx * s, h->stream)); HIP_TRY(h, dv.up(v, (size_t)k * a, h->stream));
+        hipLaunchKernelGGL(k_mlp_step_ref, dim3((k + 63) / 64), dim3(64), 0, h->stream, h->dC, h->dM, dx.p, kx, dv.p, k, ds.p, dn.p);
+        HIP_TRY(h, hipGetLastError());
+        if (out_next) HIP_TRY(h, dn.down(out_next, (size_t)k * s, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return MPPI_OK;
+    }
     DevBuf dx, dv, df, da, dn;
     HIP_TRY(h, dx.alloc((size_t)kx * s)); HIP_TRY(h, dv.alloc((size_t)k * a));
     HIP_TRY(h, df.alloc((size_t)kx * s)); HIP_TRY(h, da.alloc((size_t)k * s)); HIP_TRY(h, dn.alloc((size_t)k * s));
@@ -744,7 +834,8 @@ extern "C" mppi_status mppi_rollout_cost(mppi_handle *h, const float *x, const f
     HIP_TRY(h, dx.alloc(h->s)); HIP_TRY(h, dU.alloc(h->HA)); HIP_TRY(h, dc.alloc(h->K_local));
     HIP_TRY(h, dx.up(x, h->s, h->stream)); HIP_TRY(h, dU.up(U, h->HA, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_eps, eps, sizeof(float) * (size_t)h->K_local * h->HA, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, launch_tile(h, h->stream, SRC_HBM, MODE_COST_ONLY, dx.p, dU.p, h->d_eps, dc.p, h->d_part, nullptr));
+    if (h->hc.model_kind == MPPI_MODEL_MLP) HIP_TRY(h, launch_mlp(h, h->stream, SRC_HBM, MODE_COST_ONLY, dx.p, dU.p, h->d_eps, dc.p));
+    else HIP_TRY(h, launch_tile(h, h->stream, SRC_HBM, MODE_COST_ONLY, dx.p, dU.p, h->d_eps, dc.p, h->d_part, nullptr));
     HIP_TRY(h, dc.down(cost_out, h->K_local, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MPPI_OK;

@@ -470,6 +470,247 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// Learned model_base (BASELINE configs[3]/[4]):
+//   in = ([x;v]-Xmean)/Xstd ; h1 = relu(W1ᵀin+b1) ; h2 = relu(W2ᵀh1+b2) ; y = W3ᵀh2+b3 ;
+//   x' = x + (y·Ystd + Ymean)          (nn_model.py:215-239,289-304 convention; 2 x 256 hidden units)
+// Device-side weights, Keras layout [in x out] row-major.
+constexpr int kHid = 256;
+struct MlpDev {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    float xmean[kMaxS + kMaxA], xstd[kMaxS + kMaxA], ymean[kMaxS], ystd[kMaxS];
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// One sample per thread, plain loops in the reference order (mul and add rounded separately,
+// input index ascending): the slow, exactly-ordered evaluation behind mppi_model_step for MLP handles.
+__global__ void k_mlp_step_ref(const DevConsts *__restrict__ C, const MlpDev *__restrict__ M,
+                               const float *__restrict__ x, int kx, const float *__restrict__ v, int k,
+                               float *__restrict__ scratch, float *__restrict__ out_next)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const int s = C->s, a = C->a, nin = s + a;
+    float *h0 = scratch + (size_t)i * 2 * kHid, *h1 = h0 + kHid;
+    const float *xi = x + (size_t)(kx == 1 ? 0 : i) * s;
+    float in[kMaxS + kMaxA];
+    for (int j = 0; j < s; ++j) in[j] = (xi[j] - M->xmean[j]) / M->xstd[j];
+    for (int j = 0; j < a; ++j) in[s + j] = (v[(size_t)i * a + j] - M->xmean[s + j]) / M->xstd[s + j];
+    for (int o = 0; o < kHid; ++o) {
+        float acc = 0.0f;
+        for (int j = 0; j < nin; ++j) acc = acc + in[j] * M->W1[j * kHid + o];
+        acc = acc + M->b1[o];
+        h0[o] = acc < 0.0f ? 0.0f : acc;
+    }
+    for (int o = 0; o < kHid; ++o) {
+        float acc = 0.0f;
+        for (int j = 0; j < kHid; ++j) acc = acc + h0[j] * M->W2[j * kHid + o];
+        acc = acc + M->b2[o];
+        h1[o] = acc < 0.0f ? 0.0f : acc;
+    }
+    for (int o = 0; o < s; ++o) {
+        float acc = 0.0f;
+        for (int j = 0; j < kHid; ++j) acc = acc + h1[j] * M->W3[j * s + o];
+        acc = acc + M->b3[o];
+        out_next[(size_t)i * s + o] = xi[o] + (acc * M->ystd[o] + M->ymean[o]);
+    }
+}
+
+// k_rollout_mlp: one workgroup of 8 wavefronts owns 32 rollouts for the whole horizon.
+// Transposed formulation hᵀ = Wᵀ·inᵀ so that the rollout index sits on the LANE of every MFMA
+// operand and result (lane&31 = rollout) and everything per-rollout (state, cost, noise) is lane-local:
+//   A operand = weights, WEIGHT-STATIONARY in registers: wave w owns hidden units [32w,32w+32) of both
+//       layers: 128+1 VGPRs of W2 (k pairs (2s,2s+1) in lane halves; bias as k=256 against a row of
+//       ones) and 5 VGPRs of W1 (k = 0..8 inputs, 9 = bias);
+//   B operand = activations [k][rollout]: layer 1 from the lane's own normalised inputs (a select, no
+//       data movement), layer 2 from h1ᵀ in LDS ([256][32] fp32 = 32 KB, conflict-free row reads);
+//   v_mfma_f32_32x32x2_f32: exact fp32 (a k-ordered fmaf chain), 64 FLOP/clk/SIMD = the fp32 peak.
+//   layer 3 (256 -> s) is 2 % of the FLOPs: VALU partial dot products over the wave's 32 units straight
+//       from the accumulator registers, lane halves and the 8 waves summed in fixed order through LDS.
+// Every wave carries the (identical) state, cost and noise of its 32 rollouts redundantly: the
+// per-step VALU work is ~1 % of the MFMA time and it saves a broadcast per step. The weighted-noise sum
+// regenerates eps from the Philox counters at the end (cheap next to 64 steps of MFMA).
+// Two s_barriers per horizon step. LDS: 32 KB h1 + 6 KB partial y + 6 KB W3.
+constexpr int kMlpThreads = 512;
+constexpr int kMlpR = 32;
+__host__ __device__ inline size_t mlp_lds_floats(int S) { return (size_t)kHid * kMlpR + 8 * S * kMlpR + kHid * S + 64; }
+
+template <int A, bool QFULL, bool DIAG, int SRC, int MODE>
+__global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
+    const DevConsts *__restrict__ C, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
+    const float *__restrict__ U_dev, const float *__restrict__ eps_hbm,
+    const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int S = 2 * A, NIN = S + A;
+    constexpr int K1 = (NIN + 2) / 2 * 2; // inputs + bias, padded to the MFMA's k pairs (10 for s=6,a=3)
+    constexpr int R = kMlpR;
+    const int H = C->H, HA = H * A, K = C->K_local;
+    const int NG = (H + 3) / 4;
+    float *h1_s = smem;                 // [kHid][R]
+    float *y_s = h1_s + kHid * R;       // [8][S][R]
+    float *w3_s = y_s + 8 * S * R;      // [kHid][S]
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, j = lane & 31, hh = lane >> 5;
+    const int k0 = blockIdx.x * R;
+    const bool valid = (k0 + j) < K;
+    const int kk = valid ? k0 + j : K - 1; // clamp: out-of-range lanes recompute the last sample, masked later
+
+    // ---- stationary weights -> registers
+    float a2[kHid / 2 + 1], a1[K1 / 2];
+    const int unit = 32 * w + j;
+#pragma unroll
+    for (int s2 = 0; s2 < kHid / 2; ++s2) a2[s2] = M->W2[(size_t)(2 * s2 + hh) * kHid + unit];
+    a2[kHid / 2] = hh == 0 ? M->b2[unit] : 0.0f;
+#pragma unroll
+    for (int s1 = 0; s1 < K1 / 2; ++s1) {
+        const int kin = 2 * s1 + hh;
+        a1[s1] = kin < NIN ? M->W1[(size_t)kin * kHid + unit] : (kin == NIN ? M->b1[unit] : 0.0f);
+    }
+    for (int i = tid; i < kHid * S; i += kMlpThreads) w3_s[i] = M->W3[i];
+
+    float x[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+    float c = 0.0f;
+    const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)kk;
+    const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
+    const unsigned long long seed = C->seed;
+    float z[4 * A];
+    __syncthreads();
+
+    for (int t = 0; t < H; ++t) {
+        float u[A], e[A], v[A];
+        if (SRC == SRC_PHILOX) {
+            if ((t & 3) == 0) normals_group<A>(seed, gk, base + (unsigned long long)(t >> 2), z);
+            float zz[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) { // z[(t&3)*A + i] with a static index
+                zz[i] = (t & 3) == 0 ? z[i] : (t & 3) == 1 ? z[A + i] : (t & 3) == 2 ? z[2 * A + i] : z[3 * A + i];
+            }
+            scale_noise<A, DIAG>(C, zz, e);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
+        }
+#pragma unroll
+        for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
+        const float ac = action_cost<A, DIAG>(C, u, e);
+
+        // normalised inputs (+ the bias input 1, + zero padding)
+        float in[K1];
+#pragma unroll
+        for (int i = 0; i < S; ++i) in[i] = (x[i] - M->xmean[i]) / M->xstd[i];
+#pragma unroll
+        for (int i = 0; i < A; ++i) in[S + i] = (v[i] - M->xmean[S + i]) / M->xstd[S + i];
+        in[NIN] = 1.0f;
+#pragma unroll
+        for (int i = NIN + 1; i < K1; ++i) in[i] = 0.0f;
+
+        // ---- layer 1: h1ᵀ[32w.., :] = relu(W1ᵀ in + b1)
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s1 = 0; s1 < K1 / 2; ++s1) {
+            const float b = hh ? in[2 * s1 + 1] : in[2 * s1];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s1], b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            h1_s[(32 * w + row) * R + j] = acc[r] < 0.0f ? 0.0f : acc[r];
+        }
+        __syncthreads();
+
+        // ---- layer 2: h2ᵀ[32w.., :] = relu(W2ᵀ h1 + b2), 128 k pairs + the bias pair
+        f32x16 acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // batches of 8 k pairs: 8 LDS reads in flight, then 8 dependent MFMAs (64 cycles each, so the
+        // next batch's reads hide under them); the scheduling fence keeps the compiler from hoisting all
+        // 128 reads at once (that spilled: 128 weights + 128 operands > 256 VGPRs)
+        const float *h1p = h1_s + hh * R + j;
+#pragma unroll
+        for (int sb = 0; sb < kHid / 2; sb += 8) {
+            float bq[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bq[q] = h1p[2 * (sb + q) * R];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[sb + q], bq[q], acc2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kHid / 2], hh == 0 ? 1.0f : 0.0f, acc2, 0, 0, 0);
+
+        // ---- layer 3 partial over this wave's 32 units (16 per lane half), VALU
+        float py[S];
+#pragma unroll
+        for (int n = 0; n < S; ++n) py[n] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float hv = acc2[r] < 0.0f ? 0.0f : acc2[r];
+            const float *w3 = w3_s + (32 * w + row) * S;
+#pragma unroll
+            for (int n = 0; n < S; ++n) py[n] = __builtin_fmaf(hv, w3[n], py[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < S; ++n) {
+            const float other = __shfl_xor(py[n], 32, 64);
+            if (hh == 0) y_s[(w * S + n) * R + j] = py[n] + other;
+        }
+        __syncthreads();
+
+        // ---- y = Σ_waves partial + b3 (fixed order), state update, costs
+#pragma unroll
+        for (int n = 0; n < S; ++n) {
+            float y = y_s[(0 * S + n) * R + j];
+#pragma unroll
+            for (int ww = 1; ww < 8; ++ww) y = y + y_s[(ww * S + n) * R + j];
+            y = y + M->b3[n];
+            x[n] = x[n] + (y * M->ystd[n] + M->ymean[n]);
+        }
+        const float sc = state_cost<S, QFULL>(C, x); // cost on the POST-step state
+        const float tmp = sc + ac;
+        c = c + tmp;
+    }
+    c = c + state_cost<S, QFULL>(C, x); // terminal cost, controller_base.cpp:271-272
+    if (w == 0 && hh == 0 && valid) cost[k0 + j] = c;
+    if (MODE == MODE_COST_ONLY) return;
+
+    // ---- tile record: every wave holds the same 32 costs; lane half 1 is masked out
+    const bool live = valid && hh == 0;
+    const float beta = wave_min(live ? c : INFINITY);
+    const float ek = live ? expf(C->neg_inv_lambda * (c - beta)) : 0.0f;
+    const float eta = wave_sum(ek);
+    float *rec = partials + (size_t)blockIdx.x * (2 + HA);
+    if (w == 0 && lane == 0) { rec[0] = beta; rec[1] = eta; }
+    // V_b[t,i] = Σ_k e_k·eps[k,t,i]: wave w regenerates the noise of horizon groups g = w, w+8, ...
+    for (int g = w; g < NG; g += 8) {
+        float zz[4 * A];
+        if (SRC == SRC_PHILOX) normals_group<A>(seed, gk, base + (unsigned long long)g, zz);
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            const int t = 4 * g + tl;
+            if (t < H) {
+                float z1[A], e[A];
+                if (SRC == SRC_PHILOX) {
+#pragma unroll
+                    for (int i = 0; i < A; ++i) z1[i] = zz[tl * A + i];
+                    scale_noise<A, DIAG>(C, z1, e);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
+                }
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    const float tot = wave_sum_dpp(ek * e[i]);
+                    if (lane == 0) rec[2 + t * A + i] = tot;
+                }
+            }
+        }
+    }
+}
+
 // min / max of the costs (Py normalizeCost, controller_base.py:468-474): out[0]=min, out[1]=max-min
 __global__ __launch_bounds__(kFinishThreads) void k_cost_minmax(const float *__restrict__ cost, int K, float *__restrict__ out)
 {

@@ -416,3 +416,121 @@ def test_cpp_facade_reference_vectors_and_host_loop(m):
     r = subprocess.run([loop, "4096", "32", "2", "80"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Execution time" in r.stdout
+
+
+# =============================================================== M2: learned 2x256 MLP model_base (parity unpinned by the reference)
+def make_mlp(s, a, seed=0, hid=256):
+    """SURVEY §8d synthetic weights: U(-1/sqrt(fan_in), 1/sqrt(fan_in)), last layer x0.1."""
+    rng = np.random.default_rng(seed)
+    dims = [s + a, hid, hid, s]
+    W = [rng.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i]) for i in range(3)]
+    b = [rng.uniform(-1, 1, dims[i + 1]) / np.sqrt(dims[i]) for i in range(3)]
+    W[2] *= 0.1
+    b[2] *= 0.1
+    return dict(W=[w.astype(F32) for w in W], b=[v.astype(F32) for v in b],
+                xmean=rng.uniform(-0.1, 0.1, s + a).astype(F32), xstd=rng.uniform(0.8, 1.2, s + a).astype(F32),
+                ymean=rng.uniform(-0.01, 0.01, s).astype(F32), ystd=rng.uniform(0.8, 1.2, s).astype(F32))
+
+
+def make_mlp_pair(m, K, H, a, mlp, lam=1.0, **kw):
+    s = 2 * a
+    sigma, goal = 0.25 * np.eye(a), (GOAL3 + [0.25, 0])[:s]
+    h = m.Handle(k=K, tau=H, s_dim=s, a_dim=a, lam=lam, sigma=sigma, goal=goal, mlp=mlp, **kw)
+    p32 = orc.Problem(tau=H, s=s, a=a, lam=lam, sigma=sigma, goal=goal, mlp=mlp, threads=0)
+    p64 = orc.Problem(tau=H, s=s, a=a, lam=lam, sigma=sigma, goal=goal, mlp=mlp, threads=0, dtype=np.float64)
+    return h, p32, p64
+
+
+def test_mlp_single_step_reference_order_is_bit_exact(m):
+    """mppi_model_step on an MLP handle evaluates the layers in the oracle's order (mul, add rounded
+    separately, ascending input index): bit-identical."""
+    a, s = 3, 6
+    mlp = make_mlp(s, a, seed=3)
+    h, p32, _ = make_mlp_pair(m, 64, 4, a, mlp)
+    rng = np.random.default_rng(0)
+    X, V = rng.standard_normal((50, s)).astype(F32), rng.standard_normal((50, a)).astype(F32)
+    got = h.model_next(X, V)
+    ref = np.stack([p32.mlp_step(X[i], V[i]) for i in range(50)])
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("K,H,a", [(2048, 64, 3), (100, 16, 3), (33, 5, 2), (4096, 32, 1)])
+def test_mlp_rollout_costs_within_fp32_of_truth(m, K, H, a):
+    """MFMA rollouts (fmaf chains, k-ordered) vs the fp64 oracle ('truth') and the fp32 oracle (unfused):
+    the GPU must be as close to the truth as the fp32 CPU evaluation is, up to a small factor."""
+    s = 2 * a
+    mlp = make_mlp(s, a, seed=K)
+    h, p32, p64 = make_mlp_pair(m, K, H, a, mlp)
+    rng = np.random.default_rng(5)
+    x0 = (0.2 * rng.standard_normal(s)).astype(F32)
+    U = (0.1 * rng.standard_normal((H, a))).astype(F32)
+    eps = (0.25 * rng.standard_normal((K, H, a))).astype(F32)
+    got = h.rollout_cost(x0, U, eps).astype(np.float64)
+    truth = p64.rollout_cost(x0, U, eps)
+    cpu32 = p32.rollout_cost(x0, U, eps).astype(np.float64)
+    err_gpu = np.abs(got - truth) / np.abs(truth)
+    err_cpu = np.abs(cpu32 - truth) / np.abs(truth)
+    assert err_gpu.max() < 2e-5, err_gpu.max()
+    assert err_gpu.max() < 4 * max(err_cpu.max(), 1e-6), (err_gpu.max(), err_cpu.max())
+
+
+def test_mlp_next_matches_oracle(m):
+    """One control step of the MLP controller: injected noise, and the fused Philox path on its own noise.
+    Stated tolerance for this (unpinned) row: 1e-4 absolute on U' (costs agree to ~1e-6 relative and the
+    soft-min amplifies a cost error dc into a weight error dc/lambda)."""
+    K, H, a = 4096, 32, 3
+    s = 2 * a
+    mlp = make_mlp(s, a, seed=9)
+    h, p32, p64 = make_mlp_pair(m, K, H, a, mlp, lam=1.0, seed=4)
+    x = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
+    rng = np.random.default_rng(6)
+    for step in range(2):
+        U_in = h.get_action_sequence()
+        eps = (0.25 * rng.standard_normal((K, H, a))).astype(F32)
+        u = h.next_with_noise(x, eps)
+        u_ref, U_ref, c_ref = p64.next_with_noise(x, U_in, eps)
+        np.testing.assert_allclose(h.debug_get(m.DBG_COSTS), c_ref, rtol=2e-5)
+        np.testing.assert_allclose(u, u_ref, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=1e-4)
+    U_in = h.get_action_sequence()
+    u = h.next(x)
+    eps = h.debug_get(m.DBG_NOISE)
+    np.testing.assert_allclose(eps, orc.noise(4, 2, 0, K, H, a, 0.25 * np.eye(a)), rtol=0, atol=5e-6)
+    u_ref, U_ref, c_ref = p64.next_with_noise(x, U_in, eps)
+    np.testing.assert_allclose(h.debug_get(m.DBG_COSTS), c_ref, rtol=2e-5)
+    np.testing.assert_allclose(u, u_ref, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=1e-4)
+    w = h.debug_get(m.DBG_WEIGHTS).astype(np.float64)
+    assert abs(w.sum() - 1) < 1e-5
+
+
+def test_mlp_sharded_equals_unsharded(m):
+    import torch
+    K, H, a, shards = 2048, 16, 3, 4
+    mlp = make_mlp(6, a, seed=2)
+    full = make_mlp_pair(m, K, H, a, mlp, seed=8)[0]
+    hs = [make_mlp_pair(m, K, H, a, mlp, seed=8, shard_rank=g, shard_count=shards)[0] for g in range(shards)]
+    x = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
+    xd = torch.tensor(x, device="cuda")
+    n = hs[0].record_size
+    recs = torch.zeros(shards * n, device="cuda")
+    us = [torch.zeros(a, device="cuda") for _ in range(shards)]
+    u_full = full.next(x)
+    for g, h in enumerate(hs):
+        h.shard_partial(xd.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
+        h.synchronize()
+    for g, h in enumerate(hs):
+        h.shard_finish(recs.data_ptr(), shards, us[g].data_ptr())
+        h.synchronize()
+        np.testing.assert_array_equal(us[g].cpu().numpy(), us[0].cpu().numpy())
+        np.testing.assert_allclose(us[g].cpu().numpy(), u_full, rtol=0, atol=2e-6)
+    c_full = full.debug_get(m.DBG_COSTS)
+    for h in hs:
+        np.testing.assert_array_equal(h.debug_get(m.DBG_COSTS), c_full[h.k_offset:h.k_offset + h.k_local])
+
+
+def test_mlp_unsupported_shapes_fail_loudly(m):
+    bad = make_mlp(6, 3, hid=128)
+    with pytest.raises(m.MppiError) as e:
+        m.Handle(k=64, tau=4, s_dim=6, a_dim=3, mlp=bad)
+    assert e.value.status == 4 and "256" in str(e.value)
