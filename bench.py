@@ -33,13 +33,29 @@ CFG = dict(tau=H, s_dim=S, a_dim=A, dt=0.1, mass=1.0, lam=1.0, sigma=SIGMA, goal
 BYTES_PER_STATE_STEP = 12 * A             # noise written once, read twice, fp32
 FLOP_PER_STATE_STEP = 6 * S + 5 * A + 3
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HID = 256                                 # BASELINE configs[3]: learned 2x256 MLP model_base
+MLP_FLOP_PER_STATE_STEP = 2 * ((S + A) * HID + HID * HID + HID * S)   # 138752, SURVEY §8d
+MFMA_F32_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
 
 
-def cpu_baseline(budget_s=12.0):
+def synthetic_mlp(seed=0):
+    """9->256->256->6 ReLU, U(-1/sqrt(fan_in), 1/sqrt(fan_in)), last layer x0.1, identity normalisation."""
+    rng = np.random.default_rng(seed)
+    dims = [S + A, HID, HID, S]
+    W = [(rng.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
+    b = [(rng.uniform(-1, 1, dims[i + 1]) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
+    W[2] *= 0.1
+    b[2] *= 0.1
+    return dict(W=W, b=b)
+
+
+def cpu_baseline(budget_s=12.0, mlp=None):
     """The CPU restatement (oracle/, OpenMP over samples) timed on this box's host cores on a bounded
-    sample of the SAME workload: whole control steps (noise + rollouts + update) at K=65536, H=64."""
+    sample of the SAME workload: whole control steps (noise + rollouts + update) at H=64 —
+    K=65536 for the analytic model, K=4096 for the MLP (stated in `sample`)."""
     from oracle import oracle as orc
-    p = orc.Problem(tau=H, s=S, a=A, dt=0.1, mass=1.0, lam=1.0, sigma=SIGMA, goal=GOAL, threads=0)
+    K_PER_GPU = 65536 if mlp is None else 4096
+    p = orc.Problem(tau=H, s=S, a=A, dt=0.1, mass=1.0, lam=1.0, sigma=SIGMA, goal=GOAL, threads=0, mlp=mlp)
     x, U = np.zeros(S, np.float32), np.zeros((H, A), np.float32)
     eps = orc.noise(1, 0, 0, K_PER_GPU, H, A, SIGMA)
     p.next_with_noise(x, U, eps)  # warm-up (page in, spin up the OpenMP team)
@@ -53,14 +69,17 @@ def cpu_baseline(budget_s=12.0):
             break
     return {"value": K_PER_GPU * n / el, "unit": "rollouts/s", "cores": orc.num_threads(), "kind": "port",
             "ms_per_step": 1e3 * el / n,
-            "sample": "%d whole control steps of point_mass3d K=%d H=%d (Philox noise + rollouts + update), "
-                      "OpenMP over samples; the reference itself (TensorFlow) is not runnable here" % (n, K_PER_GPU, H)}
+            "sample": "%d whole control steps of point_mass3d%s K=%d H=%d (Philox noise + rollouts + update), "
+                      "OpenMP over samples; the reference itself (TensorFlow) is not runnable here"
+                      % (n, "" if mlp is None else " + 2x256 MLP model", K_PER_GPU, H)}
 
 
-def sync_latency(m, steps=200, warmup=20):
+def sync_latency(m, steps=200, warmup=20, mlp=None):
     """Host-synchronous closed loop: mppi_next(x)->u with the plant stepped on the host (the shape of
     the reference's loop, main.cpp:37-43). Median / p95 ms per control step."""
-    h = m.Handle(k=K_PER_GPU, **CFG)
+    h = m.Handle(k=K_PER_GPU, mlp=mlp, **CFG)
+    if mlp is not None:
+        steps, warmup = 20, 3
     x = np.zeros(S, np.float32)
     dt, ts = 0.1, []
     for i in range(warmup + steps):
@@ -93,6 +112,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["pm3d", "mlp"], default="pm3d",
+                    help="pm3d = BASELINE configs[2] (analytic, the metric's config); mlp = configs[3] (learned 2x256 MLP)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,7 +135,8 @@ def main():
     from mppi_tf_amd.distributed import ShardedController
 
     k_global = K_PER_GPU * world
-    ctl = ShardedController(device_index=local_rank, k=k_global, **CFG)
+    mlp = synthetic_mlp() if args.workload == "mlp" else None
+    ctl = ShardedController(device_index=local_rank, k=k_global, mlp=mlp, **CFG)
     assert ctl.backend.h.k_local == K_PER_GPU
     x = torch.zeros(S, dtype=torch.float32, device=dev)
 
@@ -151,6 +173,15 @@ def main():
         state_steps = K_PER_GPU * H
         alg_bytes = BYTES_PER_STATE_STEP * state_steps + 8 * K_PER_GPU
         ach = alg_bytes / (roll_ms * 1e-3) / 1e9 if roll_ms > 0 else 0.0
+        if mlp is not None:
+            flop = MLP_FLOP_PER_STATE_STEP * state_steps
+            tf = flop / (roll_ms * 1e-3) / 1e12 if roll_ms > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": "mppi::k_rollout_mlp<3, false, true, 0, 0>", "achieved": tf,
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "algorithmic_flop_per_launch": flop, "kernel_ms_avg": roll_ms, "record_tree_kernels_ms_avg": fin_ms,
+                    "launches_timed": n_prof,
+                    "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-5-class parity target rules out bf16; "
+                            "weights stationary in registers, activations in LDS"}
         out = {
             "metric": "rollouts/s (one control step = K rollouts x H steps), point_mass3d H=64",
             "value": k_global * args.steps / el, "unit": "rollouts/s",
@@ -158,8 +189,10 @@ def main():
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "state_steps_per_s": k_global * H * args.steps / el,
-            "config": {"workload": "point_mass3d analytic model, K=%d H=%d per GPU (BASELINE configs[2]), "
-                                   "on-device Philox noise, device-resident x/U" % (K_PER_GPU, H),
+            "config": {"workload": ("point_mass3d analytic model, K=%d H=%d per GPU (BASELINE configs[2]), "
+                                    "on-device Philox noise, device-resident x/U" % (K_PER_GPU, H)) if mlp is None else
+                                   ("point_mass3d learned 2x256 MLP model_base, K=%d H=%d per GPU (BASELINE configs[3]), "
+                                    "on-device Philox noise, device-resident x/U" % (K_PER_GPU, H)),
                        "K_global": k_global, "K_per_gpu": K_PER_GPU, "H": H, "s_dim": S, "a_dim": A,
                        "lambda": 1.0, "sigma": "0.25*I", "dt": 0.1, "mass": 1.0,
                        "parallelism": "K-shard x%d, one all-gather of %d floats per step" % (world, h.record_size)},
@@ -175,12 +208,14 @@ def main():
                                  "the 12a B/state-step materialised-noise model; the true limiter is VALU "
                                  "(Philox4x32-10 + Box-Muller). See DESIGN.md §4."},
         }
+        if mlp is not None:
+            out["roofline"] = roof
         if world == 1:
-            med, p95 = sync_latency(m)
+            med, p95 = sync_latency(m, mlp=mlp)
             out["ms_per_control_step_sync"] = {"median": med, "p95": p95,
                                                "what": "host-synchronous mppi_next(x)->u incl. H2D x, D2H u, 200 closed-loop steps"}
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(mlp=mlp)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

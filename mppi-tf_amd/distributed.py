@@ -54,6 +54,7 @@ class ShardedController:
     """
 
     def __init__(self, backend=None, group=None, device_index=0, **cfg):
+        """cfg: Handle arguments (k = GLOBAL sample count, tau, s_dim, a_dim, sigma, goal, mlp, ...)."""
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
