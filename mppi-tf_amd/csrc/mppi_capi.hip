@@ -382,9 +382,19 @@ template <int A>
 static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
                                const float *eps, float *cost)
 {
-    const size_t lds = mlp_lds_floats(2 * A) * 4;
+    const size_t lds = mlp_lds_floats(2 * A, A) * 4;
     const dim3 g(h->nb_mlp), b(kMlpThreads);
-#define MPPI_MLP_L(QF, DG, SRC, MODE) hipLaunchKernelGGL((k_rollout_mlp<A, QF, DG, SRC, MODE>), g, b, lds, st, h->dC, h->dM, x_dev, U_dev, eps, h->d_step, cost, h->d_part)
+#define MPPI_MLP_L(QF, DG, SRC, MODE)                                                                                   \
+    do {                                                                                                                \
+        auto kern = k_rollout_mlp<A, QF, DG, SRC, MODE>;                                                                \
+        static thread_local bool attr_done = false;                                                                     \
+        if (!attr_done) {                                                                                               \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e_ != hipSuccess) return e_;                                                                            \
+            attr_done = true;                                                                                           \
+        }                                                                                                               \
+        hipLaunchKernelGGL(kern, g, b, lds, st, h->dC, h->dM, x_dev, U_dev, eps, h->d_step, cost, h->d_part);         \
+    } while (0)
 #define MPPI_MLP_SM(QF, DG)                                                                     \
     do {                                                                                        \
         if (src == SRC_PHILOX && mode == MODE_ROLLOUT) MPPI_MLP_L(QF, DG, SRC_PHILOX, MODE_ROLLOUT);          \

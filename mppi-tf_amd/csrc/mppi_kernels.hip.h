@@ -517,24 +517,31 @@ __global__ void k_mlp_step_ref(const DevConsts *__restrict__ C, const MlpDev *__
     }
 }
 
-// k_rollout_mlp: one workgroup of 8 wavefronts owns 32 rollouts for the whole horizon.
+// k_rollout_mlp: one workgroup of 8 wavefronts owns 64 rollouts for the whole horizon.
 // Transposed formulation hᵀ = Wᵀ·inᵀ so that the rollout index sits on the LANE of every MFMA
-// operand and result (lane&31 = rollout) and everything per-rollout (state, cost, noise) is lane-local:
+// operand and result and everything per-rollout (state, cost, noise) is lane-local:
 //   A operand = weights, WEIGHT-STATIONARY in registers: wave w owns hidden units [32w,32w+32) of both
-//       layers: 128+1 VGPRs of W2 (k pairs (2s,2s+1) in lane halves; bias as k=256 against a row of
+//       layers: 128+1 VGPRs of W2 (k pairs (2s,2s+1) in the lane halves; bias as k=256 against a row of
 //       ones) and 5 VGPRs of W1 (k = 0..8 inputs, 9 = bias);
-//   B operand = activations [k][rollout]: layer 1 from the lane's own normalised inputs (a select, no
-//       data movement), layer 2 from h1ᵀ in LDS ([256][32] fp32 = 32 KB, conflict-free row reads);
-//   v_mfma_f32_32x32x2_f32: exact fp32 (a k-ordered fmaf chain), 64 FLOP/clk/SIMD = the fp32 peak.
+//   B operand = activations [k][rollout], two column blocks of 32 rollouts per weight register (each
+//       A register feeds two MFMAs): layer 1 from the lanes' own normalised inputs (one cross-half
+//       exchange), layer 2 from h1ᵀ in LDS ([256][64] fp32 = 64 KB, conflict-free row reads);
+//   v_mfma_f32_32x32x2_f32: exact fp32 (a k-ordered fmaf chain), 64 FLOP/clk/SIMD = the fp32 peak;
+//       two independent accumulators per wave keep the pipe issuing back to back.
 //   layer 3 (256 -> s) is 2 % of the FLOPs: VALU partial dot products over the wave's 32 units straight
 //       from the accumulator registers, lane halves and the 8 waves summed in fixed order through LDS.
-// Every wave carries the (identical) state, cost and noise of its 32 rollouts redundantly: the
-// per-step VALU work is ~1 % of the MFMA time and it saves a broadcast per step. The weighted-noise sum
-// regenerates eps from the Philox counters at the end (cheap next to 64 steps of MFMA).
-// Two s_barriers per horizon step. LDS: 32 KB h1 + 6 KB partial y + 6 KB W3.
+// Lane l of EVERY wave owns rollout l of the tile (state, running cost): the per-step scalar work
+// (normalise, state update, costs: ~1/10 of the MFMA time) is replicated across the 8 waves instead of
+// broadcast, and covers 64 rollouts per instruction. Noise comes from a double-buffered LDS block that
+// one wave per horizon group fills (Philox once per workgroup, not once per wave). The weighted-noise
+// sum regenerates eps from the Philox counters at the end (cheap next to H steps of MFMA).
+// Two s_barriers per horizon step. LDS: 64 KB h1 + 12 KB partial y + 6 KB W3 + 6 KB noise.
 constexpr int kMlpThreads = 512;
-constexpr int kMlpR = 32;
-__host__ __device__ inline size_t mlp_lds_floats(int S) { return (size_t)kHid * kMlpR + 8 * S * kMlpR + kHid * S + 64; }
+constexpr int kMlpR = 64;
+__host__ __device__ inline size_t mlp_lds_floats(int S, int A)
+{
+    return (size_t)kHid * kMlpR + 8 * S * kMlpR + kHid * S + 2 * 4 * A * kMlpR + 64;
+}
 
 template <int A, bool QFULL, bool DIAG, int SRC, int MODE>
 __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
@@ -551,13 +558,14 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
     float *h1_s = smem;                 // [kHid][R]
     float *y_s = h1_s + kHid * R;       // [8][S][R]
     float *w3_s = y_s + 8 * S * R;      // [kHid][S]
+    float *z_s = w3_s + kHid * S;       // [2][4*A][R] standard normals of the current / next horizon group
 
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, j = lane & 31, hh = lane >> 5;
     const int k0 = blockIdx.x * R;
-    const bool valid = (k0 + j) < K;
-    const int kk = valid ? k0 + j : K - 1; // clamp: out-of-range lanes recompute the last sample, masked later
+    const bool valid = (k0 + lane) < K;
+    const int kk = valid ? k0 + lane : K - 1; // clamp: out-of-range lanes recompute the last sample, masked later
 
     // ---- stationary weights -> registers
     float a2[kHid / 2 + 1], a1[K1 / 2];
@@ -579,18 +587,21 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
     const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)kk;
     const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
     const unsigned long long seed = C->seed;
-    float z[4 * A];
+    if (SRC == SRC_PHILOX && w == 0) { // horizon group 0
+        float z[4 * A];
+        normals_group<A>(seed, gk, base, z);
+#pragma unroll
+        for (int m = 0; m < 4 * A; ++m) z_s[m * R + lane] = z[m];
+    }
     __syncthreads();
 
     for (int t = 0; t < H; ++t) {
         float u[A], e[A], v[A];
         if (SRC == SRC_PHILOX) {
-            if ((t & 3) == 0) normals_group<A>(seed, gk, base + (unsigned long long)(t >> 2), z);
+            const float *zb = z_s + ((t >> 2) & 1) * (4 * A * R) + (t & 3) * A * R + lane;
             float zz[A];
 #pragma unroll
-            for (int i = 0; i < A; ++i) { // z[(t&3)*A + i] with a static index
-                zz[i] = (t & 3) == 0 ? z[i] : (t & 3) == 1 ? z[A + i] : (t & 3) == 2 ? z[2 * A + i] : z[3 * A + i];
-            }
+            for (int i = 0; i < A; ++i) zz[i] = zb[i * R];
             scale_noise<A, DIAG>(C, zz, e);
         } else {
 #pragma unroll
@@ -600,7 +611,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
         for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
         const float ac = action_cost<A, DIAG>(C, u, e);
 
-        // normalised inputs (+ the bias input 1, + zero padding)
+        // normalised inputs of this lane's rollout (+ the bias input 1, + zero padding)
         float in[K1];
 #pragma unroll
         for (int i = 0; i < S; ++i) in[i] = (x[i] - M->xmean[i]) / M->xstd[i];
@@ -610,62 +621,95 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
 #pragma unroll
         for (int i = NIN + 1; i < K1; ++i) in[i] = 0.0f;
 
-        // ---- layer 1: h1ᵀ[32w.., :] = relu(W1ᵀ in + b1)
-        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // ---- layer 1: h1ᵀ[32w.., cb*32..] = relu(W1ᵀ in + b1). Column block cb's B operand for k pair s1 is
+        // in[2 s1 + hh] of rollout 32cb+j: the lane's own value when cb == hh, its partner's (lane^32) otherwise.
+        f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        f32x16 acc1 = acc0;
 #pragma unroll
         for (int s1 = 0; s1 < K1 / 2; ++s1) {
-            const float b = hh ? in[2 * s1 + 1] : in[2 * s1];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s1], b, acc, 0, 0, 0);
+            const float mine = hh ? in[2 * s1 + 1] : in[2 * s1];     // in[2 s1 + hh] of my rollout (block hh)
+            const float send = hh ? in[2 * s1] : in[2 * s1 + 1];     // in[2 s1 + (1-hh)]: what my partner needs
+            const float theirs = __shfl_xor(send, 32, 64);           // partner's in[2 s1 + hh] (block 1-hh)
+            const float b0 = hh ? theirs : mine;                     // column block 0
+            const float b1 = hh ? mine : theirs;                     // column block 1
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s1], b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s1], b1, acc1, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            h1_s[(32 * w + row) * R + j] = acc[r] < 0.0f ? 0.0f : acc[r];
+            h1_s[(32 * w + row) * R + j] = acc0[r] < 0.0f ? 0.0f : acc0[r];
+            h1_s[(32 * w + row) * R + 32 + j] = acc1[r] < 0.0f ? 0.0f : acc1[r];
         }
         __syncthreads();
 
-        // ---- layer 2: h2ᵀ[32w.., :] = relu(W2ᵀ h1 + b2), 128 k pairs + the bias pair
-        f32x16 acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        // batches of 8 k pairs: 8 LDS reads in flight, then 8 dependent MFMAs (64 cycles each, so the
-        // next batch's reads hide under them); the scheduling fence keeps the compiler from hoisting all
-        // 128 reads at once (that spilled: 128 weights + 128 operands > 256 VGPRs)
+        // the next horizon group's normals, once per workgroup (wave g%8), into the other half of the buffer
+        if (SRC == SRC_PHILOX && (t & 3) == 0) {
+            const int gn = (t >> 2) + 1;
+            if (gn < NG && (gn & 7) == w) {
+                float z[4 * A];
+                normals_group<A>(seed, gk, base + (unsigned long long)gn, z);
+                float *zd = z_s + (gn & 1) * (4 * A * R) + lane;
+#pragma unroll
+                for (int m = 0; m < 4 * A; ++m) zd[m * R] = z[m];
+            }
+        }
+
+        // ---- layer 2: h2ᵀ[32w.., :] = relu(W2ᵀ h1 + b2): 128 k pairs + the bias pair, two column blocks.
+        // Batches of 4 k pairs: 8 LDS reads in flight, then 8 MFMAs on two independent accumulators; the
+        // scheduling fence keeps the compiler from hoisting all 256 reads at once (that spills).
+        acc0 = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc1 = acc0;
         const float *h1p = h1_s + hh * R + j;
 #pragma unroll
-        for (int sb = 0; sb < kHid / 2; sb += 8) {
-            float bq[8];
+        for (int sb = 0; sb < kHid / 2; sb += 4) {
+            float bq0[4], bq1[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) bq[q] = h1p[2 * (sb + q) * R];
+            for (int q = 0; q < 4; ++q) { bq0[q] = h1p[2 * (sb + q) * R]; bq1[q] = h1p[2 * (sb + q) * R + 32]; }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[sb + q], bq[q], acc2, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[sb + q], bq0[q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[sb + q], bq1[q], acc1, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kHid / 2], hh == 0 ? 1.0f : 0.0f, acc2, 0, 0, 0);
+        {
+            const float one = hh == 0 ? 1.0f : 0.0f;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kHid / 2], one, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kHid / 2], one, acc1, 0, 0, 0);
+        }
 
-        // ---- layer 3 partial over this wave's 32 units (16 per lane half), VALU
-        float py[S];
+        // ---- layer 3 partial over this wave's 32 units (16 per lane half), both column blocks, VALU
+        float py0[S], py1[S];
 #pragma unroll
-        for (int n = 0; n < S; ++n) py[n] = 0.0f;
+        for (int n = 0; n < S; ++n) { py0[n] = 0.0f; py1[n] = 0.0f; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float hv = acc2[r] < 0.0f ? 0.0f : acc2[r];
+            const float hv0 = acc0[r] < 0.0f ? 0.0f : acc0[r];
+            const float hv1 = acc1[r] < 0.0f ? 0.0f : acc1[r];
             const float *w3 = w3_s + (32 * w + row) * S;
 #pragma unroll
-            for (int n = 0; n < S; ++n) py[n] = __builtin_fmaf(hv, w3[n], py[n]);
+            for (int n = 0; n < S; ++n) {
+                const float wv = w3[n];
+                py0[n] = __builtin_fmaf(hv0, wv, py0[n]);
+                py1[n] = __builtin_fmaf(hv1, wv, py1[n]);
+            }
         }
 #pragma unroll
-        for (int n = 0; n < S; ++n) {
-            const float other = __shfl_xor(py[n], 32, 64);
-            if (hh == 0) y_s[(w * S + n) * R + j] = py[n] + other;
+        for (int n = 0; n < S; ++n) { // halves hold different rows: lane half hh keeps column block hh
+            const float keep = hh ? py1[n] : py0[n];
+            const float send = hh ? py0[n] : py1[n];
+            y_s[(w * S + n) * R + lane] = keep + __shfl_xor(send, 32, 64);
         }
         __syncthreads();
 
         // ---- y = Σ_waves partial + b3 (fixed order), state update, costs
 #pragma unroll
         for (int n = 0; n < S; ++n) {
-            float y = y_s[(0 * S + n) * R + j];
+            float y = y_s[(0 * S + n) * R + lane];
 #pragma unroll
-            for (int ww = 1; ww < 8; ++ww) y = y + y_s[(ww * S + n) * R + j];
+            for (int ww = 1; ww < 8; ++ww) y = y + y_s[(ww * S + n) * R + lane];
             y = y + M->b3[n];
             x[n] = x[n] + (y * M->ystd[n] + M->ymean[n]);
         }
@@ -674,13 +718,12 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
         c = c + tmp;
     }
     c = c + state_cost<S, QFULL>(C, x); // terminal cost, controller_base.cpp:271-272
-    if (w == 0 && hh == 0 && valid) cost[k0 + j] = c;
+    if (w == 0 && valid) cost[k0 + lane] = c;
     if (MODE == MODE_COST_ONLY) return;
 
-    // ---- tile record: every wave holds the same 32 costs; lane half 1 is masked out
-    const bool live = valid && hh == 0;
-    const float beta = wave_min(live ? c : INFINITY);
-    const float ek = live ? expf(C->neg_inv_lambda * (c - beta)) : 0.0f;
+    // ---- tile record: every wave holds the same 64 costs
+    const float beta = wave_min(valid ? c : INFINITY);
+    const float ek = valid ? expf(C->neg_inv_lambda * (c - beta)) : 0.0f;
     const float eta = wave_sum(ek);
     float *rec = partials + (size_t)blockIdx.x * (2 + HA);
     if (w == 0 && lane == 0) { rec[0] = beta; rec[1] = eta; }

@@ -45,7 +45,8 @@ if dominant and "FETCH_SIZE" in summary[dominant] and "WRITE_SIZE" in summary[do
                "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
                "hbm_bytes_per_launch": hbm, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tag " + tag}
     out["traffic"] = traffic
-    json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+    if "k_rollout_pc" in dominant:  # bench.py's default workload reads this file
+        json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 b = os.path.join(src, "bench_under_profiler.json")
 if os.path.exists(b) and os.path.getsize(b):
     out["bench_line_under_profiler"] = json.loads(open(b).read())
