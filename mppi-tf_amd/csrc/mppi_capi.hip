@@ -31,6 +31,7 @@ struct mppi_handle {
     size_t tile_lds = 0;
     int normalize = 0;
     int sigma_diag = 0; // Σ and Σ⁻¹ are exactly diagonal (the DIAG kernel instances are bit-identical then)
+    int pc_np = 5;      // producer waves per workgroup of k_rollout_pc (MPPI_PC_PRODUCERS=3 selects the 4-wave variant)
     int force_tile = 0; // MPPI_FORCE_TILE_KERNEL=1: run the LDS-tile kernel instead of the producer/consumer one (A/B timing)
     float *d_x = nullptr, *d_U = nullptr, *d_u = nullptr, *d_cost = nullptr, *d_cost2 = nullptr;
     float *d_part = nullptr, *d_part2 = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_Uupd = nullptr, *d_mm = nullptr;
@@ -195,6 +196,10 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     h->H = cfg->tau; h->s = s; h->a = a; h->HA = cfg->tau * a;
     h->normalize = cfg->normalize_cost;
     { const char *e = std::getenv("MPPI_FORCE_TILE_KERNEL"); h->force_tile = (e && e[0] == '1') ? 1 : 0; }
+    // 5 producers shorten a lone tile's pipeline (15.6 vs 18.3 us at 1 tile/CU) but cost throughput once
+    // >= 4 tiles share a CU (the kernel is VALU-issue bound there): pick by tiles per CU. MPPI_PC_PRODUCERS overrides.
+    h->pc_np = ((h->K_local + 63) / 64 <= 2 * 256) ? 5 : 3;
+    { const char *e = std::getenv("MPPI_PC_PRODUCERS"); if (e && (e[0] == '3' || e[0] == '5')) h->pc_np = e[0] - '0'; }
 
     DevConsts &c = h->hc;
     c.K_local = h->K_local; c.k_offset = h->k_offset; c.H = h->H; c.s = s; c.a = a;
@@ -354,24 +359,35 @@ static hipError_t launch_tile(mppi_handle *h, hipStream_t st, int src, int mode,
 }
 
 // the hot configuration: producer/consumer kernel (k_rollout_pc) when the horizon fits its register file
-template <int A, int NSLOT>
+template <int A, int NP, int NSLOT>
 static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_dev)
 {
-    const size_t lds = pc_lds_floats(A) * 4;
+    const size_t lds = pc_lds_floats(A, NP) * 4;
     const int nb = (h->K_local + 63) / 64;
-#define MPPI_PC_LAUNCH(QF, DG) hipLaunchKernelGGL((k_rollout_pc<A, NSLOT, QF, DG>), dim3(nb), dim3(kThreads), lds, st, h->dC, x_dev, h->d_U, h->d_step, h->d_cost, h->d_part)
-    if (h->hc.q_full) { if (h->sigma_diag) MPPI_PC_LAUNCH(true, true); else MPPI_PC_LAUNCH(true, false); }
-    else { if (h->sigma_diag) MPPI_PC_LAUNCH(false, true); else MPPI_PC_LAUNCH(false, false); }
-#undef MPPI_PC_LAUNCH
+    const dim3 g(nb), b(64 * (NP + 1));
+    if (h->sigma_diag) hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, lds, st, h->dC, x_dev, h->d_U, h->d_step, h->d_cost, h->d_part);
+    else hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, lds, st, h->dC, x_dev, h->d_U, h->d_step, h->d_cost, h->d_part);
     return hipGetLastError();
 }
 
-static bool pc_eligible(const mppi_handle *h) { return h->no_rollout.empty() && h->R == 64 && h->H <= 132 && !h->force_tile; }
+// diagonal-Q handles only (a dense Q runs the tile kernel); horizon groups per producer must fit the registers
+static bool pc_eligible(const mppi_handle *h)
+{
+    return h->no_rollout.empty() && h->R == 64 && !h->hc.q_full && !h->force_tile && h->H <= (h->pc_np == 3 ? 132 : 160);
+}
 
 static hipError_t launch_pc(mppi_handle *h, hipStream_t st, const float *x_dev)
 {
-    const bool small = h->H <= 72;
-#define MPPI_PC_CASE(AA) case AA: return small ? launch_pc_inst<AA, 6>(h, st, x_dev) : launch_pc_inst<AA, 11>(h, st, x_dev);
+    const int NG = (h->H + 3) / 4;
+    if (h->pc_np == 3) { // MPPI_PC_PRODUCERS=3: the 4-wave variant, kept for A/B timing
+        const bool small = NG <= 18;
+#define MPPI_PC_CASE(AA) case AA: return small ? launch_pc_inst<AA, 3, 6>(h, st, x_dev) : launch_pc_inst<AA, 3, 11>(h, st, x_dev);
+        switch (h->a) { MPPI_PC_CASE(1) MPPI_PC_CASE(2) MPPI_PC_CASE(3) MPPI_PC_CASE(4) }
+#undef MPPI_PC_CASE
+        return hipErrorInvalidValue;
+    }
+    const bool small = NG <= 20;
+#define MPPI_PC_CASE(AA) case AA: return small ? launch_pc_inst<AA, 5, 4>(h, st, x_dev) : launch_pc_inst<AA, 5, 8>(h, st, x_dev);
     switch (h->a) { MPPI_PC_CASE(1) MPPI_PC_CASE(2) MPPI_PC_CASE(3) MPPI_PC_CASE(4) }
 #undef MPPI_PC_CASE
     return hipErrorInvalidValue;

@@ -71,6 +71,22 @@ struct PhiloxAt : rocrand_device::philox4x32_10_engine {
 //   Philox block = (step*ceil(H/4) + g)*A + q , q = 0..A-1   -> 4A uniforms -> 4A normals
 //   normal m = 4q+{0,1,2,3} (Box-Muller pairs (x,y),(z,w) of block q) is z[t = 4g + m/A][j = m%A]
 // Every Philox output word is used (A blocks per 4 steps instead of 4).
+// Box-Muller exactly as rocRAND's box_muller(x, y) (rocrand_normal.h:53-68):
+//   u = 2^-32 + x·2^-32 ; v = 2π·2^-32 + y·2π·2^-32 ; (sin v, cos v)·sqrt(-2 ln u)
+// with the hardware-rate log and sqrt (v_log_f32·ln2, v_sqrt_f32; ~1 ulp) in place of libm-accurate
+// logf/sqrtf, whose range/denormal fix-ups cost ~20 of the ~35 instructions of a pair and buy nothing
+// here: u >= 2^-32 is never denormal and the noise only has to be N(0,1). rocRAND itself already uses
+// the fast __sincosf. -DMPPI_ROCRAND_NORMALS selects rocRAND's normal_distribution4 verbatim.
+__device__ __forceinline__ float2 box_muller_hw(unsigned int x, unsigned int y)
+{
+    const float u = ROCRAND_2POW32_INV + ((float)x * ROCRAND_2POW32_INV);
+    const float v = ROCRAND_2POW32_INV_2PI + ((float)y * ROCRAND_2POW32_INV_2PI);
+    const float s = __builtin_amdgcn_sqrtf(-2.0f * (__builtin_amdgcn_logf(u) * 0.6931471805599453f));
+    float sn, cs;
+    __sincosf(v, &sn, &cs);
+    return float2{sn * s, cs * s};
+}
+
 template <int A>
 __device__ __forceinline__ void normals_group(unsigned long long seed, unsigned long long gk,
                                               unsigned long long group_index, float (&z)[4 * A])
@@ -78,11 +94,14 @@ __device__ __forceinline__ void normals_group(unsigned long long seed, unsigned 
 #pragma unroll
     for (int q = 0; q < A; ++q) {
         PhiloxAt eng(seed, gk, 4ull * (group_index * A + q));
+#if defined(MPPI_ROCRAND_NORMALS)
         const float4 n = rocrand_device::detail::normal_distribution4(eng.block());
-        z[4 * q + 0] = n.x;
-        z[4 * q + 1] = n.y;
-        z[4 * q + 2] = n.z;
-        z[4 * q + 3] = n.w;
+        z[4 * q + 0] = n.x; z[4 * q + 1] = n.y; z[4 * q + 2] = n.z; z[4 * q + 3] = n.w;
+#else
+        const uint4 r = eng.block();
+        const float2 n0 = box_muller_hw(r.x, r.y), n1 = box_muller_hw(r.z, r.w);
+        z[4 * q + 0] = n0.x; z[4 * q + 1] = n0.y; z[4 * q + 2] = n1.x; z[4 * q + 3] = n1.y;
+#endif
     }
 }
 

@@ -173,8 +173,6 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
 // 4 workgroups (16 waves) per CU in one round, all waves busy.
 // Arithmetic per (k,t) is the same op sequence as k_rollout_tile: sample costs stay bit-identical.
 // NSLOT = max horizon groups per producer = ceil(ceil(H/4)/3)  (6 for H<=72, 11 for H<=132).
-constexpr int kPcChunkSteps = 12; // 3 producers x 4 steps
-
 // compile-time loop: the slot index must be a constant so that eps_r[slot] stays in registers
 // (a rolled loop would index the array dynamically and push it to scratch).
 template <int I, int N, typename F>
@@ -185,34 +183,37 @@ __device__ __forceinline__ void static_for(F &&f)
         static_for<I + 1, N>(f);
     }
 }
-__host__ __device__ inline size_t pc_lds_floats(int A) { return (size_t)2 * kPcChunkSteps * (A + 1) * 65 + 64 + 8; }
 
-template <int A, int NSLOT, bool QFULL, bool DIAG>
-__global__ __launch_bounds__(kThreads, (NSLOT * 4 * A <= 80 ? 4 : 2)) void k_rollout_pc(
+// NP producers + 1 consumer = NP+1 wavefronts per workgroup; a chunk = one horizon group (4 steps)
+// from every producer = 4·NP steps; two chunk buffers of (A+1) floats per (step, lane).
+__host__ __device__ inline size_t pc_lds_floats(int A, int NP) { return (size_t)2 * 4 * NP * (A + 1) * 64; }
+
+template <int A, int NP, int NSLOT, bool DIAG>
+__global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) void k_rollout_pc(
     const DevConsts *__restrict__ C, const float *__restrict__ x_dev, const float *__restrict__ U_dev,
     const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 2 * A;
-    constexpr int RP = 65;
-    constexpr int CH = kPcChunkSteps * (A + 1) * RP; // floats per chunk buffer
-    constexpr int NREG = NSLOT * 4 * A;              // noise values a producer lane keeps
+    constexpr int NW = NP + 1;
+    constexpr int CS = 4 * NP;                // steps per chunk
+    constexpr int CH = CS * (A + 1) * 64;     // floats per chunk buffer: [CS][(A+1)][64 lanes]
+    constexpr int NREG = NSLOT * 4 * A;       // noise values a producer lane keeps
     const int H = C->H;
     const int HA = H * A;
     const int K = C->K_local;
-    const int NG = (H + 3) / 4;          // horizon groups
-    const int nch = (NG + 2) / 3;        // chunks (3 groups each)
-    float *buf = smem;                   // [2][12][(A+1)][RP]
-    float *w_s = smem + 2 * CH;          // [64]
+    const int NG = (H + 3) / 4;               // horizon groups
+    const int nch = (NG + NP - 1) / NP;       // chunks
+    float *buf = smem;                        // [2][CS][(A+1)][64]
+    float *w_s = smem;                        // [64] weights: reuses buffer 0 once every chunk is consumed
 
     const int tid = threadIdx.x;
-    // Role rotation: a workgroup's 4 waves land on the CU's 4 SIMDs, and the 4 workgroups that
+    // Role rotation: a workgroup's waves are spread over the CU's 4 SIMDs, and the 4 workgroups that
     // share a CU (observed dispatch: block b -> XCD b%8, CU (b/8)%32, so they differ in b/256) would
-    // otherwise all put their light consumer wave on the same SIMD and their producers on the
-    // other three (measured: 3 SIMDs saturated, 1 at ~35 %). Rotating the consumer by b/256 gives
-    // every SIMD one consumer and three producers. Placement only affects speed, never results.
+    // otherwise put their light consumer wave on the same SIMD. Rotating the consumer by b/256 spreads
+    // consumers over the SIMDs. Placement only affects speed, never results.
     const int wave_hw = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = (wave_hw + 4 - (int)((blockIdx.x >> 8) & 3)) & 3; // SGPR: scalar branches + scalar loads of U
+    const int wave = (wave_hw + NW - (int)((blockIdx.x >> 8) % NW)) % NW; // SGPR: scalar branches, scalar loads of U
     const int lane = tid & 63;
     const int k0 = blockIdx.x * 64;
     const bool valid = (k0 + lane) < K;
@@ -227,9 +228,9 @@ __global__ __launch_bounds__(kThreads, (NSLOT * 4 * A <= 80 ? 4 : 2)) void k_rol
         float eps_r[NREG];
         static_for<0, NSLOT>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const int g = 3 * i + p;
+            const int g = NP * i + p;
             if (i < nch) { // chunk i exists (wave-uniform)
-                float *cb = buf + (i & 1) * CH + (size_t)(4 * p) * (A + 1) * RP;
+                float *cb = buf + (i & 1) * CH + (size_t)(4 * p) * (A + 1) * 64;
                 if (g < NG) {
                     float z[4 * A];
 #if defined(MPPI_ABLATE_PHILOX)
@@ -250,9 +251,9 @@ __global__ __launch_bounds__(kThreads, (NSLOT * 4 * A <= 80 ? 4 : 2)) void k_rol
                         for (int j = 0; j < A; ++j) {
                             u[j] = U_dev[tt * A + j];                // mPrepareAction controller_base.cpp:205-208 (scalar load)
                             eps_r[(i * 4 + tl) * A + j] = t < H ? e[j] : 0.0f;
-                            cb[(tl * (A + 1) + j) * RP + lane] = u[j] + e[j]; // to_apply, :258
+                            cb[(tl * (A + 1) + j) * 64 + lane] = u[j] + e[j]; // to_apply, :258
                         }
-                        cb[(tl * (A + 1) + A) * RP + lane] = action_cost<A, DIAG>(C, u, e);
+                        cb[(tl * (A + 1) + A) * 64 + lane] = action_cost<A, DIAG>(C, u, e);
                     }
                 }
                 __syncthreads(); // chunk i published
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kThreads, (NSLOT * 4 * A <= 80 ? 4 : 2)) void k_rol
             const int n = 64 * m + colbase;        // register index this lane owns the total of
             const int i = n / (4 * A), rem = n - i * (4 * A);
             const int tl = rem / A, j = rem - tl * A;
-            const int t = 4 * (3 * i + p) + tl;
+            const int t = 4 * (NP * i + p) + tl;
             if (n < NREG && t < H) rec[2 + t * A + j] = tot[m];
         }
     } else {
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(kThreads, (NSLOT * 4 * A <= 80 ? 4 : 2)) void k_rol
         __syncthreads(); // chunk 0 published
         for (int ch = 0; ch < nch; ++ch) {
             const float *cb = buf + (ch & 1) * CH;
-            const int tend = min(kPcChunkSteps, H - ch * kPcChunkSteps);
+            const int tend = min(CS, H - ch * CS);
 #if defined(MPPI_ABLATE_ROLLOUT)
             for (int tl = 0; tl < (ch == 0 ? 1 : 0); ++tl) {
 #else
@@ -300,16 +301,18 @@ __global__ __launch_bounds__(kThreads, (NSLOT * 4 * A <= 80 ? 4 : 2)) void k_rol
 #endif
                 float v[A];
 #pragma unroll
-                for (int j = 0; j < A; ++j) v[j] = cb[(tl * (A + 1) + j) * RP + lane];
-                const float ac = cb[(tl * (A + 1) + A) * RP + lane];
+                for (int j = 0; j < A; ++j) v[j] = cb[(tl * (A + 1) + j) * 64 + lane];
+                const float ac = cb[(tl * (A + 1) + A) * 64 + lane];
                 pm_step<A>(C, x, v);
-                const float sc = state_cost<S, QFULL>(C, x); // cost on the POST-step state
+                const float sc = state_cost<S, false>(C, x); // cost on the POST-step state
                 const float tmp = sc + ac;                    // Step_cost_result cost_base.cpp:49
                 c = c + tmp;                                  // path_cost        controller_base.cpp:268
             }
+            // barrier budget: producers run nch (one per chunk) + 1 (weights); the consumer 1 + (nch-1) + 1.
+            // After the last chunk nothing is published any more: the producers already sit at the weights barrier.
             if (ch + 1 < nch) __syncthreads(); // chunk ch consumed / chunk ch+1 published
         }
-        c = c + state_cost<S, QFULL>(C, x); // terminal: x_H counted a second time, :271-272
+        c = c + state_cost<S, false>(C, x); // terminal: x_H counted a second time, :271-272
         if (valid) cost[k0 + lane] = c;
         // tile-local mBeta / mExpArg / mExp / mNabla (controller_base.cpp:166-182)
         const float beta = wave_min(valid ? c : INFINITY);
@@ -321,7 +324,6 @@ __global__ __launch_bounds__(kThreads, (NSLOT * 4 * A <= 80 ? 4 : 2)) void k_rol
         __syncthreads(); // weights published
     }
 }
-
 
 // ----------------------------------------------------------------------------------------
 // k_combine_group: first level of the record tree. Workgroup j folds records
@@ -344,7 +346,12 @@ __global__ __launch_bounds__(kThreads) void k_combine_group(
     float bb[kGroup], r[kGroup];
     float beta = INFINITY;
     // loads are UNCONDITIONAL on clamped indices and masked afterwards: a load under a runtime
-    // predicate makes hipcc branch around it and wait per element (16 serial round trips, measured 6 µs)
+    // predicate makes hipcc branch around it and wait per element (16 serial round trips, measured 6 µs).
+    // The first column's values are requested before the betas so both round trips overlap.
+    float v_first[kGroup];
+    const int col_first = min(tid, HA);
+#pragma unroll
+    for (int b = 0; b < kGroup; ++b) v_first[b] = recs[(size_t)(b0 + min(b, n - 1)) * stride + 1 + col_first];
 #pragma unroll
     for (int b = 0; b < kGroup; ++b) bb[b] = recs[(size_t)(b0 + min(b, n - 1)) * stride];
 #pragma unroll
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void k_combine_group(
     for (int col = tid; col < HA + 1; col += kThreads) {
         float v[kGroup];
 #pragma unroll
-        for (int b = 0; b < kGroup; ++b) v[b] = recs[(size_t)(b0 + min(b, n - 1)) * stride + 1 + col];
+        for (int b = 0; b < kGroup; ++b) v[b] = col == tid ? v_first[b] : recs[(size_t)(b0 + min(b, n - 1)) * stride + 1 + col];
         double acc = 0.0;
 #pragma unroll
         for (int b = 0; b < kGroup; ++b) acc += (double)r[b] * (double)v[b]; // r[b] = 0 beyond n

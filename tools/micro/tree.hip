@@ -31,6 +31,7 @@ int main() {
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), finish_lds_bytes(HA), st, part2, ng, HA, 3, -1.0f, U, u, (float*)nullptr, 1, step, dbg, Uu);
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), finish_lds_bytes(HA), st, part2, 2, HA, 3, -1.0f, U, u, (float*)nullptr, 1, step, dbg, Uu);
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), finish_lds_bytes(HA), st, part2, 2, HA, 3, -1.0f, U, u, (float*)nullptr, 0, step, (float*)nullptr, (float*)nullptr);
+
     }
     CK(hipStreamSynchronize(st));
     printf("done\n");
