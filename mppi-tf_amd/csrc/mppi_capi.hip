@@ -37,7 +37,10 @@ struct mppi_handle {
     float *d_part = nullptr, *d_part2 = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_Uupd = nullptr, *d_mm = nullptr;
     float *d_eps = nullptr; // lazily allocated [K_local, H, a] for injected noise / debug export
     unsigned long long *d_step = nullptr;
-    float *h_pin = nullptr; // pinned staging: x[s] | u[a]
+    // pinned, device-mapped host staging for the synchronous path: x slot 0 | x slot 1 | u. The kernels read
+    // x and write u straight through these (zero-copy over PCIe, 24 B / 12 B): no H2D / D2H copy nodes per step.
+    float *h_pin = nullptr, *d_pin = nullptr;
+    int pin_slot = 0;
     std::string err;
     // profiling: event pairs around the rollout / finish kernels (mppi_profile_begin/end)
     std::vector<hipEvent_t> ev;   // 4 events per step: rollout begin/end, finish begin/end
@@ -178,6 +181,7 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
             return fail(nullptr, MPPI_ERR_UNSUPPORTED, "the MLP kernels implement Dense(256,relu) x2 + Dense(s_dim): widths must be {256,256,s_dim}");
         for (int l = 0; l < 3; ++l) if (!d->W[l] || !d->b[l]) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NULL MLP weight pointer");
         if (s != 2 * a || a > 4) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "MLP rollouts are instantiated for s_dim == 2*a_dim, a_dim <= 4");
+        if (cfg->q_is_full) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "MLP rollouts are instantiated for a diagonal Q");
     }
 
     int ndev = mppi_device_count();
@@ -284,7 +288,8 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         HIP_TRY(h, hipMalloc((void **)&h->d_Uupd, sizeof(float) * h->HA));
         HIP_TRY(h, hipMalloc((void **)&h->d_mm, sizeof(float) * 2));
         HIP_TRY(h, hipMalloc((void **)&h->d_step, sizeof(unsigned long long)));
-        HIP_TRY(h, hipHostMalloc((void **)&h->h_pin, sizeof(float) * (kMaxS + kMaxA), hipHostMallocDefault));
+        HIP_TRY(h, hipHostMalloc((void **)&h->h_pin, sizeof(float) * (2 * kMaxS + kMaxA), hipHostMallocMapped));
+        HIP_TRY(h, hipHostGetDevicePointer((void **)&h->d_pin, h->h_pin, 0));
         HIP_TRY(h, hipMemsetAsync(h->d_U, 0, sizeof(float) * h->HA, h->stream)); // U0 = 0
         HIP_TRY(h, hipMemsetAsync(h->d_step, 0, sizeof(unsigned long long), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_dbg, 0, sizeof(float) * 8, h->stream));
@@ -393,35 +398,27 @@ static hipError_t launch_pc(mppi_handle *h, hipStream_t st, const float *x_dev)
     return hipErrorInvalidValue;
 }
 
-// learned-model rollouts (k_rollout_mlp): 32 rollouts per workgroup of 8 waves
+// learned-model rollouts (k_rollout_mlp): 64 rollouts per workgroup of 8 waves
 template <int A>
 static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
                                const float *eps, float *cost)
 {
     const size_t lds = mlp_lds_floats(2 * A, A) * 4;
     const dim3 g(h->nb_mlp), b(kMlpThreads);
-#define MPPI_MLP_L(QF, DG, SRC, MODE)                                                                                   \
+    if (mode != MODE_ROLLOUT && mode != MODE_COST_ONLY) return hipErrorInvalidValue;
+#define MPPI_MLP_L(KERN, BIT)                                                                                           \
     do {                                                                                                                \
-        auto kern = k_rollout_mlp<A, QF, DG, SRC, MODE>;                                                                \
-        static thread_local bool attr_done = false;                                                                     \
-        if (!attr_done) {                                                                                               \
+        auto kern = KERN;                                                                                               \
+        static thread_local int attr_done = 0;                                                                          \
+        if (!(attr_done & BIT)) {                                                                                       \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e_ != hipSuccess) return e_;                                                                            \
-            attr_done = true;                                                                                           \
+            attr_done |= BIT;                                                                                           \
         }                                                                                                               \
-        hipLaunchKernelGGL(kern, g, b, lds, st, h->dC, h->dM, x_dev, U_dev, eps, h->d_step, cost, h->d_part);         \
+        hipLaunchKernelGGL(kern, g, b, lds, st, h->dC, h->dM, x_dev, U_dev, eps, h->d_step, cost, h->d_part, src, mode); \
     } while (0)
-#define MPPI_MLP_SM(QF, DG)                                                                     \
-    do {                                                                                        \
-        if (src == SRC_PHILOX && mode == MODE_ROLLOUT) MPPI_MLP_L(QF, DG, SRC_PHILOX, MODE_ROLLOUT);          \
-        else if (src == SRC_HBM && mode == MODE_ROLLOUT) MPPI_MLP_L(QF, DG, SRC_HBM, MODE_ROLLOUT);           \
-        else if (src == SRC_PHILOX && mode == MODE_COST_ONLY) MPPI_MLP_L(QF, DG, SRC_PHILOX, MODE_COST_ONLY); \
-        else if (src == SRC_HBM && mode == MODE_COST_ONLY) MPPI_MLP_L(QF, DG, SRC_HBM, MODE_COST_ONLY);       \
-        else return hipErrorInvalidValue;                                                       \
-    } while (0)
-    if (h->hc.q_full) { if (h->sigma_diag) MPPI_MLP_SM(true, true); else MPPI_MLP_SM(true, false); }
-    else { if (h->sigma_diag) MPPI_MLP_SM(false, true); else MPPI_MLP_SM(false, false); }
-#undef MPPI_MLP_SM
+    if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp<A, true>), 2);
+    else MPPI_MLP_L((k_rollout_mlp<A, false>), 4);
 #undef MPPI_MLP_L
     return hipGetLastError();
 }
@@ -602,15 +599,18 @@ static mppi_status step_host(mppi_handle *h, const float *x, int n_x, const floa
         HIP_TRY(h, hipMemcpyAsync(h->d_eps, eps, sizeof(float) * n_eps, hipMemcpyHostToDevice, h->stream));
         src = SRC_HBM;
     }
-    std::memcpy(h->h_pin, x, sizeof(float) * h->s);
-    HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_pin, sizeof(float) * h->s, hipMemcpyHostToDevice, h->stream));
+    // x goes into the pinned slot the kernels read directly (slots alternate so a step never re-reads the
+    // address of the previous x); u comes back through the pinned, device-mapped u slot.
+    h->pin_slot ^= 1;
+    std::memcpy(h->h_pin + h->pin_slot * kMaxS, x, sizeof(float) * h->s);
+    const float *x_arg = h->d_pin + h->pin_slot * kMaxS;
+    float *u_arg = h->d_pin + 2 * kMaxS;
     int nrec = 0;
-    mppi_status s = enqueue_partials(h, h->stream, src, h->d_x, h->d_eps, nullptr, &nrec);
+    mppi_status s = enqueue_partials(h, h->stream, src, x_arg, h->d_eps, nullptr, &nrec);
     if (s != MPPI_OK) return s;
-    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, nrec, h->d_U, h->d_u, nullptr, 1, h->d_Uupd));
-    HIP_TRY(h, hipMemcpyAsync(h->h_pin + kMaxS, h->d_u, sizeof(float) * h->a, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, nrec, h->d_U, u_arg, nullptr, 1, h->d_Uupd));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    std::memcpy(u_out, h->h_pin + kMaxS, sizeof(float) * h->a);
+    std::memcpy(u_out, h->h_pin + 2 * kMaxS, sizeof(float) * h->a);
     // m_db.addX(s); m_db.addU(out_tensor[1])  controller_base.cpp:146-147
     h->log_x.insert(h->log_x.end(), x, x + h->s);
     h->log_u.insert(h->log_u.end(), u_out, u_out + h->a);

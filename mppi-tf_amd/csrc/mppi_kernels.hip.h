@@ -543,6 +543,11 @@ __global__ void k_mlp_step_ref(const DevConsts *__restrict__ C, const MlpDev *__
 // one wave per horizon group fills (Philox once per workgroup, not once per wave). The weighted-noise
 // sum regenerates eps from the Philox counters at the end (cheap next to H steps of MFMA).
 // Two s_barriers per horizon step. LDS: 64 KB h1 + 12 KB partial y + 6 KB W3 + 6 KB noise.
+// Tried and dropped (round 1): phase-shifting the two column blocks so one block's scalar chain issues in
+// the MFMA gaps of the other (one micro-step per MFMA slot, pinned with sched_barrier). It was correct but
+// ran at 76 TFLOP/s against 122: with 134 weight + 32 accumulator registers the extra live ranges spilled
+// (256 B/lane of scratch inside the MFMA stream) and each pinned micro-step's LDS latency stalled the
+// in-order wave past its next MFMA. It needs the weights partly in LDS before it can pay.
 constexpr int kMlpThreads = 512;
 constexpr int kMlpR = 64;
 __host__ __device__ inline size_t mlp_lds_floats(int S, int A)
@@ -550,12 +555,14 @@ __host__ __device__ inline size_t mlp_lds_floats(int S, int A)
     return (size_t)kHid * kMlpR + 8 * S * kMlpR + kHid * S + 2 * 4 * A * kMlpR + 64;
 }
 
-template <int A, bool QFULL, bool DIAG, int SRC, int MODE>
+template <int A, bool DIAG>
 __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
     const DevConsts *__restrict__ C, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
     const float *__restrict__ U_dev, const float *__restrict__ eps_hbm,
-    const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials)
+    const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
+    const int SRC, const int MODE)
 {
+    constexpr bool QFULL = false;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 2 * A, NIN = S + A;
     constexpr int K1 = (NIN + 2) / 2 * 2; // inputs + bias, padded to the MFMA's k pairs (10 for s=6,a=3)
