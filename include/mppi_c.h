@@ -54,6 +54,10 @@ enum { MPPI_MODEL_POINT_MASS = 0, /* x' = A x + (B/m) v, src/model_base.cpp:53-8
 enum { MPPI_ACTION_COST_CPP = 0,  /* λ uᵀΣ⁻¹ε                          src/cost_base.cpp:63-68   */
        MPPI_ACTION_COST_PY = 1 }; /* ½[γ(uᵀΣ⁻¹u+2uᵀΣ⁻¹ε)+λ(1-1/υ)εᵀΣ⁻¹ε]  costs/cost_base.py:114-170 */
 
+/* mppi_config.flags */
+enum { MPPI_FLAG_UPSILON_SCALES_NOISE = 1 /* Py build_noise: eps = (υΣ)·z while the cost keeps Σ⁻¹ of the
+                                             un-augmented Σ (controller_base.py:362-368, cost_base.py:35-41) */ };
+
 /* what mppi_debug_get returns (observer_base.py:101-187 logs the same intermediates) */
 enum { MPPI_DBG_COSTS = 0,    /* c[K_local]         sample costs of the last step            */
        MPPI_DBG_BETA = 1,     /* [1]                min cost (over all shards after finish)  */
@@ -93,7 +97,7 @@ typedef struct {
     int32_t device;           /* HIP device ordinal                                       */
     int32_t shard_rank;       /* this handle owns samples [rank*k/count, (rank+1)*k/count) */
     int32_t shard_count;      /* 1 = unsharded                                            */
-    int32_t flags;            /* reserved, 0                                              */
+    int32_t flags;            /* MPPI_FLAG_* bits, 0 = the C++ reference's behaviour      */
 } mppi_config;
 
 /* ---- library ------------------------------------------------------------------------- */

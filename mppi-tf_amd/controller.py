@@ -189,13 +189,13 @@ class ControllerBase:
         self._h = Handle(k=self._k, tau=self._tau, s_dim=self._sDim, a_dim=self._aDim,
                          dt=model._dt, mass=model._mass, lam=self._lam,
                          gamma=getattr(cost, "gamma", 1.0), upsilon=getattr(cost, "upsilon", 1.0),
-                         sigma=self._upsilon * sigma if self._upsilon != 1.0 else sigma,
-                         goal=cost.goal.ravel(), Q=cost.Q, q_is_full=True,
+                         sigma=sigma, goal=cost.goal.ravel(), Q=cost.Q, q_is_full=True,
                          action_cost=cost._action_cost_kind, normalize_cost=self._normalizeCost,
-                         seed=seed, device=device)
-        if self._upsilon != 1.0:
-            # the cost keeps Σ⁻¹ of the UN-augmented Σ (cost_base.py:35-41); only the sampler uses υΣ
-            raise NotImplementedError("upsilon != 1 needs separate sampler/cost sigmas (SURVEY §8f-2)")
+                         seed=seed, device=device,
+                         # build_noise: noises = (υΣ)·z (controller_base.py:362-368); the cost keeps Σ⁻¹ of Σ
+                         upsilon_scales_noise=True)
+        if abs(getattr(cost, "upsilon", self._upsilon) - self._upsilon) > 0:
+            raise AssertionError("controller and cost must be built with the same upsilon")
         initSeq = np.asarray(initSeq, np.float32)
         if initSeq.size:
             if initSeq.shape != (tau, aDim, 1):

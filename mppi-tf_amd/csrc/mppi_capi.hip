@@ -221,8 +221,10 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     for (int i = 0; i < a; ++i) for (int j = 0; j < a; ++j) sig[i * a + j] = cfg->sigma ? cfg->sigma[i * a + j] : (i == j ? 1.0f : 0.0f);
     if (!invert(sig, a, inv)) { delete h; return fail(nullptr, MPPI_ERR_SINGULAR_SIGMA, "sigma is singular"); }
     h->sigma_diag = 1;
+    // the sampler's matrix: Σ (C++, controller_base.cpp:201) or υ·Σ (Py build_noise); Σ⁻¹ stays that of Σ
+    const float samp = (cfg->flags & MPPI_FLAG_UPSILON_SCALES_NOISE) ? cfg->upsilon : 1.0f;
     for (int i = 0; i < a; ++i) for (int j = 0; j < a; ++j) {
-        c.sigma[i * kMaxA + j] = sig[i * a + j]; c.sigma_inv[i * kMaxA + j] = inv[i * a + j];
+        c.sigma[i * kMaxA + j] = samp * sig[i * a + j]; c.sigma_inv[i * kMaxA + j] = inv[i * a + j];
         if (i != j && (sig[i * a + j] != 0.0f || inv[i * a + j] != 0.0f)) h->sigma_diag = 0;
     }
     for (int i = 0; i < s; ++i) {

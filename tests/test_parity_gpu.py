@@ -534,3 +534,27 @@ def test_mlp_unsupported_shapes_fail_loudly(m):
     with pytest.raises(m.MppiError) as e:
         m.Handle(k=64, tau=4, s_dim=6, a_dim=3, mlp=bad)
     assert e.value.status == 4 and "256" in str(e.value)
+
+
+def test_python_controller_with_upsilon_and_gamma(m):
+    """The Python reference's ControllerBase(model, cost, ...) with γ, υ != 1: the sampler draws (υΣ)·z while
+    the cost keeps Σ⁻¹ of Σ and the ½[γ(uᵀΣ⁻¹u+2uᵀΣ⁻¹ε)+λ(1-1/υ)εᵀΣ⁻¹ε] action cost
+    (controller_base.py:362-368, cost_base.py:114-170)."""
+    K, H, a, s = 1024, 12, 2, 4
+    lam, gamma, ups = 0.8, 1.5, 2.0
+    sigma = np.array([[0.3, 0.0], [0.0, 0.2]], F32)
+    goal = np.array([[1.0], [0.0], [0.5], [0.0]], F32)
+    Q = np.diag([1.0, 0.5, 2.0, 0.5]).astype(F32)
+    model = m.PointMassModel(1.5, 0.1, s, a)
+    cost = m.StaticCost(lam, gamma, ups, sigma, goal, Q)
+    ctl = m.ControllerBase(model, cost, k=K, tau=H, sDim=s, aDim=a, lam=lam, upsilon=ups, sigma=sigma, seed=3)
+    p = orc.Problem(tau=H, s=s, a=a, dt=0.1, mass=1.5, lam=lam, gamma=gamma, upsilon=ups, sigma=sigma, goal=goal.ravel(),
+                    Q=Q, action_cost=orc.ACTION_COST_PY)
+    x = np.array([[0.1], [0.0], [-0.2], [0.1]], F32)
+    u = ctl.next(x)
+    eps = ctl._h.debug_get(m.DBG_NOISE)
+    np.testing.assert_allclose(eps, orc.noise(3, 0, 0, K, H, a, ups * sigma), rtol=0, atol=1e-5)  # sampler uses υΣ
+    u_ref, U_ref, c_ref = p.next_with_noise(x.ravel(), np.zeros((H, a), F32), eps)
+    np.testing.assert_array_equal(ctl._h.debug_get(m.DBG_COSTS), c_ref)
+    np.testing.assert_allclose(u, u_ref, rtol=0, atol=U_TOL)
+    np.testing.assert_allclose(ctl._actionSeq[..., 0], U_ref, rtol=0, atol=U_TOL)
