@@ -196,7 +196,7 @@ def main():
                        "K_global": k_global, "K_per_gpu": K_PER_GPU, "H": H, "s_dim": S, "a_dim": A,
                        "lambda": 1.0, "sigma": "0.25*I", "dt": 0.1, "mass": 1.0,
                        "parallelism": "K-shard x%d, one all-gather of %d floats per step" % (world, h.record_size)},
-            "roofline": {"bound": "hbm", "kernel": "mppi::k_rollout_pc<3, 6, false, true>",
+            "roofline": {"bound": "hbm", "kernel": "mppi::k_rollout_pc<3, 3, 6, true>",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(),
                          "algorithmic_bytes_per_launch": alg_bytes,
