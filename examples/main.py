@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""The reference's Python entry point (scripts/main.py:13-121) against the MI355X control step:
+   python examples/main.py --new --config examples/config/point_mass3d.yaml --task examples/config/static_task3d.yaml -s 200
+parses the same YAML keys, builds Simulation / PointMassModel / StaticCost / ControllerBase with the
+reference's constructor arguments, runs the closed loop, and writes the transition log as CSV."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mppi_tf_amd as m  # noqa: E402
+from mppi_tf_amd.simulation import Simulation  # noqa: E402
+
+
+def parse_config(path):  # scripts/src/misc/utile.py:41-51
+    with open(path) as fh:
+        return yaml.safe_load(fh)
+
+
+def get_cost(task_file, lam, gamma, upsilon, sigma):  # scripts/src/cost.py:51-64, "static" branch
+    task = parse_config(task_file)
+    if task["type"] != "static":
+        raise NotImplementedError("only the static cost is on the accelerated path (SURVEY §2 row 12)")
+    goal = np.asarray(task["goal"], np.float32).reshape(-1, 1)
+    return m.StaticCost(lam, gamma, upsilon, np.asarray(sigma, np.float32), goal, np.asarray(task["Q"], np.float32),
+                        diag=bool(task.get("diag", False)))
+
+
+def main():
+    ap = argparse.ArgumentParser(prog="mppi", description="mppi on MI355X")
+    ap.add_argument("--new", action="store_true", help="expects a config and a task file")
+    ap.add_argument("--config", type=str, required=True)
+    ap.add_argument("--task", type=str, required=True)
+    ap.add_argument("-s", "--steps", type=int, default=200)
+    ap.add_argument("--csv", type=str, default=None, help="write the (x, u, x_next) log here (DataBase::toCSV)")
+    args = ap.parse_args()
+    conf = parse_config(args.config)
+    s_dim, a_dim = conf["state-dim"], conf["action-dim"]
+    sim = Simulation(conf.get("env"), s_dim, a_dim, None, False, dt=conf["dt"], mass=conf.get("mass", 1.0))
+    model = m.PointMassModel(conf.get("mass", 1.0), conf["dt"], s_dim, a_dim)
+    cost = get_cost(args.task, conf["lambda"], conf.get("gamma", 1.0), conf.get("upsilon", 1.0), conf["noise"])
+    cont = m.ControllerBase(model, cost, k=conf["samples"], tau=conf["horizon"], sDim=s_dim, aDim=a_dim,
+                            lam=conf["lambda"], upsilon=conf.get("upsilon", 1.0), sigma=np.asarray(conf["noise"], np.float32))
+    ts = []
+    for _ in range(args.steps):
+        x = sim.getState()
+        t0 = time.perf_counter()
+        u = cont.next(x)
+        ts.append(time.perf_counter() - t0)
+        x_next = sim.step(u)
+        cont.save(x, u, x_next)
+    goal = cost.getGoal().ravel()
+    steady = np.sort(ts[min(5, len(ts) - 1):])  # the first calls load the code objects
+    print("%d control steps, controller median %.3f ms/step (first call %.1f ms), |x - goal| = %.4f" % (
+        args.steps, 1e3 * float(np.median(steady)), 1e3 * ts[0], float(np.linalg.norm(sim.getState().ravel() - goal))))
+    if args.csv:
+        cont._h.to_csv(args.csv)
+        print("wrote", args.csv)
+
+
+if __name__ == "__main__":
+    main()

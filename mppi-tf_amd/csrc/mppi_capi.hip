@@ -227,15 +227,23 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         c.sigma[i * kMaxA + j] = samp * sig[i * a + j]; c.sigma_inv[i * kMaxA + j] = inv[i * a + j];
         if (i != j && (sig[i * a + j] != 0.0f || inv[i * a + j] != 0.0f)) h->sigma_diag = 0;
     }
+    bool q_offdiag = false;
     for (int i = 0; i < s; ++i) {
         if (cfg->q_is_full) {
-            for (int j = 0; j < s; ++j) c.qfull[i * kMaxS + j] = cfg->Q ? cfg->Q[i * s + j] : (i == j ? 1.0f : 0.0f);
+            for (int j = 0; j < s; ++j) {
+                c.qfull[i * kMaxS + j] = cfg->Q ? cfg->Q[i * s + j] : (i == j ? 1.0f : 0.0f);
+                if (i != j && c.qfull[i * kMaxS + j] != 0.0f) q_offdiag = true;
+            }
             c.qdiag[i] = c.qfull[i * kMaxS + i];
         } else {
             c.qdiag[i] = cfg->Q ? cfg->Q[i] : 1.0f;
             c.qfull[i * kMaxS + i] = c.qdiag[i];
         }
     }
+
+    // A dense Q whose off-diagonal entries are all exactly zero (the Python reference's default task files)
+    // evaluates bit-identically through the diagonal instances: the dropped products are exact zeros.
+    if (cfg->q_is_full && !q_offdiag) c.q_full = 0;
 
     // tile geometry: the largest R in {64,32,16} whose LDS image fits one CU (160 KiB), preferring
     // <= ~53 KiB so three workgroups share a CU.

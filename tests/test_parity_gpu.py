@@ -558,3 +558,22 @@ def test_python_controller_with_upsilon_and_gamma(m):
     np.testing.assert_array_equal(ctl._h.debug_get(m.DBG_COSTS), c_ref)
     np.testing.assert_allclose(u, u_ref, rtol=0, atol=U_TOL)
     np.testing.assert_allclose(ctl._actionSeq[..., 0], U_ref, rtol=0, atol=U_TOL)
+
+
+def test_reference_shaped_python_entry_point(m, tmp_path):
+    """examples/main.py = scripts/main.py's loop (YAML config + task, Simulation, PointMassModel, StaticCost,
+    ControllerBase, save) with the MuJoCo-free plant; must reach the goal and write the transition CSV."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    csv = tmp_path / "log.csv"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "main.py"), "--new",
+                        "--config", os.path.join(ROOT, "examples", "config", "point_mass3d.yaml"),
+                        "--task", os.path.join(ROOT, "examples", "config", "static_task3d.yaml"),
+                        "-s", "80", "--csv", str(csv)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    dist = float(r.stdout.split("|x - goal| =")[1].split()[0])
+    assert dist < 0.1, r.stdout
+    rows = csv.read_text().strip().splitlines()
+    assert len(rows) == 81 and rows[0].startswith("x0,")
