@@ -34,7 +34,7 @@ struct mppi_handle {
     int pc_np = 5;      // producer waves per workgroup of k_rollout_pc (MPPI_PC_PRODUCERS=3 selects the 4-wave variant)
     int force_tile = 0; // MPPI_FORCE_TILE_KERNEL=1: run the LDS-tile kernel instead of the producer/consumer one (A/B timing)
     float *d_x = nullptr, *d_U = nullptr, *d_u = nullptr, *d_cost = nullptr, *d_cost2 = nullptr;
-    float *d_part = nullptr, *d_part2 = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_Uupd = nullptr, *d_mm = nullptr;
+    float *d_part = nullptr, *d_part2 = nullptr, *d_part3 = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_Uupd = nullptr, *d_mm = nullptr;
     float *d_eps = nullptr; // lazily allocated [K_local, H, a] for injected noise / debug export
     unsigned long long *d_step = nullptr;
     // pinned, device-mapped host staging for the synchronous path: x slot 0 | x slot 1 | u. The kernels read
@@ -148,7 +148,7 @@ extern "C" void mppi_destroy(mppi_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    float *bufs[] = {h->d_x, h->d_U, h->d_u, h->d_cost, h->d_cost2, h->d_part, h->d_part2, h->d_record, h->d_dbg,
+    float *bufs[] = {h->d_x, h->d_U, h->d_u, h->d_cost, h->d_cost2, h->d_part, h->d_part2, h->d_part3, h->d_record, h->d_dbg,
                      h->d_Uupd, h->d_mm, h->d_eps};
     for (float *p : bufs) if (p) (void)hipFree(p);
     if (h->d_step) (void)hipFree(h->d_step);
@@ -271,7 +271,9 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         HIP_TRY(h, hipMalloc((void **)&h->d_cost2, sizeof(float) * h->K_local));
         const int nrec = std::max(h->nb, h->nb_mlp);
         HIP_TRY(h, hipMalloc((void **)&h->d_part, sizeof(float) * (size_t)nrec * (2 + h->HA)));
-        HIP_TRY(h, hipMalloc((void **)&h->d_part2, sizeof(float) * (size_t)((nrec + kGroup - 1) / kGroup) * (2 + h->HA)));
+        const int nrec2 = (nrec + kGroup - 1) / kGroup, nrec3 = (nrec2 + kGroup - 1) / kGroup;
+        HIP_TRY(h, hipMalloc((void **)&h->d_part2, sizeof(float) * (size_t)nrec2 * (2 + h->HA)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_part3, sizeof(float) * (size_t)nrec3 * (2 + h->HA)));
         if (cfg->model_kind == MPPI_MODEL_MLP) {
             const mppi_mlp_desc *d = cfg->mlp;
             const int nin = s + a;
@@ -451,13 +453,17 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
     // a profiled step = the rollout kernel + the finish that applies the update
     const bool prof = apply && h->prof_n < h->prof_cap;
     if (prof) { hipError_t e = hipEventRecord(h->ev[4 * h->prof_n + 2], st); if (e != hipSuccess) return e; }
-    if (nb > 4 * kGroup && recs == h->d_part) { // two-level record tree (see k_combine_group)
-        const int ng = (nb + kGroup - 1) / kGroup;
-        hipLaunchKernelGGL(k_combine_group, dim3(ng), dim3(kThreads), 0, st, recs, nb, h->HA, h->hc.neg_inv_lambda, h->d_part2);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        recs = h->d_part2;
-        nb = ng;
+    if (recs == h->d_part) { // record tree: fold 16 records per workgroup until one workgroup can finish (see k_combine_group)
+        float *out = h->d_part2;
+        for (int level = 0; level < 2 && nb > 4 * kGroup; ++level) {
+            const int ng = (nb + kGroup - 1) / kGroup;
+            hipLaunchKernelGGL(k_combine_group, dim3(ng), dim3(kThreads), 0, st, recs, nb, h->HA, h->hc.neg_inv_lambda, out);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            recs = out;
+            nb = ng;
+            out = h->d_part3;
+        }
     }
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), finish_lds_bytes(h->HA), st, recs, nb, h->HA, h->a,
                        h->hc.neg_inv_lambda, U, u_out, record_out, apply, h->d_step, h->d_dbg, U_updated);

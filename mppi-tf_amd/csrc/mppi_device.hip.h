@@ -87,18 +87,41 @@ __device__ __forceinline__ float2 box_muller_hw(unsigned int x, unsigned int y)
     return float2{sn * s, cs * s};
 }
 
+// The Philox4x32-10 block function (Random123; constants as rocrand_philox4x32_10.h:60-65) at the counter
+// rocrand_init(seed, subsequence, 4*block) would reach: counter = {lo(block), hi(block), lo(subseq), hi(subseq)},
+// key = seed. Bit-identical to rocRAND's engine (PhiloxAt above, kept for -DMPPI_ROCRAND_NORMALS and checked
+// by the noise parity test); written out so each round is 2 x v_mad_u64_u32 + 2 x v_bitop3_b32 (3-input xor)
+// instead of the 6 instructions hipcc emits for the header's two-step xor — the kernel is VALU-issue bound.
+__device__ __forceinline__ uint4 philox4x32_10_block(unsigned long long seed, unsigned long long subsequence,
+                                                     unsigned long long block)
+{
+    unsigned int c0 = (unsigned int)block, c1 = (unsigned int)(block >> 32);
+    unsigned int c2 = (unsigned int)subsequence, c3 = (unsigned int)(subsequence >> 32);
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long m0 = (unsigned long long)ROCRAND_PHILOX_M4x32_0 * c0;
+        const unsigned long long m1 = (unsigned long long)ROCRAND_PHILOX_M4x32_1 * c2;
+        const unsigned int n0 = __builtin_amdgcn_bitop3_b32((unsigned int)(m1 >> 32), c1, k0, 0x96);
+        const unsigned int n2 = __builtin_amdgcn_bitop3_b32((unsigned int)(m0 >> 32), c3, k1, 0x96);
+        c0 = n0; c1 = (unsigned int)m1; c2 = n2; c3 = (unsigned int)m0;
+        k0 += ROCRAND_PHILOX_W32_0; k1 += ROCRAND_PHILOX_W32_1;
+    }
+    return uint4{c0, c1, c2, c3};
+}
+
 template <int A>
 __device__ __forceinline__ void normals_group(unsigned long long seed, unsigned long long gk,
                                               unsigned long long group_index, float (&z)[4 * A])
 {
 #pragma unroll
     for (int q = 0; q < A; ++q) {
-        PhiloxAt eng(seed, gk, 4ull * (group_index * A + q));
 #if defined(MPPI_ROCRAND_NORMALS)
+        PhiloxAt eng(seed, gk, 4ull * (group_index * A + q));
         const float4 n = rocrand_device::detail::normal_distribution4(eng.block());
         z[4 * q + 0] = n.x; z[4 * q + 1] = n.y; z[4 * q + 2] = n.z; z[4 * q + 3] = n.w;
 #else
-        const uint4 r = eng.block();
+        const uint4 r = philox4x32_10_block(seed, gk, group_index * A + q);
         const float2 n0 = box_muller_hw(r.x, r.y), n1 = box_muller_hw(r.z, r.w);
         z[4 * q + 0] = n0.x; z[4 * q + 1] = n0.y; z[4 * q + 2] = n1.x; z[4 * q + 3] = n1.y;
 #endif

@@ -577,3 +577,28 @@ def test_reference_shaped_python_entry_point(m, tmp_path):
     assert dist < 0.1, r.stdout
     rows = csv.read_text().strip().splitlines()
     assert len(rows) == 81 and rows[0].startswith("x0,")
+
+
+def test_written_out_philox_equals_rocrand_engine(m):
+    """The default build evaluates Philox4x32-10 with its own round function and hardware-rate Box-Muller; the
+    -DMPPI_ROCRAND_NORMALS build (build/variants/, made by tools/ablate.py or build.build_variant) calls rocRAND's
+    engine and normal_distribution4 verbatim. Same counters -> the same noise up to the log/sqrt flavour."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    so = os.path.join(ROOT, "build", "variants", "libmppi_hip_rocrand_normals.so")
+    if not os.path.exists(so):
+        pytest.skip("variant library not built")
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, mppi_tf_amd as m; "
+            "h = m.Handle(k=512, tau=20, s_dim=6, a_dim=3, seed=99, sigma=0.5*np.eye(3)); h.next(np.zeros(6, np.float32)); "
+            "np.save(sys.argv[1], h.debug_get(m.DBG_NOISE))" % ROOT)
+    outs = []
+    for tag, env in (("default", {}), ("rocrand", {"MPPI_SO_PATH": so})):
+        f = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mppi_noise_%s_%d.npy" % (tag, os.getpid()))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+        os.remove(f)
+    np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=5e-6)
+    assert np.abs(outs[0]).max() > 1.0  # not degenerate
