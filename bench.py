@@ -127,8 +127,9 @@ def main():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("MPPI_FORCE_EXCHANGE") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import mppi_tf_amd as m
@@ -142,7 +143,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -155,7 +156,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     t = torch.tensor([el], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
 
@@ -217,7 +218,7 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(mlp=mlp)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -33,8 +33,16 @@ struct mppi_handle {
     int sigma_diag = 0; // Σ and Σ⁻¹ are exactly diagonal (the DIAG kernel instances are bit-identical then)
     int pc_np = 5;      // producer waves per workgroup of k_rollout_pc (MPPI_PC_PRODUCERS=3 selects the 4-wave variant)
     int force_tile = 0; // MPPI_FORCE_TILE_KERNEL=1: run the LDS-tile kernel instead of the producer/consumer one (A/B timing)
-    float *d_x = nullptr, *d_U = nullptr, *d_u = nullptr, *d_cost = nullptr, *d_cost2 = nullptr;
-    float *d_part = nullptr, *d_part2 = nullptr, *d_part3 = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_Uupd = nullptr, *d_mm = nullptr;
+    float *d_x = nullptr, *d_u = nullptr, *d_cost = nullptr, *d_cost2 = nullptr;
+    // The nominal sequence lives in one of two buffers of tau*a + a floats whose last a floats stay zero. A step
+    // reads U from ubuf[u_cur] + u_off and writes U' to the other buffer at offset 0; the shifted sequence
+    // (mShift + mInit0, controller_base.cpp:310-324) is then simply that buffer read from offset a_dim.
+    float *d_Ubuf[2] = {nullptr, nullptr};
+    int u_cur = 0, u_off = 0;
+    float *U_cur() const { return d_Ubuf[u_cur] + u_off; }
+    float *U_other() const { return d_Ubuf[1 - u_cur]; }
+    void U_advance() { u_cur = 1 - u_cur; u_off = a; }
+    float *d_part = nullptr, *d_part2 = nullptr, *d_part3 = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_mm = nullptr;
     float *d_eps = nullptr; // lazily allocated [K_local, H, a] for injected noise / debug export
     unsigned long long *d_step = nullptr;
     // pinned, device-mapped host staging for the synchronous path: x slot 0 | x slot 1 | u. The kernels read
@@ -148,8 +156,8 @@ extern "C" void mppi_destroy(mppi_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    float *bufs[] = {h->d_x, h->d_U, h->d_u, h->d_cost, h->d_cost2, h->d_part, h->d_part2, h->d_part3, h->d_record, h->d_dbg,
-                     h->d_Uupd, h->d_mm, h->d_eps};
+    float *bufs[] = {h->d_x, h->d_Ubuf[0], h->d_Ubuf[1], h->d_u, h->d_cost, h->d_cost2, h->d_part, h->d_part2, h->d_part3,
+                     h->d_record, h->d_dbg, h->d_mm, h->d_eps};
     for (float *p : bufs) if (p) (void)hipFree(p);
     if (h->d_step) (void)hipFree(h->d_step);
     if (h->dM) (void)hipFree(h->dM);
@@ -265,7 +273,10 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_TRY(h, hipMalloc((void **)&h->dC, sizeof(DevConsts)));
         HIP_TRY(h, hipMalloc((void **)&h->d_x, sizeof(float) * kMaxS));
-        HIP_TRY(h, hipMalloc((void **)&h->d_U, sizeof(float) * h->HA));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(h, hipMalloc((void **)&h->d_Ubuf[i], sizeof(float) * (h->HA + h->a)));
+            HIP_TRY(h, hipMemsetAsync(h->d_Ubuf[i], 0, sizeof(float) * (h->HA + h->a), h->stream)); // U0 = 0
+        }
         HIP_TRY(h, hipMalloc((void **)&h->d_u, sizeof(float) * kMaxA));
         HIP_TRY(h, hipMalloc((void **)&h->d_cost, sizeof(float) * h->K_local));
         HIP_TRY(h, hipMalloc((void **)&h->d_cost2, sizeof(float) * h->K_local));
@@ -297,12 +308,10 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         }
         HIP_TRY(h, hipMalloc((void **)&h->d_record, sizeof(float) * (2 + h->HA)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dbg, sizeof(float) * 8));
-        HIP_TRY(h, hipMalloc((void **)&h->d_Uupd, sizeof(float) * h->HA));
         HIP_TRY(h, hipMalloc((void **)&h->d_mm, sizeof(float) * 2));
         HIP_TRY(h, hipMalloc((void **)&h->d_step, sizeof(unsigned long long)));
         HIP_TRY(h, hipHostMalloc((void **)&h->h_pin, sizeof(float) * (2 * kMaxS + kMaxA), hipHostMallocMapped));
         HIP_TRY(h, hipHostGetDevicePointer((void **)&h->d_pin, h->h_pin, 0));
-        HIP_TRY(h, hipMemsetAsync(h->d_U, 0, sizeof(float) * h->HA, h->stream)); // U0 = 0
         HIP_TRY(h, hipMemsetAsync(h->d_step, 0, sizeof(unsigned long long), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_dbg, 0, sizeof(float) * 8, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_cost, 0, sizeof(float) * h->K_local, h->stream));
@@ -327,7 +336,7 @@ static hipError_t launch_tile_inst(mppi_handle *h, hipStream_t st, const float *
         if (e != hipSuccess) return e;
         attr_set = h->tile_lds;
     }
-    hipLaunchKernelGGL(kern, dim3(h->nb), dim3(kThreads), h->tile_lds, st, h->dC, x_dev, U_dev, eps, h->d_step, cost, part, noise_out);
+    hipLaunchKernelGGL(kern, dim3(h->nb), dim3(kThreads), h->tile_lds, st, h->dC, x_dev, U_dev, eps, h->d_step, cost, part, noise_out, 1, h->nb);
     return hipGetLastError();
 }
 
@@ -382,8 +391,9 @@ static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_
     const size_t lds = pc_lds_floats(A, NP) * 4;
     const int nb = (h->K_local + 63) / 64;
     const dim3 g(nb), b(64 * (NP + 1));
-    if (h->sigma_diag) hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, lds, st, h->dC, x_dev, h->d_U, h->d_step, h->d_cost, h->d_part);
-    else hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, lds, st, h->dC, x_dev, h->d_U, h->d_step, h->d_cost, h->d_part);
+    // tile records go out column-major ([2+HA][nb]): the finish kernel reads one column per workgroup
+    if (h->sigma_diag) hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, lds, st, h->dC, x_dev, h->U_cur(), h->d_step, h->d_cost, h->d_part, 1, nb);
+    else hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, lds, st, h->dC, x_dev, h->U_cur(), h->d_step, h->d_cost, h->d_part, 1, nb);
     return hipGetLastError();
 }
 
@@ -427,7 +437,7 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
             if (e_ != hipSuccess) return e_;                                                                            \
             attr_done |= BIT;                                                                                           \
         }                                                                                                               \
-        hipLaunchKernelGGL(kern, g, b, lds, st, h->dC, h->dM, x_dev, U_dev, eps, h->d_step, cost, h->d_part, src, mode); \
+        hipLaunchKernelGGL(kern, g, b, lds, st, h->dC, h->dM, x_dev, U_dev, eps, h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp); \
     } while (0)
     if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp<A, true>), 2);
     else MPPI_MLP_L((k_rollout_mlp<A, false>), 4);
@@ -447,26 +457,25 @@ static hipError_t launch_mlp(mppi_handle *h, hipStream_t st, int src, int mode, 
     return hipErrorInvalidValue;
 }
 
-static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *recs, int nb, float *U, float *u_out,
-                                float *record_out, int apply, float *U_updated)
+// Combine nb records (element (b,col) at recs[b*sb + col*sc]) and, if apply, update: U' = U_in + V/eta -> U_out,
+// u_out = U'[0]. More than 1024 records are first folded 16:1 (k_combine_group) into row-major scratch.
+static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *recs, int sb, int sc, int nb,
+                                const float *U_in, float *U_out, float *u_out, float *record_out, int apply)
 {
     // a profiled step = the rollout kernel + the finish that applies the update
     const bool prof = apply && h->prof_n < h->prof_cap;
     if (prof) { hipError_t e = hipEventRecord(h->ev[4 * h->prof_n + 2], st); if (e != hipSuccess) return e; }
-    if (recs == h->d_part) { // record tree: fold 16 records per workgroup until one workgroup can finish (see k_combine_group)
-        float *out = h->d_part2;
-        for (int level = 0; level < 2 && nb > 4 * kGroup; ++level) {
-            const int ng = (nb + kGroup - 1) / kGroup;
-            hipLaunchKernelGGL(k_combine_group, dim3(ng), dim3(kThreads), 0, st, recs, nb, h->HA, h->hc.neg_inv_lambda, out);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return e;
-            recs = out;
-            nb = ng;
-            out = h->d_part3;
-        }
+    float *out = h->d_part2;
+    while (nb > 1024) {
+        const int ng = (nb + kGroup - 1) / kGroup;
+        hipLaunchKernelGGL(k_combine_group, dim3(ng), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->hc.neg_inv_lambda, out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        recs = out; sb = 2 + h->HA; sc = 1; nb = ng;
+        out = h->d_part3;
     }
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), finish_lds_bytes(h->HA), st, recs, nb, h->HA, h->a,
-                       h->hc.neg_inv_lambda, U, u_out, record_out, apply, h->d_step, h->d_dbg, U_updated);
+    hipLaunchKernelGGL(k_finish_cols, dim3(h->HA), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
+                       U_in, U_out, u_out, record_out, apply, h->d_step, h->d_dbg);
     hipError_t e = hipGetLastError();
     if (prof && e == hipSuccess) { e = hipEventRecord(h->ev[4 * h->prof_n + 3], st); h->prof_stream = st; h->prof_n++; }
     return e;
@@ -480,22 +489,22 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
     if (!h->normalize) {
         const bool prof = h->prof_n < h->prof_cap;
         if (prof) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 0], st));
-        if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_ROLLOUT, x_dev, h->d_U, eps, h->d_cost));
+        if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_ROLLOUT, x_dev, h->U_cur(), eps, h->d_cost));
         else if (src == SRC_PHILOX && noise_out == nullptr && pc_eligible(h)) HIP_TRY(h, launch_pc(h, st, x_dev));
-        else HIP_TRY(h, launch_tile(h, st, src, MODE_ROLLOUT, x_dev, h->d_U, eps, h->d_cost, h->d_part, noise_out));
+        else HIP_TRY(h, launch_tile(h, st, src, MODE_ROLLOUT, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out));
         if (prof) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 1], st));
         return MPPI_OK;
     }
     if (h->shard_count != 1) return fail(h, MPPI_ERR_UNSUPPORTED, "normalize_cost needs the global max cost: unsharded handles only");
     // Py normalizeCost (controller_base.py:468-474): costs, global min/max, then the update on
     // c' = (c-min)/(max-min) with the SAME noise (regenerated from the same Philox counters).
-    if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_COST_ONLY, x_dev, h->d_U, eps, h->d_cost));
-    else HIP_TRY(h, launch_tile(h, st, src, MODE_COST_ONLY, x_dev, h->d_U, eps, h->d_cost, h->d_part, noise_out));
+    if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost));
+    else HIP_TRY(h, launch_tile(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out));
     hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(kFinishThreads), 0, st, h->d_cost, h->K_local, h->d_mm);
     HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(k_cost_normalize, dim3((h->K_local + 255) / 256), dim3(256), 0, st, h->d_cost, h->K_local, h->d_mm, h->d_cost2);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, launch_tile(h, st, src, MODE_COSTS_GIVEN, x_dev, h->d_U, eps, h->d_cost2, h->d_part, nullptr));
+    HIP_TRY(h, launch_tile(h, st, src, MODE_COSTS_GIVEN, x_dev, h->U_cur(), eps, h->d_cost2, h->d_part, nullptr));
     *nrec = h->nb;
     return MPPI_OK;
 }
@@ -575,7 +584,8 @@ extern "C" mppi_status mppi_next_device(mppi_handle *h, const float *x_dev, floa
     int nrec = 0;
     mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr, &nrec);
     if (s != MPPI_OK) return s;
-    HIP_TRY(h, launch_finish(h, st, h->d_part, nrec, h->d_U, u_dev, nullptr, 1, h->d_Uupd));
+    HIP_TRY(h, launch_finish(h, st, h->d_part, 1, nrec, nrec, h->U_cur(), h->U_other(), u_dev, nullptr, 1));
+    h->U_advance();
     return MPPI_OK;
 }
 
@@ -587,7 +597,7 @@ extern "C" mppi_status mppi_shard_partial(mppi_handle *h, const float *x_dev, fl
     int nrec = 0;
     mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr, &nrec);
     if (s != MPPI_OK) return s;
-    HIP_TRY(h, launch_finish(h, st, h->d_part, nrec, h->d_U, h->d_u, record_dev, 0, nullptr));
+    HIP_TRY(h, launch_finish(h, st, h->d_part, 1, nrec, nrec, h->U_cur(), h->U_other(), h->d_u, record_dev, 0));
     return MPPI_OK;
 }
 
@@ -596,7 +606,8 @@ extern "C" mppi_status mppi_shard_finish(mppi_handle *h, const float *records_de
     if (!h || !records_dev || !u_dev || n_records <= 0) return h ? fail(h, MPPI_ERR_INVALID_ARG, "bad records/u pointer or count") : MPPI_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    HIP_TRY(h, launch_finish(h, st, records_dev, n_records, h->d_U, u_dev, nullptr, 1, h->d_Uupd));
+    HIP_TRY(h, launch_finish(h, st, records_dev, 2 + h->HA, 1, n_records, h->U_cur(), h->U_other(), u_dev, nullptr, 1));
+    h->U_advance();
     return MPPI_OK;
 }
 
@@ -624,7 +635,8 @@ static mppi_status step_host(mppi_handle *h, const float *x, int n_x, const floa
     int nrec = 0;
     mppi_status s = enqueue_partials(h, h->stream, src, x_arg, h->d_eps, nullptr, &nrec);
     if (s != MPPI_OK) return s;
-    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, nrec, h->d_U, u_arg, nullptr, 1, h->d_Uupd));
+    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, 1, nrec, nrec, h->U_cur(), h->U_other(), u_arg, nullptr, 1));
+    h->U_advance();
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::memcpy(u_out, h->h_pin + 2 * kMaxS, sizeof(float) * h->a);
     // m_db.addX(s); m_db.addU(out_tensor[1])  controller_base.cpp:146-147
@@ -677,7 +689,7 @@ extern "C" mppi_status mppi_get_action_sequence(mppi_handle *h, float *U, int n)
     if (!h) return MPPI_ERR_INVALID_ARG;
     if (!U || n != h->HA) return fail(h, MPPI_ERR_INVALID_ARG, "U must hold tau*a floats");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(U, h->d_U, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(U, h->U_cur(), sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MPPI_OK;
 }
@@ -687,7 +699,9 @@ extern "C" mppi_status mppi_set_action_sequence(mppi_handle *h, const float *U, 
     if (!h) return MPPI_ERR_INVALID_ARG;
     if (!U || n != h->HA) return fail(h, MPPI_ERR_INVALID_ARG, "U must hold tau*a floats");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(h->d_U, U, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+    for (int i = 0; i < 2; ++i) HIP_TRY(h, hipMemsetAsync(h->d_Ubuf[i], 0, sizeof(float) * (h->HA + h->a), h->stream)); // zero tails
+    h->u_cur = 0; h->u_off = 0;
+    HIP_TRY(h, hipMemcpyAsync(h->d_Ubuf[0], U, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MPPI_OK;
 }
@@ -725,7 +739,9 @@ extern "C" mppi_status mppi_debug_get(mppi_handle *h, int what, float *out, size
     case MPPI_DBG_COSTS: src = h->d_cost; need = K; break;
     case MPPI_DBG_BETA: src = h->d_dbg; need = 1; break;
     case MPPI_DBG_ETA: src = h->d_dbg + 1; need = 1; break;
-    case MPPI_DBG_U_UPDATED: src = h->d_Uupd; need = (size_t)h->HA; break;
+    case MPPI_DBG_U_UPDATED: // U' of the last step = the current buffer from offset 0 (the warm start reads it from offset a)
+        if (h->u_off == 0) return fail(h, MPPI_ERR_INVALID_ARG, "no step has run since the action sequence was set");
+        src = h->d_Ubuf[h->u_cur]; need = (size_t)h->HA; break;
     case MPPI_DBG_WEIGHTS: {
         need = K;
         if (n != need) return fail(h, MPPI_ERR_INVALID_ARG, "wrong output size");
@@ -747,7 +763,7 @@ extern "C" mppi_status mppi_debug_get(mppi_handle *h, int what, float *out, size
         if (cur == 0) return fail(h, MPPI_ERR_INVALID_ARG, "no step has run yet");
         unsigned long long prev = cur - 1;
         HIP_TRY(h, hipMemcpyAsync(h->d_step, &prev, sizeof(prev), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, launch_tile(h, h->stream, SRC_PHILOX, MODE_COST_ONLY, h->d_x, h->d_U, nullptr, h->d_cost2, h->d_part, h->d_eps));
+        HIP_TRY(h, launch_tile(h, h->stream, SRC_PHILOX, MODE_COST_ONLY, h->d_x, h->U_cur(), nullptr, h->d_cost2, h->d_part, h->d_eps));
         HIP_TRY(h, hipMemcpyAsync(h->d_step, &cur, sizeof(cur), hipMemcpyHostToDevice, h->stream));
         src = h->d_eps;
         break;
@@ -902,7 +918,7 @@ extern "C" mppi_status mppi_update(mppi_handle *h, const float *cost, const floa
     // record = (beta, eta, V); then U' on a scratch copy of U (apply shifts it, so read U_updated)
     unsigned long long step_before = 0;
     HIP_TRY(h, hipMemcpyAsync(&step_before, h->d_step, sizeof(step_before), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, h->nb, dU.p, du.p, drec.p, 1, dUn.p));
+    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, 1, h->nb, h->nb, dU.p, dUn.p, du.p, drec.p, 1));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_step, &step_before, sizeof(step_before), hipMemcpyHostToDevice, h->stream)); // stateless call
     hipLaunchKernelGGL(k_weights, dim3((K + 255) / 256), dim3(256), 0, h->stream, h->dC, dc.p, K, drec.p, darg.p, dexp.p, dw.p);

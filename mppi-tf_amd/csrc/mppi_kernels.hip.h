@@ -29,7 +29,7 @@ template <int A, int R, bool QFULL, int SRC, int MODE>
 __global__ __launch_bounds__(kThreads) void k_rollout_tile(
     const DevConsts *__restrict__ C, const float *__restrict__ x_dev, const float *__restrict__ U_dev,
     const float *__restrict__ eps_hbm, const unsigned long long *__restrict__ step_ctr,
-    float *__restrict__ cost, float *__restrict__ partials, float *__restrict__ noise_out)
+    float *__restrict__ cost, float *__restrict__ partials, float *__restrict__ noise_out, const int rsb, const int rsc)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 2 * A;
@@ -142,8 +142,9 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
     __syncthreads();
 
     // ---- phase C: V_b[c] = Σ_k e_k·eps[k,c] in fixed k order (mWeightedNoise, :188-192) -----
-    float *rec = partials + (size_t)blockIdx.x * (2 + HA);
-    if (tid == 0) { rec[0] = red_s[0]; rec[1] = red_s[1]; }
+    // record element (b, col) lives at partials[b*rsb + col*rsc]: column-major (rsb = 1) for the finish kernel
+    float *rec = partials + (size_t)blockIdx.x * rsb;
+    if (tid == 0) { rec[0] = red_s[0]; rec[(size_t)rsc] = red_s[1]; }
 #if defined(MPPI_ABLATE_WSUM) // timing-only build: no weighted-noise sum
     for (int c = tid; c < 1; c += kThreads) {
 #else
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
         float acc = 0.0f;
 #pragma unroll 8
         for (int kl = 0; kl < R; ++kl) acc = acc + w_s[kl] * row[kl];
-        rec[2 + c] = acc;
+        rec[(size_t)(2 + c) * rsc] = acc;
     }
 }
 
@@ -191,7 +192,8 @@ __host__ __device__ inline size_t pc_lds_floats(int A, int NP) { return (size_t)
 template <int A, int NP, int NSLOT, bool DIAG>
 __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) void k_rollout_pc(
     const DevConsts *__restrict__ C, const float *__restrict__ x_dev, const float *__restrict__ U_dev,
-    const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials)
+    const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
+    const int rsb, const int rsc)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 2 * A;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
     const int lane = tid & 63;
     const int k0 = blockIdx.x * 64;
     const bool valid = (k0 + lane) < K;
-    float *rec = partials + (size_t)blockIdx.x * (2 + HA);
+    float *rec = partials + (size_t)blockIdx.x * rsb; // element (b, col) at partials[b*rsb + col*rsc]
 
     if (wave != 0) {
         // ------------------------------------------------------------------ producers
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
             const int i = n / (4 * A), rem = n - i * (4 * A);
             const int tl = rem / A, j = rem - tl * A;
             const int t = 4 * (NP * i + p) + tl;
-            if (n < NREG && t < H) rec[2 + t * A + j] = tot[m];
+            if (n < NREG && t < H) rec[(size_t)(2 + t * A + j) * rsc] = tot[m];
         }
     } else {
         // ------------------------------------------------------------------ consumer
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
         const float ek = valid ? expf(arg) : 0.0f;
         const float eta = wave_sum(ek);
         w_s[lane] = ek;
-        if (lane == 0) { rec[0] = beta; rec[1] = eta; }
+        if (lane == 0) { rec[0] = beta; rec[(size_t)rsc] = eta; }
         __syncthreads(); // weights published
     }
 }
@@ -335,14 +337,14 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
 constexpr int kGroup = 16;
 // Scalars arrive as kernel arguments (SGPRs at wave start) rather than through DevConsts: these
 // kernels are a chain of dependent memory round trips, and every hop removed is ~0.5-1 µs.
+// Input element (b, col) at recs[b*sb + col*sc]; output records are row-major [ng, 2+HA].
 __global__ __launch_bounds__(kThreads) void k_combine_group(
-    const float *__restrict__ recs, int nb, int HA, float neg_inv_lambda, float *__restrict__ out)
+    const float *__restrict__ recs, int sb, int sc, int nb, int HA, float neg_inv_lambda, float *__restrict__ out)
 {
     const int stride = 2 + HA;
     const int b0 = blockIdx.x * kGroup;
     const int n = min(kGroup, nb - b0);
     const int tid = threadIdx.x;
-    // every thread reads the group's betas itself (wave-uniform addresses -> scalar loads): no LDS, no barrier
     float bb[kGroup], r[kGroup];
     float beta = INFINITY;
     // loads are UNCONDITIONAL on clamped indices and masked afterwards: a load under a runtime
@@ -351,9 +353,9 @@ __global__ __launch_bounds__(kThreads) void k_combine_group(
     float v_first[kGroup];
     const int col_first = min(tid, HA);
 #pragma unroll
-    for (int b = 0; b < kGroup; ++b) v_first[b] = recs[(size_t)(b0 + min(b, n - 1)) * stride + 1 + col_first];
+    for (int b = 0; b < kGroup; ++b) v_first[b] = recs[(size_t)(b0 + min(b, n - 1)) * sb + (size_t)(1 + col_first) * sc];
 #pragma unroll
-    for (int b = 0; b < kGroup; ++b) bb[b] = recs[(size_t)(b0 + min(b, n - 1)) * stride];
+    for (int b = 0; b < kGroup; ++b) bb[b] = recs[(size_t)(b0 + min(b, n - 1)) * sb];
 #pragma unroll
     for (int b = 0; b < kGroup; ++b) {
         bb[b] = b < n ? bb[b] : INFINITY;
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(kThreads) void k_combine_group(
     for (int col = tid; col < HA + 1; col += kThreads) {
         float v[kGroup];
 #pragma unroll
-        for (int b = 0; b < kGroup; ++b) v[b] = col == tid ? v_first[b] : recs[(size_t)(b0 + min(b, n - 1)) * stride + 1 + col];
+        for (int b = 0; b < kGroup; ++b) v[b] = col == tid ? v_first[b] : recs[(size_t)(b0 + min(b, n - 1)) * sb + (size_t)(1 + col) * sc];
         double acc = 0.0;
 #pragma unroll
         for (int b = 0; b < kGroup; ++b) acc += (double)r[b] * (double)v[b]; // r[b] = 0 beyond n
@@ -373,107 +375,81 @@ __global__ __launch_bounds__(kThreads) void k_combine_group(
     }
 }
 
-__host__ __device__ inline size_t finish_lds_bytes(int HA) { return (size_t)(kFinishThreads + HA + 1) * 8 + 64 + 4 * kFinishThreads; }
-
 // ----------------------------------------------------------------------------------------
-// k_finish: fixed-order combine of nb records (beta_b, eta_b, V_b[HA]) laid out [nb, 2+HA]:
-//   beta = min_b beta_b ; r_b = exp(-(beta_b-beta)/λ) ; eta = Σ r_b eta_b ; V = Σ r_b V_b
-// then either emit ONE record (beta, eta, V) for the shard exchange, and/or
-// apply  U' = U + V/eta ; u = U'[0] ; U <- concat(U'[1:], 0)   (mBuildUpdateGraph :223,
-// mGetNew :326-329, mShift+mInit0 :310-324) and advance the Philox step counter.
-// The sums run in double: nb·(HA+1) adds, negligible next to the rollouts.
-// One workgroup of 1024 threads; dynamic LDS = finish_lds_bytes(HA).
-constexpr int kFinishBatch = 16; // record values a thread keeps in flight
-__global__ __launch_bounds__(kFinishThreads) void k_finish(
-    const float *__restrict__ recs, int nb, int HA, int a, float neg_inv_lambda,
-    float *__restrict__ U, float *__restrict__ u_out, float *__restrict__ record_out, int apply,
-    unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg, float *__restrict__ U_updated)
+// k_finish_cols: the whole combine + update in ONE launch, one workgroup per horizon-action column c:
+//   beta = min_b beta_b ; r_b = exp(-(beta_b-beta)/λ) ; eta = Σ r_b eta_b ; V_c = Σ r_b V_b[c]      (double sums)
+// and either a shard record (beta, eta, V) for the exchange and/or the update
+//   U'[c] = U[c] + V_c/eta ; u = U'[0]   (mBuildUpdateGraph controller_base.cpp:223, mGetNew :326-329).
+// Every workgroup derives beta and eta itself from the same loads in the same fixed order (identical
+// bits everywhere), so no workgroup waits for another. The shift (mShift + mInit0, :310-324) costs
+// nothing: U' is written to the OTHER of two U buffers whose tail holds a_dim permanent zeros, and the
+// next step reads that buffer from offset a_dim. With the tile records stored column-major the loads are
+// fully coalesced. Replaces a 16-way fold kernel plus a single-workgroup finish (4.6 + 5.2 µs).
+// Record element (b, col) at recs[b*sb + col*sc]. grid = HA workgroups of 256 threads.
+__global__ __launch_bounds__(kThreads) void k_finish_cols(
+    const float *__restrict__ recs, int sb, int sc, int nb, int HA, int a, float neg_inv_lambda,
+    const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
+    float *__restrict__ record_out, int apply, unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg)
 {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    const int ncol = HA + 1; // column 0 = eta, columns 1..HA = V
-    const int stride = 2 + HA;
-    double *part_s = fsm;                  // [kFinishThreads]
-    double *tot_s = fsm + kFinishThreads;  // [ncol]
-    float *beta_s = reinterpret_cast<float *>(tot_s + ncol); // [kFinishThreads/64]
-    float *r_s = beta_s + kFinishThreads / 64;                 // [kFinishThreads] rescale factors of the first 1024 records
-    const int tid = threadIdx.x;
-
-    // the first pass's record values are requested before anything waits on the betas
-    const int ncp0 = min(ncol, kFinishThreads);
-    const int G0 = kFinishThreads / ncp0;
-    const int col_0 = tid % ncp0, g_0 = tid / ncp0;
-    float v0[kFinishBatch];
+    __shared__ float red_f[kThreads / 64];
+    __shared__ double red_d[2][kThreads / 64];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    constexpr int PER = 4; // records per thread held in registers (nb <= 1024 in one pass)
+    const float u_old = U_in[c];
+    const unsigned long long step_old = step_ctr[0];
+    float bb[PER], ee[PER], vv[PER];
 #pragma unroll
-    for (int i = 0; i < kFinishBatch; ++i) // unconditional loads on clamped indices (see k_combine_group)
-        v0[i] = recs[(size_t)min(g_0 + i * G0, nb - 1) * stride + 1 + col_0];
-    const float u_old0 = U[min(tid, HA - 1)];
-    float my_beta = recs[(size_t)min(tid, nb - 1) * stride];
-    my_beta = tid < nb ? my_beta : INFINITY;
-    float bmin = my_beta;
-    for (int b = tid + kFinishThreads; b < nb; b += kFinishThreads) bmin = fminf(bmin, recs[(size_t)b * stride]);
+    for (int i = 0; i < PER; ++i) { // unconditional clamped loads (see k_combine_group)
+        const size_t b = (size_t)min(tid + i * kThreads, nb - 1) * sb;
+        bb[i] = recs[b];
+        ee[i] = recs[b + (size_t)sc];
+        vv[i] = recs[b + (size_t)(2 + c) * sc];
+    }
+    float bmin = INFINITY;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) bmin = fminf(bmin, (tid + i * kThreads < nb) ? bb[i] : INFINITY);
+    for (int b = tid + PER * kThreads; b < nb; b += kThreads) bmin = fminf(bmin, recs[(size_t)b * sb]);
     bmin = wave_min(bmin);
-    if ((tid & 63) == 0) beta_s[tid >> 6] = bmin;
+    if ((tid & 63) == 0) red_f[tid >> 6] = bmin;
     __syncthreads();
-    float beta = beta_s[0];
+    float beta = red_f[0];
 #pragma unroll
-    for (int w = 1; w < kFinishThreads / 64; ++w) beta = fminf(beta, beta_s[w]);
-    r_s[tid] = tid < nb ? expf(neg_inv_lambda * (my_beta - beta)) : 0.0f;
+    for (int w = 1; w < kThreads / 64; ++w) beta = fminf(beta, red_f[w]);
+
+    double se = 0.0, sv = 0.0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (tid + i * kThreads < nb) {
+            const float r = expf(neg_inv_lambda * (bb[i] - beta));
+            se += (double)r * (double)ee[i];
+            sv += (double)r * (double)vv[i];
+        }
+    }
+    for (int b = tid + PER * kThreads; b < nb; b += kThreads) {
+        const size_t o = (size_t)b * sb;
+        const float r = expf(neg_inv_lambda * (recs[o] - beta));
+        se += (double)r * (double)recs[o + (size_t)sc];
+        sv += (double)r * (double)recs[o + (size_t)(2 + c) * sc];
+    }
+    se = wave_sum_d(se);
+    sv = wave_sum_d(sv);
+    if ((tid & 63) == 0) { red_d[0][tid >> 6] = se; red_d[1][tid >> 6] = sv; }
     __syncthreads();
-
-    for (int col0 = 0; col0 < ncol; col0 += kFinishThreads) {
-        const int ncp = min(ncol - col0, kFinishThreads); // columns in this pass
-        const int G = kFinishThreads / ncp;               // record groups summed concurrently
-        const int col = tid % ncp, g = tid / ncp;
-        double acc = 0.0;
-        if (g < G) {
-            int b = g;
-            if (col0 == 0) { // the prefetched batch
+    if (tid == 0) {
+        double eta = red_d[0][0], V = red_d[1][0];
 #pragma unroll
-                for (int i = 0; i < kFinishBatch; ++i) {
-                    const int bi = g + i * G;
-                    if (bi < nb) acc += (double)r_s[bi] * (double)v0[i];
-                }
-                b = g + kFinishBatch * G;
-            }
-            for (; b < nb; b += G) {
-                const float rb = b < kFinishThreads ? r_s[b] : expf(neg_inv_lambda * (recs[(size_t)b * stride] - beta));
-                acc += (double)rb * (double)recs[(size_t)b * stride + 1 + col0 + col];
-            }
+        for (int w = 1; w < kThreads / 64; ++w) { eta += red_d[0][w]; V += red_d[1][w]; }
+        if (record_out != nullptr) {
+            record_out[2 + c] = (float)V;
+            if (c == 0) { record_out[0] = beta; record_out[1] = (float)eta; }
         }
-        part_s[tid] = acc;
-        __syncthreads();
-        if (g == 0) {
-            double t = part_s[col];
-            for (int gg = 1; gg < G; ++gg) t += part_s[gg * ncp + col];
-            tot_s[col0 + col] = t;
+        if (c == 0 && dbg != nullptr) { dbg[0] = beta; dbg[1] = (float)eta; }
+        if (apply) {
+            const float un = u_old + (float)(V / eta);
+            U_out[c] = un;            // U' ; the next step reads U_out + a (the shifted sequence)
+            if (c < a) u_out[c] = un; // mGetNew
+            if (c == 0) step_ctr[0] = step_old + 1ull;
         }
-        __syncthreads();
-    }
-
-    const double eta = tot_s[0];
-    if (record_out != nullptr) {
-        if (tid == 0) { record_out[0] = beta; record_out[1] = (float)eta; }
-        for (int c = tid; c < HA; c += kFinishThreads) record_out[2 + c] = (float)tot_s[1 + c];
-    }
-    if (dbg != nullptr && tid == 0) { dbg[0] = beta; dbg[1] = (float)eta; }
-    if (apply) {
-        // every thread reads its U'[c] before anyone writes the shifted sequence
-        for (int c0 = 0; c0 < HA; c0 += kFinishThreads) {
-            const int c = c0 + tid;
-            float un = 0.0f;
-            if (c < HA) {
-                const float wn = (float)(tot_s[1 + c] / eta);
-                un = (c0 == 0 ? u_old0 : U[c]) + wn;
-                if (U_updated != nullptr) U_updated[c] = un;
-            }
-            __syncthreads();
-            if (c < HA) {
-                if (c < a) u_out[c] = un; else U[c - a] = un;
-                if (c >= HA - a) U[c] = 0.0f;
-            }
-            __syncthreads();
-        }
-        if (tid == 0) step_ctr[0] = step_ctr[0] + 1ull;
     }
 }
 
@@ -560,7 +536,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
     const DevConsts *__restrict__ C, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
     const float *__restrict__ U_dev, const float *__restrict__ eps_hbm,
     const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
-    const int SRC, const int MODE)
+    const int SRC, const int MODE, const int rsb, const int rsc)
 {
     constexpr bool QFULL = false;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -739,8 +715,8 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
     const float beta = wave_min(valid ? c : INFINITY);
     const float ek = valid ? expf(C->neg_inv_lambda * (c - beta)) : 0.0f;
     const float eta = wave_sum(ek);
-    float *rec = partials + (size_t)blockIdx.x * (2 + HA);
-    if (w == 0 && lane == 0) { rec[0] = beta; rec[1] = eta; }
+    float *rec = partials + (size_t)blockIdx.x * rsb; // element (b, col) at partials[b*rsb + col*rsc]
+    if (w == 0 && lane == 0) { rec[0] = beta; rec[(size_t)rsc] = eta; }
     // V_b[t,i] = Σ_k e_k·eps[k,t,i]: wave w regenerates the noise of horizon groups g = w, w+8, ...
     for (int g = w; g < NG; g += 8) {
         float zz[4 * A];
@@ -761,7 +737,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
 #pragma unroll
                 for (int i = 0; i < A; ++i) {
                     const float tot = wave_sum_dpp(ek * e[i]);
-                    if (lane == 0) rec[2 + t * A + i] = tot;
+                    if (lane == 0) rec[(size_t)(2 + t * A + i) * rsc] = tot;
                 }
             }
         }

@@ -63,17 +63,23 @@ class ShardedController:
         self.record = torch.zeros(n, dtype=torch.float32, device=dev)
         self.records = torch.zeros(self.world * n, dtype=torch.float32, device=dev)
         self.u = torch.zeros(self.backend.a, dtype=torch.float32, device=dev)
+        # MPPI_FORCE_EXCHANGE=1: take the record -> all-gather -> finish path even with one rank (exercises the
+        # N>1 code path, incl. the collective, on a single-GPU box)
+        import os
+        self.force_exchange = os.environ.get("MPPI_FORCE_EXCHANGE") == "1"
 
     def next(self, x):
         """x: float32 tensor [s] on the backend's device (replicated on every rank). Returns u [a]
         (device tensor, valid in stream order; identical on every rank)."""
-        if self.world == 1 and hasattr(self.backend, "step"):
+        if self.world == 1 and hasattr(self.backend, "step") and not self.force_exchange:
             self.backend.step(x, self.u)
             return self.u
         self.backend.partial(x, self.record)
-        if self.world > 1:
+        if self.world > 1 or (self.force_exchange and dist.is_initialized()):
             dist.all_gather_into_tensor(self.records, self.record, group=self.group)
-        self.backend.finish(self.records if self.world > 1 else self.record, self.world, self.u)
+            self.backend.finish(self.records, self.world, self.u)
+        else:
+            self.backend.finish(self.record, 1, self.u)
         return self.u
 
 
