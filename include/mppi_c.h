@@ -173,7 +173,9 @@ int mppi_record_size(const mppi_handle *h);
 int mppi_local_samples(const mppi_handle *h);
 int mppi_sample_offset(const mppi_handle *h);
 /* One whole step, enqueue only: x_dev[s] -> u_dev[a]; U and the step counter advance on the
- * device. Unsharded handles only. */
+ * device. Unsharded handles only. The nominal sequence alternates between two device buffers from
+ * one call to the next (the shift is a pointer offset), so a captured hipGraph must hold an EVEN
+ * number of consecutive steps to be replayable. */
 mppi_status mppi_next_device(mppi_handle *h, const float *x_dev, float *u_dev, void *stream);
 /* Sharded step, phase 1: rollouts + local soft-min of this shard -> record_dev[record_size]. */
 mppi_status mppi_shard_partial(mppi_handle *h, const float *x_dev, float *record_dev, void *stream);

@@ -603,10 +603,17 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
 
         // normalised inputs of this lane's rollout (+ the bias input 1, + zero padding)
         float in[K1];
+#if defined(MPPI_ABLATE_MLP_DIV) // timing-only: multiply instead of divide
+#pragma unroll
+        for (int i = 0; i < S; ++i) in[i] = (x[i] - M->xmean[i]) * M->xstd[i];
+#pragma unroll
+        for (int i = 0; i < A; ++i) in[S + i] = (v[i] - M->xmean[S + i]) * M->xstd[S + i];
+#else
 #pragma unroll
         for (int i = 0; i < S; ++i) in[i] = (x[i] - M->xmean[i]) / M->xstd[i];
 #pragma unroll
         for (int i = 0; i < A; ++i) in[S + i] = (v[i] - M->xmean[S + i]) / M->xstd[S + i];
+#endif
         in[NIN] = 1.0f;
 #pragma unroll
         for (int i = NIN + 1; i < K1; ++i) in[i] = 0.0f;
@@ -673,8 +680,13 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
         float py0[S], py1[S];
 #pragma unroll
         for (int n = 0; n < S; ++n) { py0[n] = 0.0f; py1[n] = 0.0f; }
+#if defined(MPPI_ABLATE_MLP_L3) // timing-only: 1 of 16 rows
+#pragma unroll
+        for (int r = 0; r < 1; ++r) {
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+#endif
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
             const float hv0 = acc0[r] < 0.0f ? 0.0f : acc0[r];
             const float hv1 = acc1[r] < 0.0f ? 0.0f : acc1[r];
@@ -698,8 +710,10 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
 #pragma unroll
         for (int n = 0; n < S; ++n) {
             float y = y_s[(0 * S + n) * R + lane];
+#if !defined(MPPI_ABLATE_MLP_Y) // timing-only: skip the cross-wave partial sum
 #pragma unroll
             for (int ww = 1; ww < 8; ++ww) y = y + y_s[(ww * S + n) * R + lane];
+#endif
             y = y + M->b3[n];
             x[n] = x[n] + (y * M->ystd[n] + M->ymean[n]);
         }

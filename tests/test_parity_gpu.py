@@ -169,6 +169,9 @@ def test_rollout_cost_bit_exact(m, case):
 NEXT_CASES = [
     dict(K=128, H=32, a=1), dict(K=4096, H=64, a=2), dict(K=65536, H=64, a=3),
     dict(K=1000, H=50, a=3, mass=5.0), dict(K=70, H=5, a=2, lam=0.1), dict(K=3000, H=50, a=3, lam=10.0),
+    dict(K=1, H=1, a=1), dict(K=2, H=3, a=2),              # degenerate: one sample gets weight 1
+    dict(K=300, H=256, a=3), dict(K=100, H=500, a=4),      # long horizons: the R=32 / R=16 LDS-tile kernel
+    dict(K=65537, H=16, a=3),                              # one sample past 1024 tiles: the 16:1 fold level
 ]
 
 
@@ -602,3 +605,16 @@ def test_written_out_philox_equals_rocrand_engine(m):
         os.remove(f)
     np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=5e-6)
     assert np.abs(outs[0]).max() > 1.0  # not degenerate
+
+
+def test_native_cpp_sharded_host_with_rccl(m):
+    """examples/host_loop_sharded.cpp: mppi_shard_partial -> ncclAllGather -> mppi_shard_finish from C++ over every
+    visible GPU (one here), closed loop on the host plant; replicated controls must agree bit for bit."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "host_loop_sharded")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe, "8192", "32", "3", "80"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rollouts/s" in r.stdout
