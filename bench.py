@@ -137,8 +137,6 @@ def main():
 
     k_global = K_PER_GPU * world
     mlp = synthetic_mlp() if args.workload == "mlp" else None
-    ctl = ShardedController(device_index=local_rank, k=k_global, mlp=mlp, **CFG)
-    assert ctl.backend.h.k_local == K_PER_GPU
     x = torch.zeros(S, dtype=torch.float32, device=dev)
 
     def barrier():
@@ -147,14 +145,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        ctl.next(x)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctl.next(x)
-    barrier()
-    el = time.perf_counter() - t0
+    def exchange_failed(ctl):
+        """True on every rank if the direct exchange missed a deadline on any rank (its results are invalid then)"""
+        bad = torch.tensor([1 if (ctl.p2p and ctl.backend.p2p_timed_out()) else 0], dtype=torch.int32, device=dev)
+        if dist.is_initialized():
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        return bool(bad.item())
+
+    # The record exchange of a sharded step: the direct (in-kernel, peer-store) exchange if its self-test passes on
+    # every rank, else one RCCL all-gather per step. A deadline missed later also sends the whole run to RCCL.
+    for exchange in (os.environ.get("MPPI_EXCHANGE", "auto"), "rccl"):
+        ctl = ShardedController(device_index=local_rank, k=k_global, mlp=mlp, exchange=exchange, p2p_timeout_ms=200, **CFG)
+        assert ctl.backend.h.k_local == K_PER_GPU
+        for _ in range(args.warmup):
+            ctl.next(x)
+        barrier()
+        if exchange_failed(ctl):
+            continue
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctl.next(x)
+        barrier()
+        el = time.perf_counter() - t0
+        if not exchange_failed(ctl):
+            break
     t = torch.tensor([el], dtype=torch.float64, device=dev)
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -196,7 +210,13 @@ def main():
                                     "on-device Philox noise, device-resident x/U" % (K_PER_GPU, H)),
                        "K_global": k_global, "K_per_gpu": K_PER_GPU, "H": H, "s_dim": S, "a_dim": A,
                        "lambda": 1.0, "sigma": "0.25*I", "dt": 0.1, "mass": 1.0,
-                       "parallelism": "K-shard x%d, one all-gather of %d floats per step" % (world, h.record_size)},
+                       "parallelism": "K-shard x%d, %s" % (world, {
+                           "none": "single shard, no exchange",
+                           "p2p": "records (%d floats) exchanged as peer stores over xGMI inside the finish kernel (%s)"
+                                  % (h.record_size, ctl.p2p_note),
+                           "rccl": "one RCCL all-gather of %d floats per step (direct exchange: %s)"
+                                   % (h.record_size, ctl.p2p_note)}[ctl.exchange]),
+                       "exchange": ctl.exchange},
             "roofline": {"bound": "hbm", "kernel": "mppi::k_rollout_pc<3, 3, 6, true>",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(),

@@ -5,13 +5,16 @@
 //     mppi_shard_finish  (fixed-order combine, U' = U + V/eta, shift; replicated on every GPU)
 // all stream-ordered, no host synchronisation inside the step. Uses every visible GPU (1 on a one-GPU box).
 // This is the single-process flavour (ncclCommInitAll); bench.py uses one process per GPU through torch.distributed.
-//   usage: host_loop_sharded [k_per_gpu=65536] [tau=64] [a_dim=3] [steps=100]
+// With a 5th argument "p2p" the exchange is the direct one of include/mppi_c.h instead (mppi_shard_p2p_*: the finish
+// kernel stores the record into every GPU's inbox and spins for the others; peer access inside this one process).
+//   usage: host_loop_sharded [k_per_gpu=65536] [tau=64] [a_dim=3] [steps=100] [rccl|p2p]
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "mppi_c.h"
@@ -24,6 +27,7 @@ int main(int argc, char **argv)
 {
     const int kper = argc > 1 ? atoi(argv[1]) : 65536, tau = argc > 2 ? atoi(argv[2]) : 64;
     const int a = argc > 3 ? atoi(argv[3]) : 3, steps = argc > 4 ? atoi(argv[4]) : 100, s = 2 * a;
+    const bool p2p = argc > 5 && std::string(argv[5]) == "p2p";
     int ndev = 0;
     CK_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) { fprintf(stderr, "no GPU\n"); return 1; }
@@ -53,8 +57,24 @@ int main(int argc, char **argv)
         CK_HIP(hipMalloc((void **)&recs[d], sizeof(float) * nrec * ndev));
         CK_HIP(hipMemset(x_dev[d], 0, sizeof(float) * s));
     }
+    if (p2p) {
+        std::vector<void *> inbox(ndev);
+        for (int d = 0; d < ndev; ++d) CK_MPPI(mppi_shard_p2p_export(h[d], nullptr, &inbox[d]), h[d]);
+        for (int d = 0; d < ndev; ++d) {
+            CK_HIP(hipSetDevice(d));
+            for (int e = 0; e < ndev; ++e) if (e != d) {
+                hipError_t pe = hipDeviceEnablePeerAccess(e, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { fprintf(stderr, "no peer access %d -> %d\n", d, e); return 6; }
+            }
+            CK_MPPI(mppi_shard_p2p_attach(h[d], inbox.data(), ndev, 1000), h[d]);
+        }
+    }
     std::vector<float> x(s, 0.f), u(a, 0.f), u_other(a, 0.f);
     auto step = [&]() -> int {
+        if (p2p) {
+            for (int d = 0; d < ndev; ++d) CK_MPPI(mppi_shard_p2p_step(h[d], x_dev[d], u_dev[d], st[d]), h[d]);
+            return 0;
+        }
         for (int d = 0; d < ndev; ++d) CK_MPPI(mppi_shard_partial(h[d], x_dev[d], rec[d], st[d]), h[d]);
         CK_NCCL(ncclGroupStart());
         for (int d = 0; d < ndev; ++d) CK_NCCL(ncclAllGather(rec[d], recs[d], nrec, ncclFloat, comm[d], st[d]));
@@ -86,8 +106,13 @@ int main(int argc, char **argv)
     for (int it = 0; it < 200; ++it) if (int rc = step()) return rc;
     for (int d = 0; d < ndev; ++d) { CK_HIP(hipSetDevice(d)); CK_HIP(hipStreamSynchronize(st[d])); }
     const double el = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count() / 200;
-    printf("%d GPU(s), K=%d per GPU, tau=%d: |x-goal|^2 %g -> %g after %d closed-loop steps; %.1f us per sharded control step = %.3g rollouts/s\n",
-           ndev, kper, tau, d2_init, d2, steps, el * 1e6, (double)kper * ndev / el);
+    for (int d = 0; d < ndev && p2p; ++d) {
+        int late = 0;
+        CK_MPPI(mppi_shard_p2p_status(h[d], &late), h[d]);
+        if (late) { fprintf(stderr, "GPU %d: a packet missed its deadline\n", d); return 7; }
+    }
+    printf("%s exchange, %d GPU(s), K=%d per GPU, tau=%d: |x-goal|^2 %g -> %g after %d closed-loop steps; %.1f us per sharded control step = %.3g rollouts/s\n",
+           p2p ? "direct" : "RCCL all-gather", ndev, kper, tau, d2_init, d2, steps, el * 1e6, (double)kper * ndev / el);
     for (int d = 0; d < ndev; ++d) { mppi_destroy(h[d]); ncclCommDestroy(comm[d]); }
     return d2 < 0.5f * d2_init ? 0 : 1;
 }

@@ -185,6 +185,38 @@ mppi_status mppi_shard_finish(mppi_handle *h, const float *records_dev, int n_re
 /* Wait for the handle's own stream. */
 mppi_status mppi_synchronize(mppi_handle *h);
 
+/* ---- K-sharding, direct exchange: the records travel as peer stores inside the finish kernel --
+ * A control step of the analytic model is ~25 us, of the same order as one small collective launched
+ * on its own, so the exchange can also be fused into the finish kernel: every rank owns an INBOX
+ * (uncached device memory) that all peers map (hipIpc across processes, peer access inside one
+ * process); workgroup c of the finish kernel stores this shard's (beta_g, eta_g, V_g[c]) as 8-byte
+ * {value, sequence} packets into every rank's inbox (xGMI peer stores), spins until the packets of
+ * all ranks have arrived in its own, then combines them in rank order exactly as mppi_shard_finish
+ * does — same bits as the all-gather path, no collective library on the step's critical path.
+ * Bring-up (all ranks, same order):
+ *   mppi_shard_p2p_export   allocate the inbox, get its device pointer and a 64-byte hipIpcMemHandle_t
+ *   (exchange the handles out of band, e.g. over the job's bootstrap channel)
+ *   mppi_shard_p2p_open     map a peer's inbox into this process (other processes' inboxes only)
+ *   mppi_shard_p2p_attach   the shard_count inbox pointers in rank order (own entry = own inbox)
+ *   mppi_shard_p2p_probe    one self-test round (known payload, same stores/spins); run it a few
+ *                           times on every rank and agree on the outcome before trusting the path
+ * then per control step mppi_shard_p2p_step on every rank (same number of calls everywhere: packets
+ * carry a call sequence number). Every spin has a deadline (timeout_ms at attach): on expiry the
+ * step completes with garbage and mppi_shard_p2p_status reports it; nothing hangs. */
+#define MPPI_MAX_SHARD_PEERS 16
+#define MPPI_IPC_HANDLE_BYTES 64
+mppi_status mppi_shard_p2p_export(mppi_handle *h, void *ipc_handle_out /* 64 B, may be NULL */, void **inbox_dev_out);
+mppi_status mppi_shard_p2p_open(mppi_handle *h, const void *ipc_handle /* 64 B */, void **peer_inbox_out);
+mppi_status mppi_shard_p2p_attach(mppi_handle *h, void *const *inboxes, int n, int timeout_ms);
+/* ok_out = 1 if the packets of all ranks arrived with the expected payload before the deadline.
+ * Synchronises the stream. */
+mppi_status mppi_shard_p2p_probe(mppi_handle *h, void *stream, int *ok_out);
+/* One whole sharded step, enqueue only: rollouts of this shard, exchange, update; x_dev[s] -> u_dev[a]. */
+mppi_status mppi_shard_p2p_step(mppi_handle *h, const float *x_dev, float *u_dev, void *stream);
+/* timed_out = 1 if any spin of any step since attach hit its deadline (read after synchronising
+ * the stream the steps ran on). */
+mppi_status mppi_shard_p2p_status(mppi_handle *h, int *timed_out);
+
 /* ---- measurement (the reference only has a commented-out chrono loop, main.cpp:55-64) ------ */
 /* Bracket the rollout kernel and the finish kernel of the next <= max_steps steps with HIP
  * events ON THE STREAM THEY ARE LAUNCHED ON. */

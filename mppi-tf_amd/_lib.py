@@ -82,6 +82,12 @@ SIGNATURES = {
     "mppi_shard_partial": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mppi_shard_finish": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mppi_synchronize": (C.c_int, [_H]),
+    "mppi_shard_p2p_export": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mppi_shard_p2p_open": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mppi_shard_p2p_attach": (C.c_int, [_H, C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "mppi_shard_p2p_probe": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_int)]),
+    "mppi_shard_p2p_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mppi_shard_p2p_status": (C.c_int, [_H, C.POINTER(C.c_int)]),
     "mppi_profile_begin": (C.c_int, [_H, C.c_int]),
     "mppi_profile_end": (C.c_int, [_H, FP, FP, C.POINTER(C.c_int)]),
 }
@@ -299,6 +305,37 @@ class Handle:
 
     def shard_finish(self, records_ptr, n_records, u_ptr, stream=0):
         self._check(self.lib.mppi_shard_finish(self.h, records_ptr, n_records, u_ptr, stream))
+
+    # ---- direct record exchange (mppi_shard_p2p_*, include/mppi_c.h) -------------------------
+    def p2p_export(self, want_ipc=True):
+        """-> (inbox device pointer, 64-byte hipIpcMemHandle_t as bytes or None)"""
+        buf = C.create_string_buffer(64) if want_ipc else None
+        ptr = C.c_void_p()
+        self._check(self.lib.mppi_shard_p2p_export(self.h, buf, C.byref(ptr)))
+        return ptr.value, (buf.raw if want_ipc else None)
+
+    def p2p_open(self, ipc_handle):
+        """map another process's inbox -> device pointer valid here"""
+        ptr = C.c_void_p()
+        self._check(self.lib.mppi_shard_p2p_open(self.h, C.create_string_buffer(ipc_handle, 64), C.byref(ptr)))
+        return ptr.value
+
+    def p2p_attach(self, inbox_ptrs, timeout_ms=2000):
+        arr = (C.c_void_p * len(inbox_ptrs))(*inbox_ptrs)
+        self._check(self.lib.mppi_shard_p2p_attach(self.h, arr, len(inbox_ptrs), timeout_ms))
+
+    def p2p_probe(self, stream=0):
+        ok = C.c_int(0)
+        self._check(self.lib.mppi_shard_p2p_probe(self.h, stream, C.byref(ok)))
+        return bool(ok.value)
+
+    def p2p_step(self, x_ptr, u_ptr, stream=0):
+        self._check(self.lib.mppi_shard_p2p_step(self.h, x_ptr, u_ptr, stream))
+
+    def p2p_timed_out(self):
+        t = C.c_int(0)
+        self._check(self.lib.mppi_shard_p2p_status(self.h, C.byref(t)))
+        return bool(t.value)
 
     def synchronize(self):
         self._check(self.lib.mppi_synchronize(self.h))

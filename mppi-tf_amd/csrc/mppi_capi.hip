@@ -57,6 +57,17 @@ struct mppi_handle {
     std::string no_rollout; // non-empty: why this handle cannot run rollouts (helpers still work)
     // transition log (m_db of the reference: addX/addU/addNext/toCSV, data_base.cpp:29-71)
     std::vector<float> log_x, log_u, log_next;
+    // direct record exchange (mppi_shard_p2p_*): own inbox, the peers' mapped inboxes, call sequence number
+    unsigned long long *xchg_inbox = nullptr;
+    XchgPeers xchg_peers{};
+    std::vector<void *> xchg_opened; // hipIpcOpenMemHandle mappings to close
+    bool xchg_attached = false;
+    unsigned xchg_seq = 0, probe_seq = 0;
+    long long xchg_timeout_ticks = 0;
+    unsigned *h_xchg_status = nullptr, *d_xchg_status = nullptr; // pinned, device-mapped
+    float *d_probe_got = nullptr;
+    size_t xchg_step_slots() const { return (size_t)2 * HA * shard_count * 3; }
+    size_t xchg_inbox_bytes() const { return sizeof(unsigned long long) * (xchg_step_slots() + (size_t)2 * shard_count); }
 };
 
 static thread_local std::string g_create_err;
@@ -164,6 +175,10 @@ extern "C" void mppi_destroy(mppi_handle *h)
     if (h->d_mlp_w) (void)hipFree(h->d_mlp_w);
     if (h->dC) (void)hipFree(h->dC);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    for (void *p : h->xchg_opened) (void)hipIpcCloseMemHandle(p);
+    if (h->xchg_inbox) (void)hipFree(h->xchg_inbox);
+    if (h->h_xchg_status) (void)hipHostFree(h->h_xchg_status);
+    if (h->d_probe_got) (void)hipFree(h->d_probe_got);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -460,7 +475,7 @@ static hipError_t launch_mlp(mppi_handle *h, hipStream_t st, int src, int mode, 
 // Combine nb records (element (b,col) at recs[b*sb + col*sc]) and, if apply, update: U' = U_in + V/eta -> U_out,
 // u_out = U'[0]. More than 1024 records are first folded 16:1 (k_combine_group) into row-major scratch.
 static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *recs, int sb, int sc, int nb,
-                                const float *U_in, float *U_out, float *u_out, float *record_out, int apply)
+                                const float *U_in, float *U_out, float *u_out, float *record_out, int apply, bool xchg = false)
 {
     // a profiled step = the rollout kernel + the finish that applies the update
     const bool prof = apply && h->prof_n < h->prof_cap;
@@ -474,8 +489,13 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
         recs = out; sb = 2 + h->HA; sc = 1; nb = ng;
         out = h->d_part3;
     }
-    hipLaunchKernelGGL(k_finish_cols, dim3(h->HA), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
-                       U_in, U_out, u_out, record_out, apply, h->d_step, h->d_dbg);
+    if (xchg)
+        hipLaunchKernelGGL(k_finish_cols_xchg, dim3(h->HA), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
+                           U_in, U_out, u_out, h->d_step, h->d_dbg, h->xchg_peers, h->shard_count, h->shard_rank, ++h->xchg_seq,
+                           h->xchg_timeout_ticks, h->d_xchg_status);
+    else
+        hipLaunchKernelGGL(k_finish_cols, dim3(h->HA), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
+                           U_in, U_out, u_out, record_out, apply, h->d_step, h->d_dbg);
     hipError_t e = hipGetLastError();
     if (prof && e == hipSuccess) { e = hipEventRecord(h->ev[4 * h->prof_n + 3], st); h->prof_stream = st; h->prof_n++; }
     return e;
@@ -608,6 +628,103 @@ extern "C" mppi_status mppi_shard_finish(mppi_handle *h, const float *records_de
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     HIP_TRY(h, launch_finish(h, st, records_dev, 2 + h->HA, 1, n_records, h->U_cur(), h->U_other(), u_dev, nullptr, 1));
     h->U_advance();
+    return MPPI_OK;
+}
+
+// ---- direct record exchange (see include/mppi_c.h) -----------------------------------------------
+extern "C" mppi_status mppi_shard_p2p_export(mppi_handle *h, void *ipc_handle_out, void **inbox_dev_out)
+{
+    if (!h || !inbox_dev_out) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL inbox_dev_out") : MPPI_ERR_INVALID_ARG;
+    if (h->shard_count > kMaxPeers) return fail(h, MPPI_ERR_UNSUPPORTED, "direct exchange supports at most 16 shards");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->xchg_inbox) {
+        // uncached: peer stores land in memory and the local spin loads see them without any cache maintenance
+        HIP_TRY(h, hipExtMallocWithFlags((void **)&h->xchg_inbox, h->xchg_inbox_bytes(), hipDeviceMallocUncached));
+        HIP_TRY(h, hipMemset(h->xchg_inbox, 0, h->xchg_inbox_bytes()));
+        HIP_TRY(h, hipHostMalloc((void **)&h->h_xchg_status, sizeof(unsigned), hipHostMallocMapped));
+        *h->h_xchg_status = 0u;
+        HIP_TRY(h, hipHostGetDevicePointer((void **)&h->d_xchg_status, h->h_xchg_status, 0));
+        HIP_TRY(h, hipMalloc((void **)&h->d_probe_got, sizeof(float) * kMaxPeers));
+        HIP_TRY(h, hipDeviceSynchronize());
+    }
+    if (ipc_handle_out) {
+        static_assert(sizeof(hipIpcMemHandle_t) == MPPI_IPC_HANDLE_BYTES, "ipc handle size");
+        hipIpcMemHandle_t ih;
+        HIP_TRY(h, hipIpcGetMemHandle(&ih, h->xchg_inbox));
+        memcpy(ipc_handle_out, &ih, sizeof(ih));
+    }
+    *inbox_dev_out = h->xchg_inbox;
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_shard_p2p_open(mppi_handle *h, const void *ipc_handle, void **peer_inbox_out)
+{
+    if (!h || !ipc_handle || !peer_inbox_out) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL ipc handle / output") : MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipIpcMemHandle_t ih;
+    memcpy(&ih, ipc_handle, sizeof(ih));
+    void *p = nullptr;
+    HIP_TRY(h, hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess));
+    h->xchg_opened.push_back(p);
+    *peer_inbox_out = p;
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_shard_p2p_attach(mppi_handle *h, void *const *inboxes, int n, int timeout_ms)
+{
+    if (!h || !inboxes) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL inbox table") : MPPI_ERR_INVALID_ARG;
+    if (n != h->shard_count || n > kMaxPeers) return fail(h, MPPI_ERR_INVALID_ARG, "need exactly shard_count (<= 16) inbox pointers, rank order");
+    if (!h->xchg_inbox) return fail(h, MPPI_ERR_INVALID_ARG, "call mppi_shard_p2p_export first");
+    if (inboxes[h->shard_rank] != (void *)h->xchg_inbox) return fail(h, MPPI_ERR_INVALID_ARG, "entry shard_rank must be this handle's own inbox");
+    if (timeout_ms <= 0 || timeout_ms > 60000) return fail(h, MPPI_ERR_INVALID_ARG, "timeout_ms must be in [1, 60000]");
+    for (int g = 0; g < n; ++g) {
+        if (!inboxes[g]) return fail(h, MPPI_ERR_INVALID_ARG, "NULL inbox pointer");
+        h->xchg_peers.inbox[g] = (unsigned long long *)inboxes[g];
+    }
+    h->xchg_timeout_ticks = (long long)timeout_ms * 100000ll; // wall_clock64 ticks at 100 MHz
+    h->xchg_attached = true;
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_shard_p2p_probe(mppi_handle *h, void *stream, int *ok_out)
+{
+    if (!h || !ok_out) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL ok_out") : MPPI_ERR_INVALID_ARG;
+    if (!h->xchg_attached) return fail(h, MPPI_ERR_INVALID_ARG, "inboxes not attached");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const unsigned seq = ++h->probe_seq;
+    const int G = h->shard_count;
+    auto payload = [&](int g) { return (float)(1000 * (int)(seq % 1000u) + g + 1); };
+    hipLaunchKernelGGL(k_xchg_probe, dim3(1), dim3(64), 0, st, h->xchg_peers, h->xchg_step_slots(), G, h->shard_rank, seq,
+                       payload(h->shard_rank), h->xchg_timeout_ticks, h->d_xchg_status, h->d_probe_got);
+    HIP_TRY(h, hipGetLastError());
+    float got[kMaxPeers];
+    HIP_TRY(h, hipMemcpyAsync(got, h->d_probe_got, sizeof(float) * G, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    int ok = (*(volatile unsigned *)h->h_xchg_status & 1u) ? 0 : 1;
+    for (int g = 0; g < G; ++g) ok &= got[g] == payload(g);
+    *ok_out = ok;
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_shard_p2p_step(mppi_handle *h, const float *x_dev, float *u_dev, void *stream)
+{
+    if (!h || !x_dev || !u_dev) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL device pointer") : MPPI_ERR_INVALID_ARG;
+    if (!h->xchg_attached) return fail(h, MPPI_ERR_INVALID_ARG, "inboxes not attached");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    int nrec = 0;
+    mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr, &nrec);
+    if (s != MPPI_OK) return s;
+    HIP_TRY(h, launch_finish(h, st, h->d_part, 1, nrec, nrec, h->U_cur(), h->U_other(), u_dev, nullptr, 1, true));
+    h->U_advance();
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_shard_p2p_status(mppi_handle *h, int *timed_out)
+{
+    if (!h || !timed_out) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL timed_out") : MPPI_ERR_INVALID_ARG;
+    *timed_out = h->h_xchg_status ? (int)(*(volatile unsigned *)h->h_xchg_status & 1u) : 0;
     return MPPI_OK;
 }
 

@@ -386,29 +386,27 @@ __global__ __launch_bounds__(kThreads) void k_combine_group(
 // next step reads that buffer from offset a_dim. With the tile records stored column-major the loads are
 // fully coalesced. Replaces a 16-way fold kernel plus a single-workgroup finish (4.6 + 5.2 µs).
 // Record element (b, col) at recs[b*sb + col*sc]. grid = HA workgroups of 256 threads.
-__global__ __launch_bounds__(kThreads) void k_finish_cols(
-    const float *__restrict__ recs, int sb, int sc, int nb, int HA, int a, float neg_inv_lambda,
-    const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
-    float *__restrict__ record_out, int apply, unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg)
+// column_combine: (beta, eta, V_c) over nb records, valid on thread 0. ld(b, j) returns element j of record b
+// (0 = beta_b, 1 = eta_b, 2 = V_b[c]) and must be safe for every b < nb; the same code (and therefore the same
+// summation order and bits) serves the tile records in HBM and the gathered shard records in LDS.
+template <class Load>
+__device__ __forceinline__ void column_combine(Load ld, int nb, float neg_inv_lambda, float *red_f, double (*red_d)[kThreads / 64],
+                                               float &beta_out, double &eta_out, double &V_out)
 {
-    __shared__ float red_f[kThreads / 64];
-    __shared__ double red_d[2][kThreads / 64];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     constexpr int PER = 4; // records per thread held in registers (nb <= 1024 in one pass)
-    const float u_old = U_in[c];
-    const unsigned long long step_old = step_ctr[0];
     float bb[PER], ee[PER], vv[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) { // unconditional clamped loads (see k_combine_group)
-        const size_t b = (size_t)min(tid + i * kThreads, nb - 1) * sb;
-        bb[i] = recs[b];
-        ee[i] = recs[b + (size_t)sc];
-        vv[i] = recs[b + (size_t)(2 + c) * sc];
+        const int b = min(tid + i * kThreads, nb - 1);
+        bb[i] = ld(b, 0);
+        ee[i] = ld(b, 1);
+        vv[i] = ld(b, 2);
     }
     float bmin = INFINITY;
 #pragma unroll
     for (int i = 0; i < PER; ++i) bmin = fminf(bmin, (tid + i * kThreads < nb) ? bb[i] : INFINITY);
-    for (int b = tid + PER * kThreads; b < nb; b += kThreads) bmin = fminf(bmin, recs[(size_t)b * sb]);
+    for (int b = tid + PER * kThreads; b < nb; b += kThreads) bmin = fminf(bmin, ld(b, 0));
     bmin = wave_min(bmin);
     if ((tid & 63) == 0) red_f[tid >> 6] = bmin;
     __syncthreads();
@@ -426,19 +424,35 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols(
         }
     }
     for (int b = tid + PER * kThreads; b < nb; b += kThreads) {
-        const size_t o = (size_t)b * sb;
-        const float r = expf(neg_inv_lambda * (recs[o] - beta));
-        se += (double)r * (double)recs[o + (size_t)sc];
-        sv += (double)r * (double)recs[o + (size_t)(2 + c) * sc];
+        const float r = expf(neg_inv_lambda * (ld(b, 0) - beta));
+        se += (double)r * (double)ld(b, 1);
+        sv += (double)r * (double)ld(b, 2);
     }
     se = wave_sum_d(se);
     sv = wave_sum_d(sv);
     if ((tid & 63) == 0) { red_d[0][tid >> 6] = se; red_d[1][tid >> 6] = sv; }
     __syncthreads();
-    if (tid == 0) {
-        double eta = red_d[0][0], V = red_d[1][0];
+    double eta = red_d[0][0], V = red_d[1][0];
 #pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w) { eta += red_d[0][w]; V += red_d[1][w]; }
+    for (int w = 1; w < kThreads / 64; ++w) { eta += red_d[0][w]; V += red_d[1][w]; }
+    beta_out = beta; eta_out = eta; V_out = V;
+}
+
+__global__ __launch_bounds__(kThreads) void k_finish_cols(
+    const float *__restrict__ recs, int sb, int sc, int nb, int HA, int a, float neg_inv_lambda,
+    const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
+    float *__restrict__ record_out, int apply, unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg)
+{
+    __shared__ float red_f[kThreads / 64];
+    __shared__ double red_d[2][kThreads / 64];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const float u_old = U_in[c];
+    const unsigned long long step_old = step_ctr[0];
+    float beta;
+    double eta, V;
+    column_combine([&](int b, int j) { return recs[(size_t)b * sb + (size_t)(j == 2 ? 2 + c : j) * sc]; },
+                   nb, neg_inv_lambda, red_f, red_d, beta, eta, V);
+    if (tid == 0) {
         if (record_out != nullptr) {
             record_out[2 + c] = (float)V;
             if (c == 0) { record_out[0] = beta; record_out[1] = (float)eta; }
@@ -451,6 +465,89 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols(
             if (c == 0) step_ctr[0] = step_old + 1ull;
         }
     }
+}
+
+// ----------------------------------------------------------------------------------------
+// k_finish_cols_xchg: the K-sharded step's finish with the record exchange INSIDE the kernel.
+// Workgroup c folds this shard's tile records to (beta_g, eta_g, V_g[c]) as above, then
+//   send : stores the three values as 8-byte {value, seq} packets into slot (seq&1, c, rank) of EVERY rank's inbox
+//          (peer memory mapped over xGMI; one naturally-aligned 64-bit store carries value and flag together, so no
+//          fence and no separate flag — the idea of RCCL's LL protocol);
+//   recv : spins (system-scope loads of its own uncached inbox) until slot (seq&1, c, g) carries seq for every g;
+//   then combines the G records in rank order with the same column_combine and applies U' — replicated, bit-identical
+//   on every rank, and bit-identical to the all-gather path (same floats through the same code).
+// No workgroup waits on anything a peer sends only after receiving from it (every send precedes the wait), so there is
+// no circular wait. Slot reuse is safe with two parities: a rank sends seq+2 only after it has received seq+1 from
+// everyone, which they sent after they finished reading seq. Every spin has a wall-clock deadline; on expiry it sets
+// *status and falls through (the result is then garbage, the host sees the flag).
+constexpr int kMaxPeers = 16;
+struct XchgPeers { unsigned long long *inbox[kMaxPeers]; };
+
+__device__ __forceinline__ unsigned long long xchg_wait(const unsigned long long *slot, unsigned seq, long long timeout_ticks, unsigned *status)
+{
+    const long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned long long got = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(got >> 32) == seq) return got;
+        if (wall_clock64() - t0 > timeout_ticks) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return got;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_finish_cols_xchg(
+    const float *__restrict__ recs, int sb, int sc, int nb, int HA, int a, float neg_inv_lambda,
+    const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
+    unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg,
+    XchgPeers peers, int G, int rank, unsigned seq, long long timeout_ticks, unsigned *status)
+{
+    __shared__ float red_f[kThreads / 64];
+    __shared__ double red_d[2][kThreads / 64];
+    __shared__ float mine[3];
+    __shared__ float theirs[3][kMaxPeers];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const float u_old = U_in[c];
+    const unsigned long long step_old = step_ctr[0];
+    float beta;
+    double eta, V;
+    column_combine([&](int b, int j) { return recs[(size_t)b * sb + (size_t)(j == 2 ? 2 + c : j) * sc]; },
+                   nb, neg_inv_lambda, red_f, red_d, beta, eta, V);
+    if (tid == 0) { mine[0] = beta; mine[1] = (float)eta; mine[2] = (float)V; }
+    __syncthreads();
+    const size_t slot0 = ((size_t)(seq & 1u) * HA + c) * G;
+    if (tid < 3 * G) {
+        const int p = tid / 3, j = tid - 3 * p;
+        const unsigned long long pkt = ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(mine[j]);
+        __hip_atomic_store(peers.inbox[p] + (slot0 + rank) * 3 + j, pkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long got = xchg_wait(peers.inbox[rank] + (slot0 + p) * 3 + j, seq, timeout_ticks, status);
+        theirs[j][p] = __uint_as_float((unsigned)got);
+    }
+    __syncthreads();
+    column_combine([&](int b, int j) { return theirs[j][b]; }, G, neg_inv_lambda, red_f, red_d, beta, eta, V);
+    if (tid == 0) {
+        if (c == 0 && dbg != nullptr) { dbg[0] = beta; dbg[1] = (float)eta; }
+        const float un = u_old + (float)(V / eta);
+        U_out[c] = un;
+        if (c < a) u_out[c] = un;
+        if (c == 0) step_ctr[0] = step_old + 1ull;
+    }
+}
+
+// k_xchg_probe: the exchange's self-test, run once after the inboxes are attached and before the first step: the
+// same packets, stores and spins on a separate probe region of the inbox (after the 2*HA*G*3 step slots), with a
+// known payload. got[g] = the value received from rank g (the host checks got[g] == payload(g, seq)).
+__global__ void k_xchg_probe(XchgPeers peers, size_t probe_off, int G, int rank, unsigned seq, float payload,
+                             long long timeout_ticks, unsigned *status, float *got)
+{
+    const int p = threadIdx.x;
+    if (p >= G) return;
+    const size_t slot0 = probe_off + (size_t)(seq & 1u) * G;
+    const unsigned long long pkt = ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(payload);
+    __hip_atomic_store(peers.inbox[p] + slot0 + rank, pkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long r = xchg_wait(peers.inbox[rank] + slot0 + p, seq, timeout_ticks, status);
+    got[p] = __uint_as_float((unsigned)r);
 }
 
 // ----------------------------------------------------------------------------------------

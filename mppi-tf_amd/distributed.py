@@ -8,6 +8,11 @@ so results do not depend on G.  Per control step each rank
      latency-bound, far below any per-link bandwidth limit)
   3. combines them in rank order with r_g = exp(-(β_g-β)/λ) and applies U' = U + V/η, shift —
      replicated on every rank, bit-identical across ranks (same inputs, same fixed order).
+Two realisations of step 2, same bits: (i) ONE RCCL all-gather between two kernel launches, and (ii) the
+direct exchange of include/mppi_c.h (mppi_shard_p2p_*): the finish kernel itself stores the record into every
+peer's inbox over xGMI and spins for theirs — no collective launch on the critical path of a ~25 µs step.
+(ii) is brought up with a self-test and a vote over all ranks; if any rank cannot map a peer, or a probe
+packet does not arrive, every rank uses (i).  MPPI_EXCHANGE=rccl|p2p|auto (default auto) picks.
 torch is plumbing here: device buffers, the current stream, and torch.distributed (backend
 "nccl" is RCCL on ROCm; "gloo" drives the CPU test of this file's logic with a test backend).
 """
@@ -41,6 +46,25 @@ class HipShardBackend:
         """unsharded whole step (mppi_next_device): no record round trip"""
         self.h.next_device(x.data_ptr(), u.data_ptr(), self._stream())
 
+    # direct exchange (mppi_shard_p2p_*)
+    def p2p_export(self):
+        return self.h.p2p_export()
+
+    def p2p_open(self, ipc_handle):
+        return self.h.p2p_open(ipc_handle)
+
+    def p2p_attach(self, ptrs, timeout_ms):
+        self.h.p2p_attach(ptrs, timeout_ms)
+
+    def p2p_probe(self):
+        return self.h.p2p_probe(self._stream())
+
+    def p2p_step(self, x, u):
+        self.h.p2p_step(x.data_ptr(), u.data_ptr(), self._stream())
+
+    def p2p_timed_out(self):
+        return self.h.p2p_timed_out()
+
     def action_sequence(self):
         torch.cuda.current_stream(self.device).synchronize()
         return torch.from_numpy(self.h.get_action_sequence())
@@ -53,8 +77,11 @@ class ShardedController:
     (default: HipShardBackend built from cfg; tests inject a CPU test double over gloo).
     """
 
-    def __init__(self, backend=None, group=None, device_index=0, **cfg):
-        """cfg: Handle arguments (k = GLOBAL sample count, tau, s_dim, a_dim, sigma, goal, mlp, ...)."""
+    def __init__(self, backend=None, group=None, device_index=0, exchange=None, p2p_timeout_ms=2000, **cfg):
+        """cfg: Handle arguments (k = GLOBAL sample count, tau, s_dim, a_dim, sigma, goal, mlp, ...).
+        exchange: "auto" (direct exchange if its self-test passes on every rank, else the all-gather), "p2p"
+        (direct exchange or raise), "rccl" (all-gather); default from MPPI_EXCHANGE, else "auto"."""
+        import os
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -63,16 +90,65 @@ class ShardedController:
         self.record = torch.zeros(n, dtype=torch.float32, device=dev)
         self.records = torch.zeros(self.world * n, dtype=torch.float32, device=dev)
         self.u = torch.zeros(self.backend.a, dtype=torch.float32, device=dev)
-        # MPPI_FORCE_EXCHANGE=1: take the record -> all-gather -> finish path even with one rank (exercises the
-        # N>1 code path, incl. the collective, on a single-GPU box)
-        import os
+        # MPPI_FORCE_EXCHANGE=1: take the sharded path (records -> exchange -> finish) even with one rank
+        # (exercises the N>1 code path on a single-GPU box)
         self.force_exchange = os.environ.get("MPPI_FORCE_EXCHANGE") == "1"
+        exchange = exchange or os.environ.get("MPPI_EXCHANGE", "auto")
+        if exchange not in ("auto", "p2p", "rccl"):
+            raise ValueError("exchange must be auto, p2p or rccl")
+        self.p2p, self.p2p_note = False, "not requested"
+        sharded = self.world > 1 or self.force_exchange
+        if sharded and exchange != "rccl" and hasattr(self.backend, "p2p_export"):
+            self.p2p, self.p2p_note = self._bring_up_p2p(p2p_timeout_ms)
+            if exchange == "p2p" and not self.p2p:
+                raise RuntimeError("direct exchange requested but unavailable: " + self.p2p_note)
+        self.exchange = "none" if not sharded else ("p2p" if self.p2p else "rccl")
+
+    def _vote(self, ok):
+        """True iff ok on every rank"""
+        if not dist.is_initialized():
+            return bool(ok)
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.backend.device if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item())
+
+    def _bring_up_p2p(self, timeout_ms):
+        """export -> exchange IPC handles -> open -> attach -> probe x3, with a vote after each phase that can fail.
+        Every rank takes the same branch: the votes are collectives."""
+        note, ptrs = "", None
+        try:
+            own_ptr, ipc = self.backend.p2p_export()
+            ok = True
+        except Exception as e:  # HIP refused the uncached allocation or the IPC export
+            own_ptr, ipc, ok, note = None, None, False, "export: %s" % e
+        if dist.is_initialized():
+            handles = [None] * self.world
+            dist.all_gather_object(handles, ipc, group=self.group)
+        else:
+            handles = [ipc]
+        if ok:
+            try:
+                ptrs = [own_ptr if g == self.rank else self.backend.p2p_open(handles[g]) for g in range(self.world)]
+                self.backend.p2p_attach(ptrs, timeout_ms)
+            except Exception as e:
+                ok, note = False, "open/attach: %s" % e
+        if not self._vote(ok):
+            return False, note or "a peer could not map the inboxes"
+        for _ in range(3):
+            ok = self.backend.p2p_probe() and ok
+        if not self._vote(ok):
+            return False, "probe packets did not arrive on every rank"
+        return True, "self-test passed on %d rank(s)" % self.world
 
     def next(self, x):
         """x: float32 tensor [s] on the backend's device (replicated on every rank). Returns u [a]
         (device tensor, valid in stream order; identical on every rank)."""
         if self.world == 1 and hasattr(self.backend, "step") and not self.force_exchange:
             self.backend.step(x, self.u)
+            return self.u
+        if self.p2p:
+            self.backend.p2p_step(x, self.u)
             return self.u
         self.backend.partial(x, self.record)
         if self.world > 1 or (self.force_exchange and dist.is_initialized()):
@@ -81,6 +157,11 @@ class ShardedController:
         else:
             self.backend.finish(self.record, 1, self.u)
         return self.u
+
+    def check(self):
+        """After synchronising: raise if a direct-exchange spin ever hit its deadline (results are invalid then)."""
+        if self.p2p and self.backend.p2p_timed_out():
+            raise RuntimeError("direct exchange: a packet did not arrive before the deadline")
 
 
 def shard_bounds(k, rank, world):

@@ -615,6 +615,79 @@ def test_native_cpp_sharded_host_with_rccl(m):
     from conftest import ROOT
     exe = os.path.join(ROOT, "examples", "host_loop_sharded")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
-    r = subprocess.run([exe, "8192", "32", "3", "80"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "rollouts/s" in r.stdout
+    for mode in ("rccl", "p2p"):
+        r = subprocess.run([exe, "8192", "32", "3", "80", mode], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "rollouts/s" in r.stdout
+
+
+# =============================================================== direct record exchange (mppi_shard_p2p_*)
+@pytest.mark.parametrize("shards", [1, 2, 3])
+def test_direct_exchange_equals_allgather_path_bit_for_bit(m, shards):
+    """`shards` handles on this one GPU, each on its own stream, exchange their records as packets stored into each
+    other's inboxes from inside the finish kernel; U and u must equal the partial -> gather -> finish path bitwise."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    K, H, a = 4096, 32, 3
+    x = np.array([0.2, 0.1, -0.3, 0, 0.5, -0.1], F32)
+    xd = torch.tensor(x, device="cuda")
+    ref = [make_pair(m, K, H, a, seed=33, shard_rank=g, shard_count=shards)[0] for g in range(shards)]
+    hs = [make_pair(m, K, H, a, seed=33, shard_rank=g, shard_count=shards)[0] for g in range(shards)]
+    ptrs = [h.p2p_export(want_ipc=False)[0] for h in hs]
+    for h in hs:
+        h.p2p_attach(ptrs, timeout_ms=500)
+    with ThreadPoolExecutor(shards) as ex:  # a probe synchronises its stream: all ranks must be in flight together
+        for _ in range(3):
+            assert all(ex.map(lambda h: h.p2p_probe(), hs))
+    n = ref[0].record_size
+    recs = torch.zeros(shards * n, device="cuda")
+    u_ref = torch.zeros(a, device="cuda")
+    us = [torch.zeros(a, device="cuda") for _ in range(shards)]
+    for step in range(4):
+        for g, h in enumerate(ref):
+            h.shard_partial(xd.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
+            h.synchronize()
+        for h in ref:
+            h.shard_finish(recs.data_ptr(), shards, u_ref.data_ptr())
+            h.synchronize()
+        for g, h in enumerate(hs):          # enqueue only: the kernels of all shards meet on the GPU
+            h.p2p_step(xd.data_ptr(), us[g].data_ptr())
+        for h in hs:
+            h.synchronize()
+            assert not h.p2p_timed_out()
+        for g, h in enumerate(hs):
+            np.testing.assert_array_equal(us[g].cpu().numpy(), u_ref.cpu().numpy())
+            np.testing.assert_array_equal(h.get_action_sequence(), ref[0].get_action_sequence())
+            assert h.get_step_counter() == step + 1
+
+
+def test_direct_exchange_deadline_instead_of_hang(m):
+    """A rank whose peer never sends must come back with the timed-out flag, not hang."""
+    import torch
+    K, H, a = 1024, 8, 3
+    hs = [make_pair(m, K, H, a, seed=3, shard_rank=g, shard_count=2)[0] for g in range(2)]
+    ptrs = [h.p2p_export(want_ipc=False)[0] for h in hs]
+    hs[0].p2p_attach(ptrs, timeout_ms=50)
+    xd, u = torch.zeros(6, device="cuda"), torch.zeros(a, device="cuda")
+    hs[0].p2p_step(xd.data_ptr(), u.data_ptr())   # shard 1 never steps
+    hs[0].synchronize()
+    assert hs[0].p2p_timed_out()
+    with pytest.raises(m.MppiError):
+        hs[1].p2p_step(xd.data_ptr(), u.data_ptr())  # not attached
+    with pytest.raises(m.MppiError):
+        hs[1].p2p_attach(ptrs[::-1], timeout_ms=50)  # own entry must be the own inbox
+
+
+def test_direct_exchange_across_processes_over_hipipc():
+    """Two processes on this GPU (gloo rendezvous): inboxes exported with hipIpcGetMemHandle, mapped by the peer,
+    self-test + vote, then ShardedController steps; both ranks must produce the single-process result."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MPPI_EXCHANGE="p2p")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "tests", "p2p_worker.py")], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("P2P_WORKER_OK") == 2, r.stdout[-3000:] + r.stderr[-3000:]
