@@ -403,12 +403,16 @@ static hipError_t launch_tile(mppi_handle *h, hipStream_t st, int src, int mode,
 template <int A, int NP, int NSLOT>
 static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_dev)
 {
-    const size_t lds = pc_lds_floats(A, NP) * 4;
+    static const size_t lds_min = getenv("MPPI_PC_LDS_MIN") ? (size_t)atol(getenv("MPPI_PC_LDS_MIN")) : 0; // tuning knob: caps workgroups per CU
+    const size_t lds = std::max(pc_lds_floats(A, NP) * 4, lds_min);
     const int nb = (h->K_local + 63) / 64;
     const dim3 g(nb), b(64 * (NP + 1));
     // tile records go out column-major ([2+HA][nb]): the finish kernel reads one column per workgroup
-    if (h->sigma_diag) hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, lds, st, h->dC, x_dev, h->U_cur(), h->d_step, h->d_cost, h->d_part, 1, nb);
-    else hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, lds, st, h->dC, x_dev, h->U_cur(), h->d_step, h->d_cost, h->d_part, 1, nb);
+    // one round of workgroups (<= 4 per CU, all resident from the start): SIMD-true roles + progress priorities
+    static const int no_balance = getenv("MPPI_PC_NO_BALANCE") ? atoi(getenv("MPPI_PC_NO_BALANCE")) : 0; // A/B timing
+    const int balance = (nb <= 4 * 256 && !no_balance) ? 1 : 0;
+    if (h->sigma_diag) hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, lds, st, h->dC, x_dev, h->U_cur(), h->d_step, h->d_cost, h->d_part, 1, nb, balance);
+    else hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, lds, st, h->dC, x_dev, h->U_cur(), h->d_step, h->d_cost, h->d_part, 1, nb, balance);
     return hipGetLastError();
 }
 

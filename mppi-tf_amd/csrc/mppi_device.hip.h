@@ -53,6 +53,44 @@ struct DevConsts {
     float qfull[kMaxS * kMaxS];     // [s,s] row-major, FIXED stride kMaxS, zero padded
 };
 
+// The per-step helpers below take the constants through a template type CT: DevConsts in HBM, or a kernel-local copy
+// of just the fields a wave needs (PcProducerConsts / PcConsumerConsts). A barrier is a memory fence, so constants read
+// through a global pointer are re-fetched (s_load + s_waitcnt) after every __syncthreads; a local copy made before the
+// first barrier lives in SGPRs for the whole kernel. Same field names and indexing, same arithmetic.
+template <int A>
+struct PcProducerConsts {
+    int action_cost_kind;
+    float lambda, gamma, py_ncoef;
+    float sigma[A * kMaxA], sigma_inv[A * kMaxA]; // row i at [i*kMaxA + j], j < A
+    template <bool DIAG>
+    __device__ __forceinline__ void load(const DevConsts *__restrict__ C)
+    {
+        action_cost_kind = C->action_cost_kind;
+        lambda = C->lambda; gamma = C->gamma; py_ncoef = C->py_ncoef;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (!DIAG || i == j) {
+                    sigma[i * kMaxA + j] = C->sigma[i * kMaxA + j];
+                    sigma_inv[i * kMaxA + j] = C->sigma_inv[i * kMaxA + j];
+                }
+            }
+        }
+    }
+};
+template <int S>
+struct PcConsumerConsts {
+    float dt, bp, bq, neg_inv_lambda;
+    float goal[S], qdiag[S];
+    __device__ __forceinline__ void load(const DevConsts *__restrict__ C)
+    {
+        dt = C->dt; bp = C->bp; bq = C->bq; neg_inv_lambda = C->neg_inv_lambda;
+#pragma unroll
+        for (int i = 0; i < S; ++i) { goal[i] = C->goal[i]; qdiag[i] = C->qdiag[i]; }
+    }
+};
+
 // ----------------------------------------------------------------------------------------
 // Noise: Philox4x32-10 evaluated AT a counter through rocRAND's own engine. Equivalent to
 //   rocrand_init(seed, subsequence, 4*block, &st); rocrand_normal4(&st);
@@ -71,7 +109,7 @@ struct PhiloxAt : rocrand_device::philox4x32_10_engine {
 //   Philox block = (step*ceil(H/4) + g)*A + q , q = 0..A-1   -> 4A uniforms -> 4A normals
 //   normal m = 4q+{0,1,2,3} (Box-Muller pairs (x,y),(z,w) of block q) is z[t = 4g + m/A][j = m%A]
 // Every Philox output word is used (A blocks per 4 steps instead of 4).
-// Box-Muller exactly as rocRAND's box_muller(x, y) (rocrand_normal.h:53-68):
+// Box-Muller as rocRAND's box_muller(x, y) (rocrand_normal.h:53-68):
 //   u = 2^-32 + x·2^-32 ; v = 2π·2^-32 + y·2π·2^-32 ; (sin v, cos v)·sqrt(-2 ln u)
 // with the hardware-rate log and sqrt (v_log_f32·ln2, v_sqrt_f32; ~1 ulp) in place of libm-accurate
 // logf/sqrtf, whose range/denormal fix-ups cost ~20 of the ~35 instructions of a pair and buy nothing
@@ -79,12 +117,13 @@ struct PhiloxAt : rocrand_device::philox4x32_10_engine {
 // the fast __sincosf. -DMPPI_ROCRAND_NORMALS selects rocRAND's normal_distribution4 verbatim.
 __device__ __forceinline__ float2 box_muller_hw(unsigned int x, unsigned int y)
 {
-    const float u = ROCRAND_2POW32_INV + ((float)x * ROCRAND_2POW32_INV);
-    const float v = ROCRAND_2POW32_INV_2PI + ((float)y * ROCRAND_2POW32_INV_2PI);
-    const float s = __builtin_amdgcn_sqrtf(-2.0f * (__builtin_amdgcn_logf(u) * 0.6931471805599453f));
-    float sn, cs;
-    __sincosf(v, &sn, &cs);
-    return float2{sn * s, cs * s};
+    // u and the angle as single fused multiply-adds (within 1 ulp of the two-step form above); the angle is kept in
+    // REVOLUTIONS, which is what v_sin_f32 / v_cos_f32 take (2π·2^-32·(y+1) would only be divided by 2π again), and
+    // -2·ln2 is one constant: 13 instead of 18 instructions per pair in a VALU-issue-bound kernel.
+    const float u = __builtin_fmaf((float)x, ROCRAND_2POW32_INV, ROCRAND_2POW32_INV);
+    const float rev = __builtin_fmaf((float)y, ROCRAND_2POW32_INV, ROCRAND_2POW32_INV);
+    const float s = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u) * -1.3862943611198906f);
+    return float2{__builtin_amdgcn_sinf(rev) * s, __builtin_amdgcn_cosf(rev) * s};
 }
 
 // The Philox4x32-10 block function (Random123; constants as rocrand_philox4x32_10.h:60-65) at the counter
@@ -132,17 +171,17 @@ __device__ __forceinline__ void normals_group(unsigned long long seed, unsigned 
 // DIAG: Σ (and Σ⁻¹) are diagonal — the reference's default Σ = c·I. The dense row sum then adds
 // exact zeros (0·z_j) to ONE non-zero product, so evaluating only that product is bit-identical
 // (up to the sign of a zero) and saves 2(A²-A) operations per (k,t).
-template <int A, bool DIAG = false>
-__device__ __forceinline__ void scale_noise(const DevConsts *__restrict__ C, const float (&z)[A], float (&e)[A])
+template <int A, bool DIAG = false, class CT = DevConsts>
+__device__ __forceinline__ void scale_noise(const CT *__restrict__ C, const float (&z)[A], float (&e)[A])
 {
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         if (DIAG) {
             e[i] = C->sigma[i * kMaxA + i] * z[i];
         } else {
-            float acc = 0.0f;
+            float acc = C->sigma[i * kMaxA] * z[0]; // 0 + x is x (up to the sign of a zero): the first add is dropped
 #pragma unroll
-            for (int j = 0; j < A; ++j) acc = acc + C->sigma[i * kMaxA + j] * z[j];
+            for (int j = 1; j < A; ++j) acc = acc + C->sigma[i * kMaxA + j] * z[j];
             e[i] = acc;
         }
     }
@@ -152,8 +191,8 @@ __device__ __forceinline__ void scale_noise(const DevConsts *__restrict__ C, con
 // model_base.cpp:53-82  x' = A x + (B/m) v with A = I⊗[[1,dt],[0,1]], B = I⊗[[dt²/2],[dt]]/m.
 // The dense rows reduce to (products with the structural zeros are exact):
 //   free_p = p + dt*q ; free_q = q ; act_p = bp*v ; act_q = bq*v ; x' = free + act.
-template <int A>
-__device__ __forceinline__ void pm_free_step(const DevConsts *__restrict__ C, const float (&x)[2 * A], float (&fr)[2 * A])
+template <int A, class CT = DevConsts>
+__device__ __forceinline__ void pm_free_step(const CT *__restrict__ C, const float (&x)[2 * A], float (&fr)[2 * A])
 {
 #pragma unroll
     for (int j = 0; j < A; ++j) {
@@ -162,8 +201,8 @@ __device__ __forceinline__ void pm_free_step(const DevConsts *__restrict__ C, co
     }
 }
 
-template <int A>
-__device__ __forceinline__ void pm_action_step(const DevConsts *__restrict__ C, const float (&v)[A], float (&ac)[2 * A])
+template <int A, class CT = DevConsts>
+__device__ __forceinline__ void pm_action_step(const CT *__restrict__ C, const float (&v)[A], float (&ac)[2 * A])
 {
 #pragma unroll
     for (int j = 0; j < A; ++j) {
@@ -172,8 +211,8 @@ __device__ __forceinline__ void pm_action_step(const DevConsts *__restrict__ C, 
     }
 }
 
-template <int A>
-__device__ __forceinline__ void pm_step(const DevConsts *__restrict__ C, float (&x)[2 * A], const float (&v)[A])
+template <int A, class CT = DevConsts>
+__device__ __forceinline__ void pm_step(const CT *__restrict__ C, float (&x)[2 * A], const float (&v)[A])
 {
     float fr[2 * A], ac[2 * A];
     pm_free_step<A>(C, x, fr);
@@ -183,13 +222,13 @@ __device__ __forceinline__ void pm_step(const DevConsts *__restrict__ C, float (
 }
 
 // cost_base.cpp:56-61 mStateCost: diff = x-g ; left = Q·diff ; cost = diffᵀ·left.
-template <int S, bool QFULL>
-__device__ __forceinline__ float state_cost(const DevConsts *__restrict__ C, const float (&x)[S])
+template <int S, bool QFULL, class CT = DevConsts>
+__device__ __forceinline__ float state_cost(const CT *__restrict__ C, const float (&x)[S])
 {
     float diff[S], left[S];
 #pragma unroll
     for (int i = 0; i < S; ++i) diff[i] = x[i] - C->goal[i];
-    if (QFULL) {
+    if constexpr (QFULL) {
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             float acc = 0.0f;
@@ -201,15 +240,15 @@ __device__ __forceinline__ float state_cost(const DevConsts *__restrict__ C, con
 #pragma unroll
         for (int i = 0; i < S; ++i) left[i] = C->qdiag[i] * diff[i];
     }
-    float acc = 0.0f;
+    float acc = diff[0] * left[0];
 #pragma unroll
-    for (int i = 0; i < S; ++i) acc = acc + diff[i] * left[i];
+    for (int i = 1; i < S; ++i) acc = acc + diff[i] * left[i];
     return acc;
 }
 
 // cost_base.cpp:63-68 (C++: λ·uᵀ(Σ⁻¹ε), u = NOMINAL action) or cost_base.py:114-170 (γ/υ form).
-template <int A, bool DIAG = false>
-__device__ __forceinline__ float action_cost(const DevConsts *__restrict__ C, const float (&u)[A], const float (&e)[A])
+template <int A, bool DIAG = false, class CT = DevConsts>
+__device__ __forceinline__ float action_cost(const CT *__restrict__ C, const float (&u)[A], const float (&e)[A])
 {
     float rhsN[A];
 #pragma unroll
@@ -217,15 +256,15 @@ __device__ __forceinline__ float action_cost(const DevConsts *__restrict__ C, co
         if (DIAG) { // see scale_noise: the off-diagonal terms are exact zeros
             rhsN[i] = C->sigma_inv[i * kMaxA + i] * e[i];
         } else {
-            float acc = 0.0f;
+            float acc = C->sigma_inv[i * kMaxA] * e[0];
 #pragma unroll
-            for (int j = 0; j < A; ++j) acc = acc + C->sigma_inv[i * kMaxA + j] * e[j];
+            for (int j = 1; j < A; ++j) acc = acc + C->sigma_inv[i * kMaxA + j] * e[j];
             rhsN[i] = acc;
         }
     }
-    float mix = 0.0f;
+    float mix = u[0] * rhsN[0];
 #pragma unroll
-    for (int i = 0; i < A; ++i) mix = mix + u[i] * rhsN[i];
+    for (int i = 1; i < A; ++i) mix = mix + u[i] * rhsN[i];
     if (C->action_cost_kind == MPPI_ACTION_COST_CPP) return C->lambda * mix;
 
     float rhsA[A];
@@ -234,18 +273,18 @@ __device__ __forceinline__ float action_cost(const DevConsts *__restrict__ C, co
         if (DIAG) {
             rhsA[i] = C->sigma_inv[i * kMaxA + i] * u[i];
         } else {
-            float acc = 0.0f;
+            float acc = C->sigma_inv[i * kMaxA] * u[0];
 #pragma unroll
-            for (int j = 0; j < A; ++j) acc = acc + C->sigma_inv[i * kMaxA + j] * u[j];
+            for (int j = 1; j < A; ++j) acc = acc + C->sigma_inv[i * kMaxA + j] * u[j];
             rhsA[i] = acc;
         }
     }
     mix = 2.0f * mix;
-    float n = 0.0f, ac = 0.0f;
+    float n = e[0] * rhsN[0], ac = u[0] * rhsA[0];
 #pragma unroll
-    for (int i = 0; i < A; ++i) n = n + e[i] * rhsN[i];
+    for (int i = 1; i < A; ++i) n = n + e[i] * rhsN[i];
 #pragma unroll
-    for (int i = 0; i < A; ++i) ac = ac + u[i] * rhsA[i];
+    for (int i = 1; i < A; ++i) ac = ac + u[i] * rhsA[i];
     ac = C->gamma * ac;
     mix = C->gamma * mix;
     n = C->py_ncoef * n;

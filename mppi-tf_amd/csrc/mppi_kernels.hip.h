@@ -185,6 +185,48 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
+// -DMPPI_PC_TIMELINE (tools/timeline.py, timing study only): every wave stamps s_memrealtime (100 MHz) at its
+// phase boundaries into LDS and the consumer dumps the 64 stamps in place of the tile's costs.
+#if defined(MPPI_PC_TIMELINE)
+__device__ __forceinline__ unsigned long long pc_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define MPPI_STAMP_RT(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); if (lane == 0) tl_s[(slot)] = (float)(t_ & 0xFFFFFFull); } while (0)
+#define MPPI_STAMP(slot) do { const unsigned long long t_ = pc_stamp(); if (lane == 0) tl_s[(slot)] = (float)(t_ & 0xFFFFFFull); } while (0)
+#else
+#define MPPI_STAMP_RT(slot) do { } while (0)
+#define MPPI_STAMP(slot) do { } while (0)
+#endif
+
+// Wave priority by progress (s_setprio): the SIMD arbiter favours the oldest wave, so the workgroups sharing a CU
+// finish one after the other and the last one runs alone, latency-bound. Lowering a wave's priority as it advances
+// lets the ones behind catch up, so that all of them finish together. Only when the whole grid is resident at once
+// (`balance`, at most 4 workgroups per CU): with several rounds of workgroups the age order staggers their phases,
+// which is what keeps the SIMDs busy there (K=2^20: 224 us without, 244 us with priorities).
+// virtual progress = chunk index + a head start of 3/4 chunk per generation of age (the arbiter still breaks ties
+// by age inside one level): level = 3 - floor(4*(i + 3(3-gen)/4)/n), gen = blockIdx/256 = arrival order on the CU.
+// Measured at K=65536, H=64 (tools/timeline.py): workgroup end times 10.5 .. 19.4 us after the first start without,
+// 13.2 .. 15.3 us with; kernel 21.9 -> 19.2 us together with the SIMD-true role placement below.
+#if !defined(MPPI_PC_PRIO_BIAS)
+#define MPPI_PC_PRIO_BIAS 3
+#endif
+__device__ __forceinline__ void pc_set_prio(int i, int n, int gen)
+{
+    const int bias = MPPI_PC_PRIO_BIAS * (3 - min(gen, 3)); // quarter chunks
+    const int lvl = 3 - min(3, (16 * i + 4 * bias) / (4 * n));
+    switch (lvl) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 // NP producers + 1 consumer = NP+1 wavefronts per workgroup; a chunk = one horizon group (4 steps)
 // from every producer = 4·NP steps; two chunk buffers of (A+1) floats per (step, lane).
 __host__ __device__ inline size_t pc_lds_floats(int A, int NP) { return (size_t)2 * 4 * NP * (A + 1) * 64; }
@@ -193,7 +235,7 @@ template <int A, int NP, int NSLOT, bool DIAG>
 __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) void k_rollout_pc(
     const DevConsts *__restrict__ C, const float *__restrict__ x_dev, const float *__restrict__ U_dev,
     const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
-    const int rsb, const int rsc)
+    const int rsb, const int rsc, const int balance)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 2 * A;
@@ -208,18 +250,42 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
     const int nch = (NG + NP - 1) / NP;       // chunks
     float *buf = smem;                        // [2][CS][(A+1)][64]
     float *w_s = smem;                        // [64] weights: reuses buffer 0 once every chunk is consumed
+#if defined(MPPI_PC_TIMELINE)
+    __shared__ float tl_s[64];
+    if (threadIdx.x < 64) tl_s[threadIdx.x] = 0.0f;
+    __syncthreads();
+#endif
 
     const int tid = threadIdx.x;
-    // Role rotation: a workgroup's waves are spread over the CU's 4 SIMDs, and the 4 workgroups that
-    // share a CU (observed dispatch: block b -> XCD b%8, CU (b/8)%32, so they differ in b/256) would
-    // otherwise put their light consumer wave on the same SIMD. Rotating the consumer by b/256 spreads
-    // consumers over the SIMDs. Placement only affects speed, never results.
+    // Role placement. A workgroup's waves are spread over the CU's 4 SIMDs and the 4 workgroups that share a CU
+    // (observed dispatch: block b -> XCD b%8, then a CU of it; blocks b, b+256, b+512, b+768 meet on one CU) should
+    // put their light consumer wave on 4 DIFFERENT SIMDs, so that every SIMD runs 1 consumer + NP producers. The
+    // hardware rotates the SIMD order of successive workgroups itself (measured with HW_ID: consumers chosen by wave
+    // index landed 2+2+0+0), so with one wave per SIMD the role comes from the SIMD id the wave actually runs on:
+    // consumer = the wave on SIMD gen%4 (gen = b/256). Falls back to the wave index when the 4 waves are not on 4
+    // distinct SIMDs, and for grids of several rounds (no fixed set of co-resident workgroups there).
+    // Placement only affects speed, never results.
     const int wave_hw = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = (wave_hw + NW - (int)((blockIdx.x >> 8) % NW)) % NW; // SGPR: scalar branches, scalar loads of U
+    const int gen = (int)(blockIdx.x >> 8);
+    int wave = (wave_hw + NW - gen % NW) % NW; // SGPR: scalar branches, scalar loads of U
+    if (NW == 4 && balance) {
+        __shared__ int simd_s[4];
+        const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); // HW_REG_HW_ID[5:4]
+        if ((tid & 63) == 0) simd_s[wave_hw] = simd;
+        __syncthreads();
+        const int s0 = simd_s[0], s1 = simd_s[1], s2 = simd_s[2], s3 = simd_s[3];
+        if (((1 << s0) | (1 << s1) | (1 << s2) | (1 << s3)) == 15) wave = (simd + 4 - (gen & 3)) & 3;
+        wave = __builtin_amdgcn_readfirstlane(wave);
+    }
     const int lane = tid & 63;
     const int k0 = blockIdx.x * 64;
     const bool valid = (k0 + lane) < K;
     float *rec = partials + (size_t)blockIdx.x * rsb; // element (b, col) at partials[b*rsb + col*rsc]
+#if defined(MPPI_PC_TIMELINE)
+    if (lane == 0) { // where this wave runs: HW_ID[15:0] (wave, simd, pipe, cu, sh, se) and XCC_ID[3:0]; role in slot
+        tl_s[48 + wave] = (float)(__builtin_amdgcn_s_getreg((15 << 11) | 4) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16));
+    }
+#endif
 
     if (wave != 0) {
         // ------------------------------------------------------------------ producers
@@ -228,12 +294,26 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
         const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
         const unsigned long long seed = C->seed;
         float eps_r[NREG];
+        PcProducerConsts<A> pcst; // SGPR-resident copy: no constant re-fetch after the barriers
+        pcst.template load<DIAG>(C);
+        const PcProducerConsts<A> *PC = &pcst;
+        MPPI_STAMP(16 + 10 * p + 9);
         static_for<0, NSLOT>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int g = NP * i + p;
+            if (balance) pc_set_prio(i, nch, gen);
             if (i < nch) { // chunk i exists (wave-uniform)
                 float *cb = buf + (i & 1) * CH + (size_t)(4 * p) * (A + 1) * 64;
                 if (g < NG) {
+                    // the nominal actions of the group's 4 steps: scalar loads issued ahead of the Philox rounds that
+                    // hide them (mPrepareAction controller_base.cpp:205-208); steps past the horizon are never consumed
+                    float ug[4][A];
+#pragma unroll
+                    for (int tl = 0; tl < 4; ++tl) {
+                        const int tt = min(4 * g + tl, H - 1);
+#pragma unroll
+                        for (int j = 0; j < A; ++j) ug[tl][j] = U_dev[tt * A + j];
+                    }
                     float z[4 * A];
 #if defined(MPPI_ABLATE_PHILOX)
 #pragma unroll
@@ -247,17 +327,19 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
                         float zz[A], e[A], u[A];
 #pragma unroll
                         for (int j = 0; j < A; ++j) zz[j] = z[tl * A + j];
-                        scale_noise<A, DIAG>(C, zz, e);
-                        const int tt = t < H ? t : H - 1; // steps past the horizon are never consumed
+                        scale_noise<A, DIAG>(PC, zz, e);
 #pragma unroll
                         for (int j = 0; j < A; ++j) {
-                            u[j] = U_dev[tt * A + j];                // mPrepareAction controller_base.cpp:205-208 (scalar load)
+                            u[j] = ug[tl][j];
+                            // (the select costs 1 instruction but saves 20 VGPRs: hipcc keeps 94 instead of 114 live, which
+                            //  is the 5th resident workgroup per CU for grids of several rounds)
                             eps_r[(i * 4 + tl) * A + j] = t < H ? e[j] : 0.0f;
                             cb[(tl * (A + 1) + j) * 64 + lane] = u[j] + e[j]; // to_apply, :258
                         }
-                        cb[(tl * (A + 1) + A) * 64 + lane] = action_cost<A, DIAG>(C, u, e);
+                        cb[(tl * (A + 1) + A) * 64 + lane] = action_cost<A, DIAG>(PC, u, e);
                     }
                 }
+                MPPI_STAMP(16 + 10 * p + (i < 7 ? i : 6));
                 __syncthreads(); // chunk i published
             }
             if (!(i < nch && g < NG)) {
@@ -266,6 +348,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
             }
         });
         __syncthreads(); // weights published by the consumer
+        MPPI_STAMP(16 + 10 * p + 7);
         // phase C from registers: V_b[t,j] = Σ_k e_k·eps[k,t,j]  (mWeightedNoise, controller_base.cpp:188-192)
         const float w = w_s[lane];
 #pragma unroll
@@ -286,14 +369,22 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
             const int t = 4 * (NP * i + p) + tl;
             if (n < NREG && t < H) rec[(size_t)(2 + t * A + j) * rsc] = tot[m];
         }
+        MPPI_STAMP(16 + 10 * p + 8);
     } else {
         // ------------------------------------------------------------------ consumer
         float x[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+        PcConsumerConsts<S> ccst;
+        ccst.load(C);
+        const PcConsumerConsts<S> *CC = &ccst;
         float c = 0.0f;
+        MPPI_STAMP(0);
+        MPPI_STAMP_RT(62);
         __syncthreads(); // chunk 0 published
+        MPPI_STAMP(1);
         for (int ch = 0; ch < nch; ++ch) {
+            if (balance) pc_set_prio(ch, nch, gen);
             const float *cb = buf + (ch & 1) * CH;
             const int tend = min(CS, H - ch * CS);
 #if defined(MPPI_ABLATE_ROLLOUT)
@@ -305,25 +396,41 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
 #pragma unroll
                 for (int j = 0; j < A; ++j) v[j] = cb[(tl * (A + 1) + j) * 64 + lane];
                 const float ac = cb[(tl * (A + 1) + A) * 64 + lane];
-                pm_step<A>(C, x, v);
-                const float sc = state_cost<S, false>(C, x); // cost on the POST-step state
+                pm_step<A>(CC, x, v);
+                const float sc = state_cost<S, false>(CC, x); // cost on the POST-step state
                 const float tmp = sc + ac;                    // Step_cost_result cost_base.cpp:49
                 c = c + tmp;                                  // path_cost        controller_base.cpp:268
             }
             // barrier budget: producers run nch (one per chunk) + 1 (weights); the consumer 1 + (nch-1) + 1.
             // After the last chunk nothing is published any more: the producers already sit at the weights barrier.
+            MPPI_STAMP(2 + (ch < 7 ? ch : 6));
             if (ch + 1 < nch) __syncthreads(); // chunk ch consumed / chunk ch+1 published
         }
-        c = c + state_cost<S, false>(C, x); // terminal: x_H counted a second time, :271-272
+        c = c + state_cost<S, false>(CC, x); // terminal: x_H counted a second time, :271-272
+#if !defined(MPPI_PC_TIMELINE)
         if (valid) cost[k0 + lane] = c;
+#endif
         // tile-local mBeta / mExpArg / mExp / mNabla (controller_base.cpp:166-182)
         const float beta = wave_min(valid ? c : INFINITY);
-        const float arg = C->neg_inv_lambda * (c - beta);
+        const float arg = CC->neg_inv_lambda * (c - beta);
         const float ek = valid ? expf(arg) : 0.0f;
         const float eta = wave_sum(ek);
         w_s[lane] = ek;
         if (lane == 0) { rec[0] = beta; rec[(size_t)rsc] = eta; }
+        MPPI_STAMP(9);
+        MPPI_STAMP_RT(63);
         __syncthreads(); // weights published
+#if defined(MPPI_PC_TIMELINE)
+        __builtin_amdgcn_s_sleep(127); // let the producers finish and stamp (a few hundred cycles), then dump
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+        if (valid) cost[k0 + lane] = tl_s[lane];
+#endif
     }
 }
 
