@@ -59,6 +59,14 @@ public:
     }
     void saveNext(std::vector<float> x_next) { mppi_detail::check(mppi_save_next(m_h, x_next.data(), (int)x_next.size()), m_h, "mppi_save_next"); }
     void toCSV(std::string filename) { mppi_detail::check(mppi_to_csv(m_h, filename.c_str()), m_h, "mppi_to_csv"); }
+    // Options of the Python reference's update, not in the C++ one: clip_act (controller_base.py:500-504) and the
+    // Savitzky-Golay filterSeq (controller_base.py:277-291). Empty vectors / window 0 switch them off.
+    void setActionLimits(const std::vector<float> &a_min, const std::vector<float> &a_max)
+    {
+        mppi_detail::check(mppi_set_action_limits(m_h, a_min.empty() ? nullptr : a_min.data(), a_max.empty() ? nullptr : a_max.data(),
+                                                  (int)a_min.size()), m_h, "mppi_set_action_limits");
+    }
+    void setSequenceFilter(int window, int polyorder) { mppi_detail::check(mppi_set_sequence_filter(m_h, window, polyorder), m_h, "mppi_set_sequence_filter"); }
 
     // mBeta … mWeightedNoise + mBuildUpdateGraph (controller_base.cpp:166-192, 215-224), fused on the device
     struct UpdateTerms {

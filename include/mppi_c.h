@@ -134,6 +134,20 @@ mppi_status mppi_next_with_noise(mppi_handle *h, const float *x, int n_x, const 
 mppi_status mppi_save_next(mppi_handle *h, const float *x_next, int n);
 mppi_status mppi_to_csv(mppi_handle *h, const char *filename);
 
+/* ---- options of the Python reference's update ------------------------- */
+/* clip_act (controller_base.py:500-504; the call at :453 is commented out in the reference, so off
+ * by default): clamp every row of the updated sequence U' = U + Σ w·eps to [a_min[j], a_max[j]]
+ * (the model's min_act()/max_act(), model_base.py:121-125) before u = U'[0] is taken.
+ * n must equal a_dim; a_min = a_max = NULL switches it off. */
+mppi_status mppi_set_action_limits(mppi_handle *h, const float *a_min, const float *a_max, int n);
+/* filterSeq (controller_base.py:277-291): scipy.signal.savgol_filter(actionSeq, window, polyorder,
+ * deriv=0, axis=0) [mode 'interp'] on the stored (shifted) sequence after every step; the smoothed
+ * sequence is the next step's warm start (the reference computes it into an attribute it never
+ * reads). window odd, 1 <= window <= tau, 0 <= polyorder < window; window = 0 switches it off
+ * (default). The reference's literals (10, 9) have an even window, which 'interp' mode does not
+ * define uniquely; they are rejected. */
+mppi_status mppi_set_sequence_filter(mppi_handle *h, int window, int polyorder);
+
 /* ---- controller state (deterministic replay; SURVEY §5 checkpoint row) ------------------ */
 mppi_status mppi_get_action_sequence(mppi_handle *h, float *U, int n);        /* n = tau*a */
 mppi_status mppi_set_action_sequence(mppi_handle *h, const float *U, int n);
@@ -175,7 +189,8 @@ int mppi_sample_offset(const mppi_handle *h);
 /* One whole step, enqueue only: x_dev[s] -> u_dev[a]; U and the step counter advance on the
  * device. Unsharded handles only. The nominal sequence alternates between two device buffers from
  * one call to the next (the shift is a pointer offset), so a captured hipGraph must hold an EVEN
- * number of consecutive steps to be replayable. */
+ * number of consecutive steps to be replayable (any number with a sequence filter set: the filter
+ * writes back into the first buffer). */
 mppi_status mppi_next_device(mppi_handle *h, const float *x_dev, float *u_dev, void *stream);
 /* Sharded step, phase 1: rollouts + local soft-min of this shard -> record_dev[record_size]. */
 mppi_status mppi_shard_partial(mppi_handle *h, const float *x_dev, float *record_dev, void *stream);

@@ -82,6 +82,8 @@ SIGNATURES = {
     "mppi_shard_partial": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mppi_shard_finish": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mppi_synchronize": (C.c_int, [_H]),
+    "mppi_set_action_limits": (C.c_int, [_H, FP, FP, C.c_int]),
+    "mppi_set_sequence_filter": (C.c_int, [_H, C.c_int, C.c_int]),
     "mppi_shard_p2p_export": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mppi_shard_p2p_open": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mppi_shard_p2p_attach": (C.c_int, [_H, C.POINTER(C.c_void_p), C.c_int, C.c_int]),
@@ -305,6 +307,19 @@ class Handle:
 
     def shard_finish(self, records_ptr, n_records, u_ptr, stream=0):
         self._check(self.lib.mppi_shard_finish(self.h, records_ptr, n_records, u_ptr, stream))
+
+    # ---- options of the Python reference's update ---------------------------------------------
+    def set_action_limits(self, a_min=None, a_max=None):
+        """clip_act (controller_base.py:500-504): clamp U' rows to [a_min, a_max]; None, None = off"""
+        if a_min is None and a_max is None:
+            self._check(self.lib.mppi_set_action_limits(self.h, None, None, 0))
+            return
+        lo, hi = f32(a_min, (self.a,)), f32(a_max, (self.a,))
+        self._check(self.lib.mppi_set_action_limits(self.h, fp(lo), fp(hi), self.a))
+
+    def set_sequence_filter(self, window, polyorder=3):
+        """filterSeq (controller_base.py:277-291): Savitzky-Golay smoothing of the stored sequence; window 0 = off"""
+        self._check(self.lib.mppi_set_sequence_filter(self.h, int(window), int(polyorder)))
 
     # ---- direct record exchange (mppi_shard_p2p_*, include/mppi_c.h) -------------------------
     def p2p_export(self, want_ipc=True):

@@ -201,6 +201,17 @@ class ControllerBase:
             if initSeq.shape != (tau, aDim, 1):
                 raise AssertionError
             self._h.set_action_sequence(initSeq[..., 0])
+        # filterSeq (controller_base.py:277-291). The reference's literals are savgol_filter(seq, 10, 9): an even
+        # window ('interp' mode does not define it uniquely) whose result it never reads; here filterSeq=True means
+        # the neighbouring odd window (11, 9) when the horizon allows it, or filterSeq=(window, polyorder).
+        if filterSeq:
+            w, p = filterSeq if isinstance(filterSeq, (tuple, list)) else (11, 9)
+            self._h.set_sequence_filter(w, p)
+        # clip_act (controller_base.py:500-504): the model's action limits, if it has any
+        lo = getattr(model, "_actMin", None)
+        hi = getattr(model, "_actMax", None)
+        if lo is not None and hi is not None:
+            self._h.set_action_limits(np.asarray(lo, np.float32).reshape(-1), np.asarray(hi, np.float32).reshape(-1))
         self._timingDict = {"total": 0., "calls": 0}
         self._steps = 0
 

@@ -41,7 +41,13 @@ struct mppi_handle {
     int u_cur = 0, u_off = 0;
     float *U_cur() const { return d_Ubuf[u_cur] + u_off; }
     float *U_other() const { return d_Ubuf[1 - u_cur]; }
-    void U_advance() { u_cur = 1 - u_cur; u_off = a; }
+    float *d_Uupd = nullptr; // U' of the last step (MPPI_DBG_U_UPDATED)
+    void U_advance() { u_cur = 1 - u_cur; u_off = a; d_Uupd = d_Ubuf[u_cur]; }
+    // options of the Python reference's update: clip_act limits [a_min | a_max] and the Savitzky-Golay filter
+    float *d_clip = nullptr;
+    int sg_window = 0;
+    float *d_sg_rows = nullptr;
+    int *d_sg_start = nullptr;
     float *d_part = nullptr, *d_part2 = nullptr, *d_part3 = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_mm = nullptr;
     float *d_eps = nullptr; // lazily allocated [K_local, H, a] for injected noise / debug export
     unsigned long long *d_step = nullptr;
@@ -175,6 +181,9 @@ extern "C" void mppi_destroy(mppi_handle *h)
     if (h->d_mlp_w) (void)hipFree(h->d_mlp_w);
     if (h->dC) (void)hipFree(h->dC);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->d_clip) (void)hipFree(h->d_clip);
+    if (h->d_sg_rows) (void)hipFree(h->d_sg_rows);
+    if (h->d_sg_start) (void)hipFree(h->d_sg_start);
     for (void *p : h->xchg_opened) (void)hipIpcCloseMemHandle(p);
     if (h->xchg_inbox) (void)hipFree(h->xchg_inbox);
     if (h->h_xchg_status) (void)hipHostFree(h->h_xchg_status);
@@ -496,13 +505,121 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
     if (xchg)
         hipLaunchKernelGGL(k_finish_cols_xchg, dim3(h->HA), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
                            U_in, U_out, u_out, h->d_step, h->d_dbg, h->xchg_peers, h->shard_count, h->shard_rank, ++h->xchg_seq,
-                           h->xchg_timeout_ticks, h->d_xchg_status);
+                           h->xchg_timeout_ticks, h->d_xchg_status, h->d_clip);
     else
         hipLaunchKernelGGL(k_finish_cols, dim3(h->HA), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
-                           U_in, U_out, u_out, record_out, apply, h->d_step, h->d_dbg);
+                           U_in, U_out, u_out, record_out, apply, h->d_step, h->d_dbg, h->d_clip);
     hipError_t e = hipGetLastError();
     if (prof && e == hipSuccess) { e = hipEventRecord(h->ev[4 * h->prof_n + 3], st); h->prof_stream = st; h->prof_n++; }
     return e;
+}
+
+// After the update: the shifted sequence becomes the warm start (a pointer offset), then the optional
+// Savitzky-Golay smoothing (filterSeq) writes the filtered sequence into the other buffer.
+static hipError_t advance_sequence(mppi_handle *h, hipStream_t st)
+{
+    h->U_advance();
+    if (h->sg_window > 0) {
+        hipLaunchKernelGGL(k_savgol, dim3((h->HA + 255) / 256), dim3(256), 0, st, h->U_cur(), h->U_other(), h->d_sg_rows,
+                           h->d_sg_start, h->H, h->a, h->sg_window);
+        h->u_cur = 1 - h->u_cur;
+        h->u_off = 0;
+    }
+    return hipGetLastError();
+}
+
+// Savitzky-Golay weights (scipy.signal.savgol_filter, deriv=0, mode='interp'): for row t the window starts at
+// s = clamp(t-h, 0, H-w) and the fitted polynomial is evaluated at x0 = t-(s+h): weights = e(x0)ᵀ(AᵀA)⁻¹Aᵀ with
+// A[i][k] = ((i-h)/h')^k. Normal equations in long double with abscissae scaled to [-1,1], partial pivoting.
+static bool savgol_rows(int H, int w, int p, std::vector<float> &rows, std::vector<int> &start)
+{
+    const int hw = w / 2, n = p + 1;
+    const long double sc = hw > 0 ? (long double)hw : 1.0L;
+    rows.assign((size_t)H * w, 0.f);
+    start.assign(H, 0);
+    std::vector<long double> A((size_t)w * n);
+    for (int i = 0; i < w; ++i) {
+        long double v = 1.0L;
+        for (int k = 0; k < n; ++k) { A[(size_t)i * n + k] = v; v *= (long double)(i - hw) / sc; }
+    }
+    std::vector<long double> N((size_t)n * n);
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) {
+            long double acc = 0.0L;
+            for (int i = 0; i < w; ++i) acc += A[(size_t)i * n + r] * A[(size_t)i * n + c];
+            N[(size_t)r * n + c] = acc;
+        }
+    for (int t = 0; t < H; ++t) {
+        const int s0 = std::min(std::max(t - hw, 0), H - w);
+        start[t] = s0;
+        const long double x0 = (long double)(t - (s0 + hw)) / sc;
+        std::vector<long double> M(N), y(n);
+        long double v = 1.0L;
+        for (int k = 0; k < n; ++k) { y[k] = v; v *= x0; }
+        for (int c = 0; c < n; ++c) { // Gaussian elimination, partial pivoting
+            int piv = c;
+            for (int r = c + 1; r < n; ++r) if (fabsl(M[(size_t)r * n + c]) > fabsl(M[(size_t)piv * n + c])) piv = r;
+            if (fabsl(M[(size_t)piv * n + c]) < 1e-300L) return false;
+            if (piv != c) { for (int k = 0; k < n; ++k) std::swap(M[(size_t)piv * n + k], M[(size_t)c * n + k]); std::swap(y[piv], y[c]); }
+            for (int r = c + 1; r < n; ++r) {
+                const long double f = M[(size_t)r * n + c] / M[(size_t)c * n + c];
+                for (int k = c; k < n; ++k) M[(size_t)r * n + k] -= f * M[(size_t)c * n + k];
+                y[r] -= f * y[c];
+            }
+        }
+        for (int r = n - 1; r >= 0; --r) {
+            long double acc = y[r];
+            for (int k = r + 1; k < n; ++k) acc -= M[(size_t)r * n + k] * y[k];
+            y[r] = acc / M[(size_t)r * n + r];
+        }
+        for (int i = 0; i < w; ++i) {
+            long double acc = 0.0L;
+            for (int k = 0; k < n; ++k) acc += A[(size_t)i * n + k] * y[k];
+            rows[(size_t)t * w + i] = (float)acc;
+        }
+    }
+    return true;
+}
+
+extern "C" mppi_status mppi_set_action_limits(mppi_handle *h, const float *a_min, const float *a_max, int n)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!a_min && !a_max) {
+        if (h->d_clip) { HIP_TRY(h, hipDeviceSynchronize()); HIP_TRY(h, hipFree(h->d_clip)); h->d_clip = nullptr; }
+        return MPPI_OK;
+    }
+    if (!a_min || !a_max || n != h->a) return fail(h, MPPI_ERR_INVALID_ARG, "a_min and a_max must both have a_dim floats");
+    std::vector<float> lim(2 * (size_t)n);
+    for (int j = 0; j < n; ++j) {
+        if (!(a_min[j] <= a_max[j])) return fail(h, MPPI_ERR_INVALID_ARG, "a_min must be <= a_max");
+        lim[j] = a_min[j]; lim[n + j] = a_max[j];
+    }
+    if (!h->d_clip) HIP_TRY(h, hipMalloc((void **)&h->d_clip, sizeof(float) * 2 * n));
+    HIP_TRY(h, hipMemcpy(h->d_clip, lim.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_set_sequence_filter(mppi_handle *h, int window, int polyorder)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (window == 0) { h->sg_window = 0; return MPPI_OK; }
+    if (window < 1 || (window & 1) == 0 || window > h->H || polyorder < 0 || polyorder >= window)
+        return fail(h, MPPI_ERR_INVALID_ARG, "filter window must be odd and <= tau, 0 <= polyorder < window");
+    std::vector<float> rows;
+    std::vector<int> start;
+    if (!savgol_rows(h->H, window, polyorder, rows, start)) return fail(h, MPPI_ERR_INVALID_ARG, "singular Savitzky-Golay system");
+    if (h->d_sg_rows) { HIP_TRY(h, hipFree(h->d_sg_rows)); h->d_sg_rows = nullptr; }
+    if (h->d_sg_start) { HIP_TRY(h, hipFree(h->d_sg_start)); h->d_sg_start = nullptr; }
+    HIP_TRY(h, hipMalloc((void **)&h->d_sg_rows, sizeof(float) * rows.size()));
+    HIP_TRY(h, hipMalloc((void **)&h->d_sg_start, sizeof(int) * start.size()));
+    HIP_TRY(h, hipMemcpy(h->d_sg_rows, rows.data(), sizeof(float) * rows.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_sg_start, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
+    h->sg_window = window;
+    return MPPI_OK;
 }
 
 // rollouts of this shard -> partial records in d_part; *nrec = how many. Handles normalizeCost.
@@ -609,7 +726,7 @@ extern "C" mppi_status mppi_next_device(mppi_handle *h, const float *x_dev, floa
     mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr, &nrec);
     if (s != MPPI_OK) return s;
     HIP_TRY(h, launch_finish(h, st, h->d_part, 1, nrec, nrec, h->U_cur(), h->U_other(), u_dev, nullptr, 1));
-    h->U_advance();
+    HIP_TRY(h, advance_sequence(h, st));
     return MPPI_OK;
 }
 
@@ -631,7 +748,7 @@ extern "C" mppi_status mppi_shard_finish(mppi_handle *h, const float *records_de
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     HIP_TRY(h, launch_finish(h, st, records_dev, 2 + h->HA, 1, n_records, h->U_cur(), h->U_other(), u_dev, nullptr, 1));
-    h->U_advance();
+    HIP_TRY(h, advance_sequence(h, st));
     return MPPI_OK;
 }
 
@@ -721,7 +838,7 @@ extern "C" mppi_status mppi_shard_p2p_step(mppi_handle *h, const float *x_dev, f
     mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr, &nrec);
     if (s != MPPI_OK) return s;
     HIP_TRY(h, launch_finish(h, st, h->d_part, 1, nrec, nrec, h->U_cur(), h->U_other(), u_dev, nullptr, 1, true));
-    h->U_advance();
+    HIP_TRY(h, advance_sequence(h, st));
     return MPPI_OK;
 }
 
@@ -757,7 +874,7 @@ static mppi_status step_host(mppi_handle *h, const float *x, int n_x, const floa
     mppi_status s = enqueue_partials(h, h->stream, src, x_arg, h->d_eps, nullptr, &nrec);
     if (s != MPPI_OK) return s;
     HIP_TRY(h, launch_finish(h, h->stream, h->d_part, 1, nrec, nrec, h->U_cur(), h->U_other(), u_arg, nullptr, 1));
-    h->U_advance();
+    HIP_TRY(h, advance_sequence(h, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::memcpy(u_out, h->h_pin + 2 * kMaxS, sizeof(float) * h->a);
     // m_db.addX(s); m_db.addU(out_tensor[1])  controller_base.cpp:146-147
@@ -821,7 +938,7 @@ extern "C" mppi_status mppi_set_action_sequence(mppi_handle *h, const float *U, 
     if (!U || n != h->HA) return fail(h, MPPI_ERR_INVALID_ARG, "U must hold tau*a floats");
     HIP_TRY(h, hipSetDevice(h->device));
     for (int i = 0; i < 2; ++i) HIP_TRY(h, hipMemsetAsync(h->d_Ubuf[i], 0, sizeof(float) * (h->HA + h->a), h->stream)); // zero tails
-    h->u_cur = 0; h->u_off = 0;
+    h->u_cur = 0; h->u_off = 0; h->d_Uupd = nullptr;
     HIP_TRY(h, hipMemcpyAsync(h->d_Ubuf[0], U, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MPPI_OK;
@@ -861,8 +978,8 @@ extern "C" mppi_status mppi_debug_get(mppi_handle *h, int what, float *out, size
     case MPPI_DBG_BETA: src = h->d_dbg; need = 1; break;
     case MPPI_DBG_ETA: src = h->d_dbg + 1; need = 1; break;
     case MPPI_DBG_U_UPDATED: // U' of the last step = the current buffer from offset 0 (the warm start reads it from offset a)
-        if (h->u_off == 0) return fail(h, MPPI_ERR_INVALID_ARG, "no step has run since the action sequence was set");
-        src = h->d_Ubuf[h->u_cur]; need = (size_t)h->HA; break;
+        if (!h->d_Uupd) return fail(h, MPPI_ERR_INVALID_ARG, "no step has run since the action sequence was set");
+        src = h->d_Uupd; need = (size_t)h->HA; break;
     case MPPI_DBG_WEIGHTS: {
         need = K;
         if (n != need) return fail(h, MPPI_ERR_INVALID_ARG, "wrong output size");

@@ -548,13 +548,16 @@ __device__ __forceinline__ void column_combine(Load ld, int nb, float neg_inv_la
 __global__ __launch_bounds__(kThreads) void k_finish_cols(
     const float *__restrict__ recs, int sb, int sc, int nb, int HA, int a, float neg_inv_lambda,
     const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
-    float *__restrict__ record_out, int apply, unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg)
+    float *__restrict__ record_out, int apply, unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg,
+    const float *__restrict__ clip)
 {
     __shared__ float red_f[kThreads / 64];
     __shared__ double red_d[2][kThreads / 64];
     const int c = blockIdx.x, tid = threadIdx.x;
     const float u_old = U_in[c];
     const unsigned long long step_old = step_ctr[0];
+    float lo = -INFINITY, hi = INFINITY; // clip_act (controller_base.py:500-504): [a_min | a_max], NULL = off
+    if (clip != nullptr) { lo = clip[c % a]; hi = clip[a + c % a]; }
     float beta;
     double eta, V;
     column_combine([&](int b, int j) { return recs[(size_t)b * sb + (size_t)(j == 2 ? 2 + c : j) * sc]; },
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols(
         }
         if (c == 0 && dbg != nullptr) { dbg[0] = beta; dbg[1] = (float)eta; }
         if (apply) {
-            const float un = u_old + (float)(V / eta);
+            const float un = fminf(fmaxf(u_old + (float)(V / eta), lo), hi);
             U_out[c] = un;            // U' ; the next step reads U_out + a (the shifted sequence)
             if (c < a) u_out[c] = un; // mGetNew
             if (c == 0) step_ctr[0] = step_old + 1ull;
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols_xchg(
     const float *__restrict__ recs, int sb, int sc, int nb, int HA, int a, float neg_inv_lambda,
     const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
     unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg,
-    XchgPeers peers, int G, int rank, unsigned seq, long long timeout_ticks, unsigned *status)
+    XchgPeers peers, int G, int rank, unsigned seq, long long timeout_ticks, unsigned *status, const float *__restrict__ clip)
 {
     __shared__ float red_f[kThreads / 64];
     __shared__ double red_d[2][kThreads / 64];
@@ -617,6 +620,8 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols_xchg(
     const int c = blockIdx.x, tid = threadIdx.x;
     const float u_old = U_in[c];
     const unsigned long long step_old = step_ctr[0];
+    float lo = -INFINITY, hi = INFINITY;
+    if (clip != nullptr) { lo = clip[c % a]; hi = clip[a + c % a]; }
     float beta;
     double eta, V;
     column_combine([&](int b, int j) { return recs[(size_t)b * sb + (size_t)(j == 2 ? 2 + c : j) * sc]; },
@@ -635,11 +640,27 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols_xchg(
     column_combine([&](int b, int j) { return theirs[j][b]; }, G, neg_inv_lambda, red_f, red_d, beta, eta, V);
     if (tid == 0) {
         if (c == 0 && dbg != nullptr) { dbg[0] = beta; dbg[1] = (float)eta; }
-        const float un = u_old + (float)(V / eta);
+        const float un = fminf(fmaxf(u_old + (float)(V / eta), lo), hi);
         U_out[c] = un;
         if (c < a) u_out[c] = un;
         if (c == 0) step_ctr[0] = step_old + 1ull;
     }
+}
+
+// k_savgol: filterSeq (controller_base.py:277-291): out[t,j] = Σ_i rows[t,i]·in[start[t]+i, j]. rows holds, for
+// every t, the `window` Savitzky-Golay weights that evaluate the least-squares polynomial of the window starting at
+// start[t] at position t (centre for interior rows, off-centre for the 'interp' edges); built on the host in fp64.
+__global__ void k_savgol(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ rows,
+                         const int *__restrict__ start, int H, int a, int window)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * a) return;
+    const int t = idx / a, j = idx - t * a;
+    const float *r = rows + (size_t)t * window;
+    const float *src = in + (size_t)start[t] * a + j;
+    double acc = 0.0;
+    for (int i = 0; i < window; ++i) acc += (double)r[i] * (double)src[(size_t)i * a];
+    out[idx] = (float)acc;
 }
 
 // k_xchg_probe: the exchange's self-test, run once after the inboxes are attached and before the first step: the

@@ -691,3 +691,60 @@ def test_direct_exchange_across_processes_over_hipipc():
                        timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("P2P_WORKER_OK") == 2, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+# =============================================================== options of the Python update
+def test_action_limits_clip_the_updated_sequence(m):
+    """clip_act (controller_base.py:500-504): U' = clip(U + Σ w eps, a_min, a_max) row-wise, u = U'[0]."""
+    K, H, a = 512, 10, 2
+    h, p = make_pair(m, K, H, a, seed=4)
+    lo, hi = np.array([-0.05, -0.3], F32), np.array([0.1, 0.02], F32)
+    h.set_action_limits(lo, hi)
+    x = np.array([0.3, 0.0, -0.2, 0.1], F32)
+    U = np.zeros((H, a), F32)
+    for step in range(3):
+        u = h.next(x)
+        eps = h.debug_get(m.DBG_NOISE)
+        u_ref, U_sh, _ = p.next_with_noise(x, U, eps)  # unclipped update of the same U and noise
+        ref = {"U_new": np.concatenate([u_ref.reshape(1, a), U_sh[:-1]])}
+        Uc = np.clip(ref["U_new"].astype(F32), lo, hi)
+        np.testing.assert_allclose(h.debug_get(m.DBG_U_UPDATED), Uc, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(u, Uc[0], rtol=0, atol=2e-6)
+        U = h.get_action_sequence()
+        np.testing.assert_allclose(U[:-1], h.debug_get(m.DBG_U_UPDATED)[1:], rtol=0, atol=0)
+        assert (U >= lo - 1e-7).all() and (U <= hi + 1e-7).all()
+    assert (np.abs(ref["U_new"]) > np.maximum(np.abs(lo), np.abs(hi))).any(), "the limits never bound: weak test"
+    h.set_action_limits(None, None)
+    h.next(x)
+    with pytest.raises(m.MppiError):
+        h.set_action_limits(hi, lo)
+
+
+@pytest.mark.parametrize("window,order", [(5, 3), (11, 9), (7, 2), (1, 0)])
+def test_sequence_filter_matches_scipy_savgol(m, window, order):
+    """filterSeq (controller_base.py:277-291): the stored sequence after a step = savgol_filter(shifted U', window,
+    order, axis=0) (mode 'interp'); u and U' themselves are not filtered."""
+    from scipy.signal import savgol_filter
+    K, H, a = 256, 24, 3
+    h, p = make_pair(m, K, H, a, seed=6)
+    h.set_sequence_filter(window, order)
+    x = np.array([0.3, 0.0, -0.2, 0.1, 0.5, 0.0], F32)
+    U = np.zeros((H, a), F32)
+    for step in range(3):
+        u = h.next(x)
+        eps = h.debug_get(m.DBG_NOISE)
+        u_ref, U_sh, _ = p.next_with_noise(x, U, eps)
+        ref = {"U_new": np.concatenate([u_ref.reshape(1, a), U_sh[:-1]])}
+        np.testing.assert_allclose(h.debug_get(m.DBG_U_UPDATED), ref["U_new"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(u, ref["U_new"][0], rtol=0, atol=2e-6)
+        Uupd = h.debug_get(m.DBG_U_UPDATED).astype(np.float64)
+        shifted = np.concatenate([Uupd[1:], np.zeros((1, a))])
+        want = savgol_filter(shifted, window, order, deriv=0, delta=1.0, axis=0)
+        U = h.get_action_sequence()
+        np.testing.assert_allclose(U, want, rtol=0, atol=2e-6)
+    h.set_sequence_filter(0)
+    h.next(x)
+    np.testing.assert_array_equal(h.get_action_sequence()[:-1], h.debug_get(m.DBG_U_UPDATED)[1:])
+    for bad in [(10, 9), (H + 1, 2), (5, 5)]:
+        with pytest.raises(m.MppiError):
+            h.set_sequence_filter(*bad)
