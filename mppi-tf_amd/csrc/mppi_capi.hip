@@ -24,7 +24,8 @@ struct mppi_handle {
     int K_global = 0, K_local = 0, k_offset = 0, shard_rank = 0, shard_count = 1;
     int H = 0, s = 0, a = 0, HA = 0;
     int R = 64, nb = 0;   // tile size / record count of the point-mass tile kernels
-    int nb_mlp = 0;       // record count of the MLP rollout kernel (32 rollouts per workgroup)
+    int nb_mlp = 0;       // record count of the MLP rollout kernel (64 rollouts per workgroup)
+    int mlp_bx3 = 0;      // MPPI_FLAG_MLP_BF16X3: split-bf16 matrix-core variant of the MLP rollout
     MlpDev hm{};          // learned model: device pointers + normalisation (host copy)
     MlpDev *dM = nullptr;
     float *d_mlp_w = nullptr; // one allocation holding W1,b1,W2,b2,W3,b3
@@ -290,6 +291,8 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     else if (tile_lds_floats(h->HA, R) * 4 > lds_cap) h->no_rollout = "tau*a_dim too large: the 16-rollout LDS tile exceeds 160 KiB";
     h->R = R; h->nb = (h->K_local + R - 1) / R; h->tile_lds = tile_lds_floats(h->HA, R) * 4;
     h->nb_mlp = cfg->model_kind == MPPI_MODEL_MLP ? (h->K_local + kMlpR - 1) / kMlpR : 0;
+    h->mlp_bx3 = (cfg->model_kind == MPPI_MODEL_MLP && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) ? 1 : 0;
+    if (getenv("MPPI_MLP_BF16X3") && cfg->model_kind == MPPI_MODEL_MLP) h->mlp_bx3 = atoi(getenv("MPPI_MLP_BF16X3")) != 0; // A/B runs
 
     mppi_status st = MPPI_OK;
     auto body = [&]() -> mppi_status {
@@ -467,7 +470,10 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
         }                                                                                                               \
         hipLaunchKernelGGL(kern, g, b, lds, st, h->dC, h->dM, x_dev, U_dev, eps, h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp); \
     } while (0)
-    if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp<A, true>), 2);
+    if (h->mlp_bx3) {
+        if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp_bx3<A, true>), 8);
+        else MPPI_MLP_L((k_rollout_mlp_bx3<A, false>), 16);
+    } else if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp<A, true>), 2);
     else MPPI_MLP_L((k_rollout_mlp<A, false>), 4);
 #undef MPPI_MLP_L
     return hipGetLastError();
