@@ -187,7 +187,7 @@ __device__ __forceinline__ void static_for(F &&f)
 
 // -DMPPI_PC_TIMELINE (tools/timeline.py, timing study only): every wave stamps s_memrealtime (100 MHz) at its
 // phase boundaries into LDS and the consumer dumps the 64 stamps in place of the tile's costs.
-#if defined(MPPI_PC_TIMELINE)
+#if defined(MPPI_PC_TIMELINE) || defined(MPPI_MLP_TIMELINE)
 __device__ __forceinline__ unsigned long long pc_stamp()
 {
     unsigned long long t;
@@ -196,6 +196,8 @@ __device__ __forceinline__ unsigned long long pc_stamp()
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
+#endif
+#if defined(MPPI_PC_TIMELINE)
 #define MPPI_STAMP_RT(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); if (lane == 0) tl_s[(slot)] = (float)(t_ & 0xFFFFFFull); } while (0)
 #define MPPI_STAMP(slot) do { const unsigned long long t_ = pc_stamp(); if (lane == 0) tl_s[(slot)] = (float)(t_ & 0xFFFFFFull); } while (0)
 #else
@@ -1064,6 +1066,19 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
 #pragma unroll
     for (int i = 0; i < S; ++i) x[i] = x_dev[i];
     float c = 0.0f;
+    // wave-uniform normalisation constants, read once (a barrier would otherwise force a re-fetch per step); the
+    // division by xstd becomes a multiplication by its reciprocal: this path is tolerance-bound, not order-bound
+    float xm[NIN], xr[NIN], b3v[S], ysd[S], ymn[S];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) { xm[i] = M->xmean[i]; xr[i] = 1.0f / M->xstd[i]; }
+#pragma unroll
+    for (int i = 0; i < S; ++i) { b3v[i] = M->b3[i]; ysd[i] = M->ystd[i]; ymn[i] = M->ymean[i]; }
+    PcProducerConsts<A> pcst;
+    pcst.template load<DIAG>(C);
+    const PcProducerConsts<A> *PC = &pcst;
+    PcConsumerConsts<S> ccst;
+    ccst.load(C);
+    const PcConsumerConsts<S> *CC = &ccst;
     const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)kk;
     const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
     const unsigned long long seed = C->seed;
@@ -1075,6 +1090,12 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
     }
     __syncthreads();
 
+#if defined(MPPI_MLP_TIMELINE)
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = pc_stamp();
+#define MLP_PH(i) do { const unsigned long long tn_ = pc_stamp(); tph[i] += tn_ - tlast; tlast = tn_; } while (0)
+#else
+#define MLP_PH(i) do { } while (0)
+#endif
     for (int t = 0; t < H; ++t) {
         float u[A], e[A], v[A];
         if (SRC == SRC_PHILOX) {
@@ -1082,27 +1103,28 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
             float zz[A];
 #pragma unroll
             for (int i = 0; i < A; ++i) zz[i] = zb[i * R];
-            scale_noise<A, DIAG>(C, zz, e);
+            scale_noise<A, DIAG>(PC, zz, e);
         } else {
 #pragma unroll
             for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
         }
 #pragma unroll
         for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
-        const float ac = action_cost<A, DIAG>(C, u, e);
+        const float ac = action_cost<A, DIAG>(PC, u, e);
 
         // normalised inputs of this lane's rollout, the bias input 1, zero padding -> two 8-element fragments
         bf16x8 f0h, f0l, f1h, f1l;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float val = 0.0f;
-            if (i < S) val = (x[i] - M->xmean[i]) / M->xstd[i];
-            else if (i < NIN) val = (v[i - S] - M->xmean[i]) / M->xstd[i];
+            if (i < S) val = (x[i] - xm[i]) * xr[i];
+            else if (i < NIN) val = (v[i - S] - xm[i]) * xr[i];
             else if (i == NIN) val = 1.0f;
             __bf16 hi, lo;
             split_bf16(val, hi, lo);
             if (i < 8) { f0h[i] = hi; f0l[i] = lo; } else { f1h[i - 8] = hi; f1l[i - 8] = lo; }
         }
+        MLP_PH(0); // noise, action cost, input normalisation + split
         // ---- layer 1. Column block cb's B fragment of lane (r, h) is inputs [8h, 8h+8) of rollout 32cb+r, held by
         // lane (r, cb): its own fragment when cb == h, its partner's (lane^32) otherwise — one exchange per step.
         bf16x8 th, tl;
@@ -1124,6 +1146,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc1, 0, 0, 0);
+        MLP_PH(1); // exchange + layer-1 MFMAs issued
         // relu, split, and out to the image in accumulator order: registers 8s..8s+7 are the 8 elements of this lane's
         // B fragment of k-block 2w+s
 #pragma unroll
@@ -1143,7 +1166,9 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
             img[((0 * 16 + kb) * 2 + hh) * 64 + 32 + j] = h1h;
             img[((1 * 16 + kb) * 2 + hh) * 64 + 32 + j] = h1l;
         }
+        MLP_PH(2); // relu + split + image writes
         __syncthreads();
+        MLP_PH(3); // barrier 1
 
         // the next horizon group's normals, once per workgroup (wave g%8), into the other half of the buffer
         if (SRC == SRC_PHILOX && (t & 3) == 0) {
@@ -1161,8 +1186,13 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
         acc0 = bias2;
         acc1 = bias2;
         const bf16x8 *ih = img + hh * 64 + j, *il = img + (16 * 2 + hh) * 64 + j;
+#if defined(MPPI_ABLATE_BX3_L2)
+#pragma unroll
+        for (int kb = 0; kb < 2; kb += 2) {
+#else
 #pragma unroll
         for (int kb = 0; kb < 16; kb += 2) {
+#endif
             bf16x8 q0h[2], q0l[2], q1h[2], q1l[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -1181,30 +1211,37 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        MLP_PH(4); // next group's noise (1 wave in 8, every 4th step) + layer-2 MFMAs issued
         // ---- layer 3 partial over this wave's 32 units (16 per lane half), both column blocks, fp32 VALU
-        float py0[S], py1[S];
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 py[S]; // (column block 0, column block 1): one v_pk_fma_f32 per (row, output)
 #pragma unroll
-        for (int n = 0; n < S; ++n) { py0[n] = 0.0f; py1[n] = 0.0f; }
+        for (int n = 0; n < S; ++n) py[n] = (f32x2){0.0f, 0.0f};
+#if defined(MPPI_ABLATE_BX3_L3)
+#pragma unroll
+        for (int r = 0; r < 1; ++r) {
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+#endif
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float hv0 = fmaxf(acc0[r], 0.0f);
-            const float hv1 = fmaxf(acc1[r], 0.0f);
+            const f32x2 hv = {fmaxf(acc0[r], 0.0f), fmaxf(acc1[r], 0.0f)};
             const float *w3 = w3_s + (32 * w + row) * S;
 #pragma unroll
             for (int n = 0; n < S; ++n) {
                 const float wv = w3[n];
-                py0[n] = __builtin_fmaf(hv0, wv, py0[n]);
-                py1[n] = __builtin_fmaf(hv1, wv, py1[n]);
+                py[n] = __builtin_elementwise_fma(hv, (f32x2){wv, wv}, py[n]);
             }
         }
 #pragma unroll
         for (int n = 0; n < S; ++n) { // halves hold different rows: lane half hh keeps column block hh
-            const float keep = hh ? py1[n] : py0[n];
-            const float send = hh ? py0[n] : py1[n];
+            const float keep = hh ? py[n][1] : py[n][0];
+            const float send = hh ? py[n][0] : py[n][1];
             y_s[(w * S + n) * R + lane] = keep + __shfl_xor(send, 32, 64);
         }
+        MLP_PH(5); // layer 3 (waits for the MFMA results) + partial writes
         __syncthreads();
+        MLP_PH(6); // barrier 2
 
         // ---- y = Σ_waves partial + b3 (fixed order), state update, costs
 #pragma unroll
@@ -1212,14 +1249,23 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
             float y = y_s[(0 * S + n) * R + lane];
 #pragma unroll
             for (int ww = 1; ww < 8; ++ww) y = y + y_s[(ww * S + n) * R + lane];
-            y = y + M->b3[n];
-            x[n] = x[n] + (y * M->ystd[n] + M->ymean[n]);
+            y = y + b3v[n];
+            x[n] = x[n] + (y * ysd[n] + ymn[n]);
         }
-        const float sc = state_cost<S, QFULL>(C, x); // cost on the POST-step state
+        const float sc = state_cost<S, QFULL>(CC, x); // cost on the POST-step state
         const float tmp = sc + ac;
         c = c + tmp;
+        MLP_PH(7); // y reduction, state update, costs
     }
-    c = c + state_cost<S, QFULL>(C, x); // terminal cost, controller_base.cpp:271-272
+#if defined(MPPI_MLP_TIMELINE)
+    if (lane < 8) { float v_ = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v_ = lane == q ? (float)tph[q] : v_;
+        c = v_; }
+    if (valid && lane < 8) cost[k0 + 8 * w + lane] = c; // wave w's 8 phase totals at cost[k0 + 8w ..]
+    return;
+#endif
+    c = c + state_cost<S, QFULL>(CC, x); // terminal cost, controller_base.cpp:271-272
     if (w == 0 && valid) cost[k0 + lane] = c;
     if (MODE == MODE_COST_ONLY) return;
 

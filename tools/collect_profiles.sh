@@ -18,6 +18,9 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_grbm -- $BENCH > $OUT/pmc_grbm.log 2>&1
+if [ "$WORKLOAD" = "mlp" ]; then  # matrix-core occupancy of the MLP kernels (own pass; a refused counter only loses this pass)
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $OUT/pmc_mfma -- $BENCH > $OUT/pmc_mfma.log 2>&1
+fi
 cd $R
 grep -h '"metric"' $OUT/*.log | head -1 > $OUT/bench_under_profiler.json
 ls -R $OUT | head -40
