@@ -45,11 +45,52 @@ class OracleShardBackend:
         self.step_no += 1
 
 
+class P2PDoubleBackend(OracleShardBackend):
+    """Adds the direct-exchange hooks of HipShardBackend so that ShardedController's bring-up (export -> gather the
+    handles -> open -> attach -> probe x3, a vote after each phase) runs on CPU. mode: "ok" | "open_fails" |
+    "probe_fails" (the failure happens on the LAST rank only: the vote must still send every rank to the all-gather).
+    The step itself moves the records with a gloo all-gather: only the control flow is under test here."""
+
+    def __init__(self, rank, world, mode, **cfg):
+        super().__init__(rank, world, **cfg)
+        self.rank, self.world, self.mode = rank, world, mode
+        self.attached, self.probes, self.p2p_steps = None, 0, 0
+
+    def p2p_export(self):
+        return 1000 + self.rank, b"ipc-handle-of-rank-%02d" % self.rank
+
+    def p2p_open(self, ipc_handle):
+        if self.mode == "open_fails" and self.rank == self.world - 1:
+            raise RuntimeError("hipIpcOpenMemHandle: invalid argument (test double)")
+        assert ipc_handle.startswith(b"ipc-handle-of-rank-")
+        return 1000 + int(ipc_handle[-2:])
+
+    def p2p_attach(self, ptrs, timeout_ms):
+        assert ptrs == [1000 + g for g in range(self.world)] and timeout_ms > 0
+        self.attached = list(ptrs)
+
+    def p2p_probe(self):
+        self.probes += 1
+        return not (self.mode == "probe_fails" and self.rank == self.world - 1)
+
+    def p2p_step(self, x, u):
+        self.p2p_steps += 1
+        rec = torch.zeros(self.record_size)
+        recs = torch.zeros(self.world * self.record_size)
+        self.partial(x, rec)
+        dist.all_gather_into_tensor(recs, rec)
+        self.finish(recs, self.world, u)
+
+    def p2p_timed_out(self):
+        return False
+
+
 def run(cfg, n_steps, world_override=None):
     from mppi_tf_amd.distributed import ShardedController
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    be = OracleShardBackend(rank, world, **cfg)
+    mode = os.environ.get("MPPI_TEST_P2P", "")
+    be = P2PDoubleBackend(rank, world, mode, **cfg) if mode else OracleShardBackend(rank, world, **cfg)
     ctl = ShardedController(backend=be)
     A, B = orc.pm_matrices(0.1, 1.0, cfg["s_dim"], cfg["a_dim"])
     x = np.zeros(cfg["s_dim"], np.float32)
@@ -58,7 +99,9 @@ def run(cfg, n_steps, world_override=None):
         u = ctl.next(torch.from_numpy(x.copy())).numpy().copy()
         us.append(u.tolist())
         x = orc.model_step(A, B, x[None], u[None])[0]
-    return dict(rank=rank, world=world, lo=be.lo, hi=be.hi, u=us, U=be.U.tolist())
+    ctl.check()
+    return dict(rank=rank, world=world, lo=be.lo, hi=be.hi, u=us, U=be.U.tolist(), exchange=ctl.exchange, note=ctl.p2p_note,
+                p2p_steps=getattr(be, "p2p_steps", 0), probes=getattr(be, "probes", 0))
 
 
 if __name__ == "__main__":

@@ -21,10 +21,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(world, tmp_path, steps=3):
-    out = str(tmp_path / ("res_w%d" % world))
+def launch(world, tmp_path, steps=3, p2p=""):
+    out = str(tmp_path / ("res_w%d%s" % (world, p2p)))
     env = dict(os.environ, MPPI_TEST_CFG=json.dumps(CFG), MPPI_TEST_OUT=out, MPPI_TEST_STEPS=str(steps),
-               OMP_NUM_THREADS="2")
+               OMP_NUM_THREADS="2", MPPI_TEST_P2P=p2p)
+    env.pop("MPPI_EXCHANGE", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -49,6 +50,19 @@ def test_sharded_control_loop_matches_unsharded(world, tmp_path, unsharded):
         assert r["u"] == res[0]["u"] and r["U"] == res[0]["U"]
     np.testing.assert_allclose(res[0]["u"], unsharded["u"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(res[0]["U"], unsharded["U"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", ["ok", "open_fails", "probe_fails"])
+def test_direct_exchange_bring_up_votes_and_falls_back(mode, tmp_path, unsharded):
+    """ShardedController's direct-exchange bring-up on CPU with a test double: when mapping a peer or a probe fails on
+    ONE rank, EVERY rank must take the all-gather path (the votes are collectives); results are the same either way."""
+    res = launch(2, tmp_path, p2p=mode)
+    want = "p2p" if mode == "ok" else "rccl"
+    assert [r["exchange"] for r in res] == [want, want], [r["note"] for r in res]
+    assert all((r["p2p_steps"] == 3) == (mode == "ok") for r in res)
+    assert all(r["probes"] == (0 if mode == "open_fails" else 3) for r in res)
+    assert res[1]["u"] == res[0]["u"] and res[1]["U"] == res[0]["U"]
+    np.testing.assert_allclose(res[0]["u"], unsharded["u"], rtol=0, atol=2e-6)
 
 
 def test_shard_bounds_cover_everything():
