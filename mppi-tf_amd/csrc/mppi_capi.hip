@@ -4,6 +4,7 @@
 #include "mppi_kernels.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -876,12 +877,30 @@ static mppi_status step_host(mppi_handle *h, const float *x, int n_x, const floa
     std::memcpy(h->h_pin + h->pin_slot * kMaxS, x, sizeof(float) * h->s);
     const float *x_arg = h->d_pin + h->pin_slot * kMaxS;
     float *u_arg = h->d_pin + 2 * kMaxS;
+    constexpr uint32_t kUSentinel = 0x7fc0deadu;
+    static const bool spin_env = !(getenv("MPPI_SYNC_SPIN") && atoi(getenv("MPPI_SYNC_SPIN")) == 0);
+    const bool spin_u = spin_env && h->sg_window == 0; // with a sequence filter the step has one more kernel after u
+    if (spin_u) for (int j = 0; j < h->a; ++j) reinterpret_cast<volatile uint32_t *>(h->h_pin + 2 * kMaxS)[j] = kUSentinel;
     int nrec = 0;
     mppi_status s = enqueue_partials(h, h->stream, src, x_arg, h->d_eps, nullptr, &nrec);
     if (s != MPPI_OK) return s;
     HIP_TRY(h, launch_finish(h, h->stream, h->d_part, 1, nrec, nrec, h->U_cur(), h->U_other(), u_arg, nullptr, 1));
     HIP_TRY(h, advance_sequence(h, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // u arrives in the pinned slot as `a` single 4-byte stores over PCIe: watch the slot instead of waiting for the
+    // stream's completion signal (the runtime's wake-up costs several us of a ~35 us synchronous step). The slot was
+    // filled with a NaN pattern the update cannot produce; if it has not changed after 2 ms (a long step, an error, a
+    // genuine NaN) fall back to the ordinary wait. Later calls on this handle are stream-ordered behind the step.
+    bool seen = false;
+    if (spin_u) {
+        volatile uint32_t *slot = reinterpret_cast<volatile uint32_t *>(h->h_pin + 2 * kMaxS);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 0; !seen; ++it) {
+            seen = true;
+            for (int j = 0; j < h->a; ++j) seen = seen && slot[j] != kUSentinel;
+            if (!seen && (it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    if (!seen) HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::memcpy(u_out, h->h_pin + 2 * kMaxS, sizeof(float) * h->a);
     // m_db.addX(s); m_db.addU(out_tensor[1])  controller_base.cpp:146-147
     h->log_x.insert(h->log_x.end(), x, x + h->s);
