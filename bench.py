@@ -155,7 +155,7 @@ def main():
     # The record exchange of a sharded step: the direct (in-kernel, peer-store) exchange if its self-test passes on
     # every rank, else one RCCL all-gather per step. A deadline missed later also sends the whole run to RCCL.
     for exchange in (os.environ.get("MPPI_EXCHANGE", "auto"), "rccl"):
-        ctl = ShardedController(device_index=local_rank, k=k_global, mlp=mlp, exchange=exchange, p2p_timeout_ms=200, **CFG)
+        ctl = ShardedController(device_index=local_rank, k=k_global, mlp=mlp, exchange=exchange, p2p_timeout_ms=1000, **CFG)
         assert ctl.backend.h.k_local == K_PER_GPU
         for _ in range(args.warmup):
             ctl.next(x)
