@@ -246,7 +246,6 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
     constexpr int CH = CS * (A + 1) * 64;     // floats per chunk buffer: [CS][(A+1)][64 lanes]
     constexpr int NREG = NSLOT * 4 * A;       // noise values a producer lane keeps
     const int H = C->H;
-    const int HA = H * A;
     const int K = C->K_local;
     const int NG = (H + 3) / 4;               // horizon groups
     const int nch = (NG + NP - 1) / NP;       // chunks
@@ -548,7 +547,7 @@ __device__ __forceinline__ void column_combine(Load ld, int nb, float neg_inv_la
 }
 
 __global__ __launch_bounds__(kThreads) void k_finish_cols(
-    const float *__restrict__ recs, int sb, int sc, int nb, int HA, int a, float neg_inv_lambda,
+    const float *__restrict__ recs, int sb, int sc, int nb, int /*HA*/, int a, float neg_inv_lambda,
     const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
     float *__restrict__ record_out, int apply, unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg,
     const float *__restrict__ clip)
