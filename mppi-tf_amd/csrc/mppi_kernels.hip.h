@@ -726,6 +726,46 @@ __global__ void k_mlp_step_ref(const DevConsts *__restrict__ C, const MlpDev *__
     }
 }
 
+// Tile record of the MLP rollout kernels: every wave holds the same 64 costs; beta, eta by wave 0, and
+// V_b[t,i] = Σ_k e_k·eps[k,t,i] with wave w regenerating the noise of horizon groups g = w, w+8, ... from the Philox
+// counters (cheap next to H steps of MFMA).
+template <int A, bool DIAG>
+__device__ __forceinline__ void mlp_tile_record(const DevConsts *__restrict__ C, float c, bool valid, int w, int lane, int kk,
+                                                int H, int NG, int SRC, const float *__restrict__ eps_hbm,
+                                                unsigned long long seed, unsigned long long gk, unsigned long long base,
+                                                float *__restrict__ rec, int rsc)
+{
+    const int HA = H * A;
+    const float beta = wave_min(valid ? c : INFINITY);
+    const float ek = valid ? expf(C->neg_inv_lambda * (c - beta)) : 0.0f;
+    const float eta = wave_sum(ek);
+    if (w == 0 && lane == 0) { rec[0] = beta; rec[(size_t)rsc] = eta; }
+    for (int g = w; g < NG; g += 8) {
+        float zz[4 * A];
+        if (SRC == SRC_PHILOX) normals_group<A>(seed, gk, base + (unsigned long long)g, zz);
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            const int t = 4 * g + tl;
+            if (t < H) {
+                float z1[A], e[A];
+                if (SRC == SRC_PHILOX) {
+#pragma unroll
+                    for (int i = 0; i < A; ++i) z1[i] = zz[tl * A + i];
+                    scale_noise<A, DIAG>(C, z1, e);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
+                }
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    const float tot = wave_sum_dpp(ek * e[i]);
+                    if (lane == 0) rec[(size_t)(2 + t * A + i) * rsc] = tot;
+                }
+            }
+        }
+    }
+}
+
 // k_rollout_mlp: one workgroup of 8 wavefronts owns 64 rollouts for the whole horizon.
 // Transposed formulation hᵀ = Wᵀ·inᵀ so that the rollout index sits on the LANE of every MFMA
 // operand and result and everything per-rollout (state, cost, noise) is lane-local:
@@ -951,37 +991,8 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
     if (w == 0 && valid) cost[k0 + lane] = c;
     if (MODE == MODE_COST_ONLY) return;
 
-    // ---- tile record: every wave holds the same 64 costs
-    const float beta = wave_min(valid ? c : INFINITY);
-    const float ek = valid ? expf(C->neg_inv_lambda * (c - beta)) : 0.0f;
-    const float eta = wave_sum(ek);
-    float *rec = partials + (size_t)blockIdx.x * rsb; // element (b, col) at partials[b*rsb + col*rsc]
-    if (w == 0 && lane == 0) { rec[0] = beta; rec[(size_t)rsc] = eta; }
-    // V_b[t,i] = Σ_k e_k·eps[k,t,i]: wave w regenerates the noise of horizon groups g = w, w+8, ...
-    for (int g = w; g < NG; g += 8) {
-        float zz[4 * A];
-        if (SRC == SRC_PHILOX) normals_group<A>(seed, gk, base + (unsigned long long)g, zz);
-#pragma unroll
-        for (int tl = 0; tl < 4; ++tl) {
-            const int t = 4 * g + tl;
-            if (t < H) {
-                float z1[A], e[A];
-                if (SRC == SRC_PHILOX) {
-#pragma unroll
-                    for (int i = 0; i < A; ++i) z1[i] = zz[tl * A + i];
-                    scale_noise<A, DIAG>(C, z1, e);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
-                }
-#pragma unroll
-                for (int i = 0; i < A; ++i) {
-                    const float tot = wave_sum_dpp(ek * e[i]);
-                    if (lane == 0) rec[(size_t)(2 + t * A + i) * rsc] = tot;
-                }
-            }
-        }
-    }
+    mlp_tile_record<A, DIAG>(C, c, valid, w, lane, kk, H, NG, SRC, eps_hbm, seed, gk, base,
+                             partials + (size_t)blockIdx.x * rsb, rsc); // element (b, col) at partials[b*rsb + col*rsc]
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1268,36 +1279,8 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
     if (w == 0 && valid) cost[k0 + lane] = c;
     if (MODE == MODE_COST_ONLY) return;
 
-    // ---- tile record: every wave holds the same 64 costs (as k_rollout_mlp)
-    const float beta = wave_min(valid ? c : INFINITY);
-    const float ek = valid ? expf(C->neg_inv_lambda * (c - beta)) : 0.0f;
-    const float eta = wave_sum(ek);
-    float *rec = partials + (size_t)blockIdx.x * rsb;
-    if (w == 0 && lane == 0) { rec[0] = beta; rec[(size_t)rsc] = eta; }
-    for (int g = w; g < NG; g += 8) {
-        float zz[4 * A];
-        if (SRC == SRC_PHILOX) normals_group<A>(seed, gk, base + (unsigned long long)g, zz);
-#pragma unroll
-        for (int tl2 = 0; tl2 < 4; ++tl2) {
-            const int t = 4 * g + tl2;
-            if (t < H) {
-                float z1[A], e[A];
-                if (SRC == SRC_PHILOX) {
-#pragma unroll
-                    for (int i = 0; i < A; ++i) z1[i] = zz[tl2 * A + i];
-                    scale_noise<A, DIAG>(C, z1, e);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
-                }
-#pragma unroll
-                for (int i = 0; i < A; ++i) {
-                    const float tot = wave_sum_dpp(ek * e[i]);
-                    if (lane == 0) rec[(size_t)(2 + t * A + i) * rsc] = tot;
-                }
-            }
-        }
-    }
+    mlp_tile_record<A, DIAG>(C, c, valid, w, lane, kk, H, NG, SRC, eps_hbm, seed, gk, base,
+                             partials + (size_t)blockIdx.x * rsb, rsc); // element (b, col) at partials[b*rsb + col*rsc]
 }
 
 // min / max of the costs (Py normalizeCost, controller_base.py:468-474): out[0]=min, out[1]=max-min
