@@ -294,6 +294,11 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     h->nb_mlp = cfg->model_kind == MPPI_MODEL_MLP ? (h->K_local + kMlpR - 1) / kMlpR : 0;
     h->mlp_bx3 = (cfg->model_kind == MPPI_MODEL_MLP && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) ? 1 : 0;
     if (getenv("MPPI_MLP_BF16X3") && cfg->model_kind == MPPI_MODEL_MLP) h->mlp_bx3 = atoi(getenv("MPPI_MLP_BF16X3")) != 0; // A/B runs
+    // the two-set software-pipelined variant (k_rollout_mlp_bx3p): 128 rollouts per workgroup
+    if (h->mlp_bx3 && getenv("MPPI_MLP_BX3_PIPE") && atoi(getenv("MPPI_MLP_BX3_PIPE")) != 0) {
+        h->mlp_bx3 = 2;
+        h->nb_mlp = (h->K_local + kMlpR2 - 1) / kMlpR2;
+    }
 
     mppi_status st = MPPI_OK;
     auto body = [&]() -> mppi_status {
@@ -457,7 +462,7 @@ template <int A>
 static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
                                const float *eps, float *cost)
 {
-    const size_t lds = mlp_lds_floats(2 * A, A) * 4;
+    const size_t lds = (h->mlp_bx3 == 2 ? mlp_bx3p_lds_floats(2 * A, A) : mlp_lds_floats(2 * A, A)) * 4;
     const dim3 g(h->nb_mlp), b(kMlpThreads);
     if (mode != MODE_ROLLOUT && mode != MODE_COST_ONLY) return hipErrorInvalidValue;
 #define MPPI_MLP_L(KERN, BIT)                                                                                           \
@@ -471,7 +476,10 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
         }                                                                                                               \
         hipLaunchKernelGGL(kern, g, b, lds, st, h->dC, h->dM, x_dev, U_dev, eps, h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp); \
     } while (0)
-    if (h->mlp_bx3) {
+    if (h->mlp_bx3 == 2) {
+        if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp_bx3p<A, true>), 32);
+        else MPPI_MLP_L((k_rollout_mlp_bx3p<A, false>), 64);
+    } else if (h->mlp_bx3) {
         if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp_bx3<A, true>), 8);
         else MPPI_MLP_L((k_rollout_mlp_bx3<A, false>), 16);
     } else if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp<A, true>), 2);

@@ -752,3 +752,32 @@ def test_sequence_filter_matches_scipy_savgol(m, window, order):
     for bad in [(10, 9), (H + 1, 2), (5, 5)]:
         with pytest.raises(m.MppiError):
             h.set_sequence_filter(*bad)
+
+
+def test_mlp_bf16x3_pipelined_variant_is_bit_identical(m, monkeypatch):
+    """k_rollout_mlp_bx3p (MPPI_MLP_BX3_PIPE=1: two 64-rollout sets per workgroup, the scalar chain of one inside the
+    MFMA stream of the other) must give the SAME bits as k_rollout_mlp_bx3, run after run. This is the regression test
+    of a hardware hazard found while building it: a vector instruction that overwrites an MFMA's source registers right
+    after the MFMA issues (across a branch, where hipcc pads nothing) corrupts 16-lane groups of rollouts at random."""
+    a, s = 3, 6
+    for K, H in [(2048, 32), (300, 64), (4096, 17)]:
+        mlp = make_mlp(s, a, seed=K)
+        cfg = dict(k=K, tau=H, s_dim=s, a_dim=a, lam=1.0, sigma=0.25 * np.eye(a), goal=GOAL3, mlp=mlp, mlp_bf16x3=True, seed=3)
+        monkeypatch.delenv("MPPI_MLP_BX3_PIPE", raising=False)
+        h0 = m.Handle(**cfg)
+        monkeypatch.setenv("MPPI_MLP_BX3_PIPE", "1")
+        h1 = m.Handle(**cfg)
+        monkeypatch.delenv("MPPI_MLP_BX3_PIPE", raising=False)
+        rng = np.random.default_rng(5)
+        x0 = (0.2 * rng.standard_normal(s)).astype(F32)
+        U = (0.1 * rng.standard_normal((H, a))).astype(F32)
+        eps = (0.25 * rng.standard_normal((K, H, a))).astype(F32)
+        c0 = h0.rollout_cost(x0, U, eps)
+        for _ in range(3):
+            np.testing.assert_array_equal(h1.rollout_cost(x0, U, eps), c0)
+        # a whole step on the fused Philox path: same sample costs; the controls differ only by the grouping of the
+        # soft-min sums (128- instead of 64-rollout tile records)
+        u1, u0 = h1.next(x0), h0.next(x0)
+        np.testing.assert_array_equal(h1.debug_get(m.DBG_COSTS), h0.debug_get(m.DBG_COSTS))
+        np.testing.assert_allclose(u1, u0, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(h1.get_action_sequence(), h0.get_action_sequence(), rtol=0, atol=1e-6)

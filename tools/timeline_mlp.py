@@ -24,13 +24,18 @@ u = torch.zeros(a, device="cuda")
 for _ in range(2):
     h.next_device(x.data_ptr(), u.data_ptr())
 h.synchronize()
-c = h.debug_get(m.DBG_COSTS).reshape(-1, 8, 8).astype(np.float64)  # [block][wave][phase] cycles summed over H steps
-names = ["noise/action cost/input split", "exchange + L1 MFMA issue", "relu + split + image write", "barrier 1",
+pipe = os.environ.get("MPPI_MLP_BX3_PIPE") == "1"
+c = h.debug_get(m.DBG_COSTS)
+if pipe:  # 128 rollouts per workgroup: the first 64 cost slots of every block hold [wave][phase]; units = half-iterations
+    c = c.reshape(-1, 128)[:, :64]
+c = c.reshape(-1, 8, 8).astype(np.float64)  # [block][wave][phase] cycles summed over H steps
+names = ["fragments -> L1 -> relu/split -> image", "barrier A", "L2 MFMA issue (+ chain of the other set)", "L3 + y write", "barrier B",
+         "-", "-", "-"] if pipe else ["noise/action cost/input split", "exchange + L1 MFMA issue", "relu + split + image write", "barrier 1",
          "(noise gen) + L2 MFMA issue", "L3 (waits for MFMA) + y write", "barrier 2", "y reduce + state + cost"]
-per = c.mean(axis=(0, 1)) / H
-print("cycles per horizon step, mean over blocks and waves (total %.0f = %.2f us at 2.4 GHz):" % (per.sum(), per.sum() / 2400))
+per = c.mean(axis=(0, 1)) / (2 * H if pipe else H)
+print("cycles per %s, mean over blocks and waves (total %.0f = %.2f us at 2.4 GHz):" % ("half-iteration (64 rollouts x 1 step)" if pipe else "horizon step", per.sum(), per.sum() / 2400))
 for n, v in zip(names, per):
     print("  %7.0f  %s" % (v, n))
 print("per wave (block 0):")
 for w in range(8):
-    print("  wave %d: " % w + " ".join("%6.0f" % (v / H) for v in c[0, w]))
+    print("  wave %d: " % w + " ".join("%6.0f" % (v / (2 * H if pipe else H)) for v in c[0, w]))
