@@ -772,6 +772,8 @@ extern "C" mppi_status mppi_shard_p2p_export(mppi_handle *h, void *ipc_handle_ou
 {
     if (!h || !inbox_dev_out) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL inbox_dev_out") : MPPI_ERR_INVALID_ARG;
     if (h->shard_count > kMaxPeers) return fail(h, MPPI_ERR_UNSUPPORTED, "direct exchange supports at most 16 shards");
+    // fault injection for the fallback tests: MPPI_P2P_FAULT=export|probe
+    if (getenv("MPPI_P2P_FAULT") && !strcmp(getenv("MPPI_P2P_FAULT"), "export")) return fail(h, MPPI_ERR_HIP, "injected fault: inbox export refused");
     HIP_TRY(h, hipSetDevice(h->device));
     if (!h->xchg_inbox) {
         // uncached: peer stores land in memory and the local spin loads see them without any cache maintenance
@@ -839,6 +841,7 @@ extern "C" mppi_status mppi_shard_p2p_probe(mppi_handle *h, void *stream, int *o
     HIP_TRY(h, hipStreamSynchronize(st));
     int ok = (*(volatile unsigned *)h->h_xchg_status & 1u) ? 0 : 1;
     for (int g = 0; g < G; ++g) ok &= got[g] == payload(g);
+    if (getenv("MPPI_P2P_FAULT") && !strcmp(getenv("MPPI_P2P_FAULT"), "probe")) ok = 0;
     *ok_out = ok;
     return MPPI_OK;
 }

@@ -781,3 +781,31 @@ def test_mlp_bf16x3_pipelined_variant_is_bit_identical(m, monkeypatch):
         np.testing.assert_array_equal(h1.debug_get(m.DBG_COSTS), h0.debug_get(m.DBG_COSTS))
         np.testing.assert_allclose(u1, u0, rtol=0, atol=1e-6)
         np.testing.assert_allclose(h1.get_action_sequence(), h0.get_action_sequence(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("fault", ["", "export", "probe"])
+def test_sharded_controller_falls_back_when_the_direct_exchange_cannot_come_up(m, monkeypatch, fault):
+    """ShardedController on the real backend (one rank, exchange forced): with an injected fault in the inbox export
+    or in the probe it must take the all-gather path, and give the same controls either way."""
+    import torch
+    from mppi_tf_amd.distributed import ShardedController
+    monkeypatch.setenv("MPPI_FORCE_EXCHANGE", "1")
+    monkeypatch.delenv("MPPI_EXCHANGE", raising=False)
+    if fault:
+        monkeypatch.setenv("MPPI_P2P_FAULT", fault)
+    else:
+        monkeypatch.delenv("MPPI_P2P_FAULT", raising=False)
+    K, H, a = 4096, 32, 3
+    cfg = dict(k=K, tau=H, s_dim=6, a_dim=a, sigma=0.25 * np.eye(a), goal=GOAL3, seed=11)
+    ctl = ShardedController(**cfg)
+    assert ctl.exchange == ("rccl" if fault else "p2p"), ctl.p2p_note
+    ref = m.Handle(**cfg)
+    x = torch.tensor([0.2, 0.1, -0.3, 0, 0.5, -0.1], device="cuda")
+    for _ in range(3):
+        u = ctl.next(x)
+        torch.cuda.synchronize()
+        ctl.check()
+        np.testing.assert_allclose(u.cpu().numpy(), ref.next(x.cpu().numpy()), rtol=0, atol=2e-6)
+    if fault == "export":
+        with pytest.raises(RuntimeError):
+            ShardedController(exchange="p2p", **cfg)
