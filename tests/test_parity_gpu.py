@@ -257,15 +257,24 @@ def test_next_equals_next_with_its_own_noise(m):
         np.testing.assert_allclose(h1.get_action_sequence(), U, rtol=0, atol=U_TOL)
 
 
-@pytest.mark.parametrize("K,H,a", [(65536, 64, 3), (1000, 50, 3), (4096, 64, 2), (128, 32, 1), (777, 100, 3), (300, 130, 4), (64, 3, 2)])
-def test_producer_consumer_kernel_equals_tile_kernel(m, monkeypatch, K, H, a):
+DENSE_SIGMA3 = np.array([[0.3, 0.05, 0.0], [0.02, 0.2, -0.04], [0.0, 0.03, 0.25]])
+
+
+@pytest.mark.parametrize("K,H,a,sigma", [
+    (65536, 64, 3, None), (1000, 50, 3, None), (4096, 64, 2, None), (128, 32, 1, None), (777, 100, 3, None),
+    (300, 130, 4, None), (64, 3, 2, None),
+    (40000, 20, 3, None),          # 513..1024 tiles: 3 producers, SIMD-true roles + progress priorities
+    (70000, 16, 3, None),          # > 1024 tiles: several rounds, roles by wave index, no priorities
+    (5000, 24, 3, DENSE_SIGMA3),   # dense Σ: the non-diagonal instances
+])
+def test_producer_consumer_kernel_equals_tile_kernel(m, monkeypatch, K, H, a, sigma):
     """k_rollout_pc (hot path) vs k_rollout_tile on the same Philox counters: costs bit-identical,
     update within rounding."""
     x = (0.1 * np.arange(2 * a)).astype(F32)
     monkeypatch.setenv("MPPI_FORCE_TILE_KERNEL", "1")
-    ht, p = make_pair(m, K, H, a, seed=77)
+    ht, p = make_pair(m, K, H, a, seed=77, sigma=sigma)
     monkeypatch.setenv("MPPI_FORCE_TILE_KERNEL", "0")
-    hp, _ = make_pair(m, K, H, a, seed=77)
+    hp, _ = make_pair(m, K, H, a, seed=77, sigma=sigma)
     for _ in range(2):
         ut, up = ht.next(x), hp.next(x)
         np.testing.assert_array_equal(hp.debug_get(m.DBG_COSTS), ht.debug_get(m.DBG_COSTS))
@@ -274,7 +283,7 @@ def test_producer_consumer_kernel_equals_tile_kernel(m, monkeypatch, K, H, a):
         np.testing.assert_array_equal(hp.debug_get(m.DBG_NOISE), ht.debug_get(m.DBG_NOISE))
         ht.set_action_sequence(hp.get_action_sequence())
     # and against the oracle on the exported noise, from a fresh identical state
-    h3, _ = make_pair(m, K, H, a, seed=77)
+    h3, _ = make_pair(m, K, H, a, seed=77, sigma=sigma)
     u3 = h3.next(x)
     e3 = h3.debug_get(m.DBG_NOISE)
     u_ref, U_ref, c_ref = p.next_with_noise(x, np.zeros((H, a), F32), e3)
