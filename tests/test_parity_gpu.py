@@ -818,3 +818,35 @@ def test_sharded_controller_falls_back_when_the_direct_exchange_cannot_come_up(m
     if fault == "export":
         with pytest.raises(RuntimeError):
             ShardedController(exchange="p2p", **cfg)
+
+
+def test_device_resident_steps_replay_from_a_hipgraph(m):
+    """mppi_next_device is enqueue-only, and all state that advances (U in its two buffers, the Philox step counter)
+    lives on the device: an EVEN number of consecutive steps captured into a hipGraph replays as further control steps
+    (include/mppi_c.h). Captured through torch's graph API on its capture stream; compared with plain launches."""
+    import torch
+    K, H, a = 4096, 32, 3
+    hg, _ = make_pair(m, K, H, a, seed=13)
+    hd, _ = make_pair(m, K, H, a, seed=13)
+    x = torch.tensor([0.2, 0.1, -0.3, 0.0, 0.5, -0.1], device="cuda")
+    ug = [torch.zeros(a, device="cuda") for _ in range(2)]
+    ud = torch.zeros(a, device="cuda")
+    # one plain step first on both: the first step reads U from offset 0, later ones from the shifted offset
+    for h, u in ((hg, ug[0]), (hd, ud)):
+        h.next_device(x.data_ptr(), u.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st = torch.cuda.current_stream().cuda_stream
+        hg.next_device(x.data_ptr(), ug[0].data_ptr(), st)
+        hg.next_device(x.data_ptr(), ug[1].data_ptr(), st)
+    replays = 3
+    for _ in range(replays):
+        g.replay()
+    torch.cuda.synchronize()
+    for i in range(2 * replays):
+        hd.next_device(x.data_ptr(), ud.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(ug[1].cpu().numpy(), ud.cpu().numpy())
+    np.testing.assert_array_equal(hg.get_action_sequence(), hd.get_action_sequence())
+    assert hg.get_step_counter() == hd.get_step_counter() == 1 + 2 * replays
