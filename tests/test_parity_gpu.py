@@ -172,6 +172,7 @@ NEXT_CASES = [
     dict(K=1, H=1, a=1), dict(K=2, H=3, a=2),              # degenerate: one sample gets weight 1
     dict(K=300, H=256, a=3), dict(K=100, H=500, a=4),      # long horizons: the R=32 / R=16 LDS-tile kernel
     dict(K=65537, H=16, a=3),                              # one sample past 1024 tiles: the 16:1 fold level
+    dict(K=200001, H=16, a=3),                             # 3126 tiles: several rounds of workgroups, ragged last tile
 ]
 
 
