@@ -223,11 +223,13 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_flop_per_launch": FLOP_PER_STATE_STEP * state_steps,
                          "kernel_ms_avg": roll_ms, "record_tree_kernels_ms_avg": fin_ms, "launches_timed": n_prof,
-                         "timing": "HIP events on the launch stream around each launch (dispatch latency included; "
-                                   "rocprofv3 begin-to-end durations in profiles/ are ~2 us shorter)",
-                         "note": "noise is generated and consumed on-chip (LDS), so physical HBM traffic is far below "
-                                 "the 12a B/state-step materialised-noise model; the true limiter is VALU "
-                                 "(Philox4x32-10 + Box-Muller). See DESIGN.md §4."},
+                         "timing": "HIP events bound to each launch of the kernel on its stream (hipExtLaunchKernel start/stop "
+                                   "events = the dispatch's own begin/end, the quantity rocprofv3 reports in profiles/)",
+                         "note": "achieved = ALGORITHMIC bytes (SURVEY 8d: noise written once + read twice, 36 B per state-step) "
+                                 "per launch / kernel time; the noise is generated and consumed on-chip, so the physical HBM "
+                                 "traffic (`traffic`, PMC) is ~20x lower and the algorithmic rate can exceed the HBM peak "
+                                 "(frac > 1 means faster than ANY kernel that materialises the noise could be); the true "
+                                 "limiter is VALU issue (Philox4x32-10 + Box-Muller), see DESIGN.md 4."},
         }
         if mlp is not None:
             out["roofline"] = roof

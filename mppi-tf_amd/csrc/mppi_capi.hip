@@ -2,6 +2,7 @@
 // of mppi_kernels.hip.h.  No CPU compute path exists here: every numeric entry point launches
 // HIP kernels and fails with MPPI_ERR_NO_DEVICE / MPPI_ERR_HIP when it cannot.
 #include "mppi_kernels.hip.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -62,6 +63,9 @@ struct mppi_handle {
     std::vector<hipEvent_t> ev;   // 4 events per step: rollout begin/end, finish begin/end
     int prof_cap = 0, prof_n = 0; // steps that can be / have been recorded
     hipStream_t prof_stream = nullptr;
+    // when a step is being profiled the dominant kernel is launched with hipExtLaunchKernel, whose start/stop events
+    // carry the dispatch's own begin/end timestamps (what rocprofv3 reports), not the stream-level gaps around it
+    hipEvent_t kev0 = nullptr, kev1 = nullptr;
     std::string no_rollout; // non-empty: why this handle cannot run rollouts (helpers still work)
     // transition log (m_db of the reference: addX/addU/addNext/toCSV, data_base.cpp:29-71)
     std::vector<float> log_x, log_u, log_next;
@@ -429,8 +433,11 @@ static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_
     // one round of workgroups (<= 4 per CU, all resident from the start): SIMD-true roles + progress priorities
     static const int no_balance = getenv("MPPI_PC_NO_BALANCE") ? atoi(getenv("MPPI_PC_NO_BALANCE")) : 0; // A/B timing
     const int balance = (nb <= 4 * 256 && !no_balance) ? 1 : 0;
-    if (h->sigma_diag) hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, lds, st, h->dC, x_dev, h->U_cur(), h->d_step, h->d_cost, h->d_part, 1, nb, balance);
-    else hipLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, lds, st, h->dC, x_dev, h->U_cur(), h->d_step, h->d_cost, h->d_part, 1, nb, balance);
+    const DevConsts *dC = h->dC;
+    const float *U = h->U_cur();
+    const unsigned long long *stp = h->d_step;
+    if (h->sigma_diag) hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, nb, balance);
+    else hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, nb, balance);
     return hipGetLastError();
 }
 
@@ -474,7 +481,8 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
             if (e_ != hipSuccess) return e_;                                                                            \
             attr_done |= BIT;                                                                                           \
         }                                                                                                               \
-        hipLaunchKernelGGL(kern, g, b, lds, st, h->dC, h->dM, x_dev, U_dev, eps, h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp); \
+        hipExtLaunchKernelGGL(kern, g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, x_dev, U_dev, eps, \
+                              (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp);                \
     } while (0)
     if (h->mlp_bx3 == 2) {
         if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp_bx3p<A, true>), 32);
@@ -644,11 +652,17 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
     *nrec = mlp ? h->nb_mlp : h->nb;
     if (!h->normalize) {
         const bool prof = h->prof_n < h->prof_cap;
-        if (prof) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 0], st));
-        if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_ROLLOUT, x_dev, h->U_cur(), eps, h->d_cost));
-        else if (src == SRC_PHILOX && noise_out == nullptr && pc_eligible(h)) HIP_TRY(h, launch_pc(h, st, x_dev));
-        else HIP_TRY(h, launch_tile(h, st, src, MODE_ROLLOUT, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out));
-        if (prof) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 1], st));
+        const bool pc = !mlp && src == SRC_PHILOX && noise_out == nullptr && pc_eligible(h);
+        const bool kernel_events = prof && (mlp || pc); // the kernel's own begin/end; other kernels: events around the launch
+        if (prof && !kernel_events) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 0], st));
+        h->kev0 = kernel_events ? h->ev[4 * h->prof_n + 0] : nullptr;
+        h->kev1 = kernel_events ? h->ev[4 * h->prof_n + 1] : nullptr;
+        hipError_t le = mlp ? launch_mlp(h, st, src, MODE_ROLLOUT, x_dev, h->U_cur(), eps, h->d_cost)
+                      : pc  ? launch_pc(h, st, x_dev)
+                            : launch_tile(h, st, src, MODE_ROLLOUT, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out);
+        h->kev0 = h->kev1 = nullptr;
+        HIP_TRY(h, le);
+        if (prof && !kernel_events) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 1], st));
         return MPPI_OK;
     }
     if (h->shard_count != 1) return fail(h, MPPI_ERR_UNSUPPORTED, "normalize_cost needs the global max cost: unsharded handles only");
