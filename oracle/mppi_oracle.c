@@ -97,6 +97,16 @@ void orc_noise(uint64_t seed, uint64_t step, uint64_t k_offset, int k, int tau, 
     }
 }
 
+/* thread count of the OpenMP regions that follow (the single-thread rows of the CPU baseline table) */
+void orc_set_num_threads(int n)
+{
+#if defined(_OPENMP)
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #if defined(_OPENMP)

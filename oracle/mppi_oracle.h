@@ -74,6 +74,7 @@ void orc_noise(uint64_t seed, uint64_t step, uint64_t k_offset, int k, int tau, 
                const float *sigma, float *eps_out);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

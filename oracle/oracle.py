@@ -103,6 +103,13 @@ def num_threads():
     return int(_lib.orc_num_threads())
 
 
+def set_num_threads(n):
+    """OpenMP thread count of the following calls (noise generation included)"""
+    _get(np.float32)
+    _lib.orc_set_num_threads.argtypes = [C.c_int]
+    _lib.orc_set_num_threads(int(n))
+
+
 # --------------------------------------------------------------------------- model (A4)
 def block_diag(mat, nb, dtype=np.float32):
     I = _get(dtype)
