@@ -49,33 +49,11 @@ def synthetic_mlp(seed=0):
     return dict(W=W, b=b)
 
 
-def usable_cpus():
-    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box gives one
-    job a share of a many-core host; OpenMP's default of one thread per visible core then oversubscribes it badly)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
-            else:
-                q = int(txt[0])
-                if q > 0:
-                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                    n = min(n, max(1, int(q / per + 0.5)))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return max(1, n)
-
-
 def cpu_baseline(budget_s=12.0, mlp=None):
     """The CPU restatement (oracle/, OpenMP over samples) timed on this box's host cores on a bounded
     sample of the SAME workload: whole control steps (noise + rollouts + update) at H=64 —
     K=65536 for the analytic model, K=4096 for the MLP (stated in `sample`)."""
     from oracle import oracle as orc
-    orc.set_num_threads(min(orc.num_threads(), usable_cpus()))
     K_PER_GPU = 65536 if mlp is None else 4096
     p = orc.Problem(tau=H, s=S, a=A, dt=0.1, mass=1.0, lam=1.0, sigma=SIGMA, goal=GOAL, threads=0, mlp=mlp)
     x, U = np.zeros(S, np.float32), np.zeros((H, A), np.float32)

@@ -86,6 +86,10 @@ def _get(dtype):
     if _lib is None:
         build()
         _lib = C.CDLL(_SO)
+        # size the OpenMP team to the CPUs this job may really use (see usable_cpus)
+        _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_set_num_threads.argtypes = [C.c_int]
+        _lib.orc_set_num_threads(min(int(_lib.orc_num_threads()), usable_cpus()))
     key = np.dtype(dtype).name
     if key not in _insts:
         if key == "float32":
@@ -95,6 +99,27 @@ def _get(dtype):
         else:
             raise ValueError(dtype)
     return _insts[key]
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box gives one
+    job a share of a many-core host; OpenMP's default of one thread per visible core then oversubscribes it badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
 
 
 def num_threads():

@@ -24,9 +24,7 @@ def mlp3():
     return dict(W=W, b=b)
 
 
-import bench  # noqa: E402  (usable_cpus: affinity mask and cgroup quota)
-
-ALL = min(orc.num_threads(), bench.usable_cpus())
+ALL = min(orc.num_threads(), orc.usable_cpus())
 
 
 def run(name, K, H, a, threads, budget, mlp=None):
@@ -50,7 +48,7 @@ def run(name, K, H, a, threads, budget, mlp=None):
 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
-    print("host cores: %d visible, %d usable by this job (affinity / cgroup quota) -> OpenMP threads %d" % (os.cpu_count(), bench.usable_cpus(), ALL))
+    print("host cores: %d visible, %d usable by this job (affinity / cgroup quota) -> OpenMP threads %d" % (os.cpu_count(), orc.usable_cpus(), ALL))
     for name, K, H, a, mlp in [("C1 point_mass1d", 128, 32, 1, None), ("C2 point_mass2d", 4096, 64, 2, None),
                                ("C3 point_mass3d", 65536, 64, 3, None), ("C4 point_mass3d + MLP (reduced K)", 2048, 64, 3, mlp3())]:
         for threads in (1, 0):
