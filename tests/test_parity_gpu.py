@@ -692,6 +692,13 @@ def test_direct_exchange_deadline_instead_of_hang(m):
         hs[1].p2p_attach(ptrs[::-1], timeout_ms=50)  # own entry must be the own inbox
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_direct_exchange_across_processes_over_hipipc():
     """Two processes on this GPU (gloo rendezvous): inboxes exported with hipIpcGetMemHandle, mapped by the peer,
     self-test + vote, then ShardedController steps; both ranks must produce the single-process result."""
@@ -701,7 +708,7 @@ def test_direct_exchange_across_processes_over_hipipc():
     from conftest import ROOT
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MPPI_EXCHANGE="p2p")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.join(ROOT, "tests", "p2p_worker.py")], capture_output=True, text=True,
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "p2p_worker.py")], capture_output=True, text=True,
                        timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("P2P_WORKER_OK") == 2, r.stdout[-3000:] + r.stderr[-3000:]
