@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """The reference's Python entry point (scripts/main.py:13-121) against the MI355X control step:
-   python examples/main.py --new --config examples/config/point_mass3d.yaml --task examples/config/static_task3d.yaml -s 200
+   python examples/main.py --new --config examples/config/point_mass3d.yaml --task examples/config/static_task3d.yaml -s 200 -l --log_dir runs/a
+   python examples/main.py --replay --log_dir runs/a/controller
 parses the same YAML keys, builds Simulation / PointMassModel / StaticCost / ControllerBase with the
-reference's constructor arguments, runs the closed loop, and writes the transition log as CSV."""
+reference's constructor arguments, runs the closed loop, and writes the transition log as CSV.
+--new / --replay are the reference's mutually exclusive modes (main.py:17-24): with -l the run's config and task are
+dumped as <log_dir>/controller/{config,task}.yaml (what ObserverBase does, observer_base.py:39-54), and --replay reads
+exactly those two files back (utile.py:53-59 parse_dir) and repeats the experiment — same seed, same Philox stream,
+so the replayed transitions are bit-identical."""
 import argparse
 import os
 import sys
@@ -16,9 +21,32 @@ import mppi_tf_amd as m  # noqa: E402
 from mppi_tf_amd.simulation import Simulation  # noqa: E402
 
 
-def parse_config(path):  # scripts/src/misc/utile.py:41-51
+def parse_config(path):  # scripts/src/misc/utile.py:41-44
     with open(path) as fh:
         return yaml.safe_load(fh)
+
+
+def parse_dir(log_dir):  # scripts/src/misc/utile.py:47-59: the config.yaml / task.yaml a logged run left behind
+    config_file = task_file = None
+    for name in os.listdir(log_dir):
+        if not os.path.isfile(os.path.join(log_dir, name)):
+            continue
+        if name == "config.yaml":
+            config_file = os.path.join(log_dir, name)
+        elif name == "task.yaml":
+            task_file = os.path.join(log_dir, name)
+    if config_file is None or task_file is None:
+        raise FileNotFoundError("%s holds no config.yaml / task.yaml (a run logged with -l writes them)" % log_dir)
+    return parse_config(config_file), task_file
+
+
+def write_log_dir(log_path, conf, task):  # observer_base.py:39-54
+    logdir = os.path.join(log_path, "controller")
+    os.makedirs(logdir, exist_ok=True)
+    for name, d in (("config.yaml", conf), ("task.yaml", task)):
+        with open(os.path.join(logdir, name), "w") as fh:
+            yaml.dump(d, fh)
+    return logdir
 
 
 def get_cost(task_file, lam, gamma, upsilon, sigma):  # scripts/src/cost.py:51-64, "static" branch
@@ -32,13 +60,31 @@ def get_cost(task_file, lam, gamma, upsilon, sigma):  # scripts/src/cost.py:51-6
 
 def main():
     ap = argparse.ArgumentParser(prog="mppi", description="mppi on MI355X")
-    ap.add_argument("--new", action="store_true", help="expects a config and a task file")
-    ap.add_argument("--config", type=str, required=True)
-    ap.add_argument("--task", type=str, required=True)
+    group = ap.add_mutually_exclusive_group(required=True)  # main.py:17-24
+    group.add_argument("--replay", action="store_true", help="replay the experiment a log dir describes")
+    group.add_argument("--new", action="store_true", help="expects a config and a task file")
+    ap.add_argument("--log_dir", type=str, help="--replay: the logged run's directory (holding config.yaml and task.yaml); "
+                                                "--new -l: where <log_dir>/controller/ is created")
+    ap.add_argument("--config", type=str)
+    ap.add_argument("--task", type=str)
+    ap.add_argument("-l", "--log", action="store_true", help="leave config.yaml / task.yaml (and the CSV) in the log dir")
     ap.add_argument("-s", "--steps", type=int, default=200)
-    ap.add_argument("--csv", type=str, default=None, help="write the (x, u, x_next) log here (DataBase::toCSV)")
+    ap.add_argument("--csv", type=str, default=None, help="write the (x, u, x_next) log here (DataBase::toCSV's bytes)")
     args = ap.parse_args()
-    conf = parse_config(args.config)
+    if args.new:
+        if not args.config or not args.task:
+            ap.error("--new expects --config and --task")
+        conf = parse_config(args.config)
+    else:
+        if not args.log_dir:
+            ap.error("--replay expects --log_dir")
+        conf, args.task = parse_dir(args.log_dir)
+    if args.log:
+        if not args.log_dir:
+            ap.error("-l expects --log_dir")
+        logdir = write_log_dir(args.log_dir, conf, parse_config(args.task))
+        if args.csv is None:
+            args.csv = os.path.join(logdir, "transitions.csv")
     s_dim, a_dim = conf["state-dim"], conf["action-dim"]
     sim = Simulation(conf.get("env"), s_dim, a_dim, None, False, dt=conf["dt"], mass=conf.get("mass", 1.0))
     model = m.PointMassModel(conf.get("mass", 1.0), conf["dt"], s_dim, a_dim)

@@ -23,12 +23,17 @@ public:
         mppi_config cfg;
         mppi_detail::check(mppi_config_init(&cfg, k, tau, dt, 1.f, s_dim, a_dim), nullptr, "mppi_config_init");
         mppi_detail::check(mppi_create(&cfg, &m_h), nullptr, "mppi_create");
+        // the reference's next() appends (x, u) to m_db on every call (controller_base.cpp:146-147): the log is on,
+        // as a ring of kLogRows transitions (the reference's vectors grow without bound)
+        mppi_detail::check(mppi_set_transition_log(m_h, kLogRows), m_h, "mppi_set_transition_log");
     }
+    static constexpr int kLogRows = 1 << 16;
     // everything the reference hard-codes, as the caller's mppi_config (K-sharding, Σ, goal, seed, ...)
     explicit ControllerBase(const mppi_config &cfg)
         : m_k(cfg.k), m_tau(cfg.tau), m_s_dim(cfg.s_dim), m_a_dim(cfg.a_dim), m_dt(cfg.dt), m_mass(cfg.mass)
     {
         mppi_detail::check(mppi_create(&cfg, &m_h), nullptr, "mppi_create");
+        mppi_detail::check(mppi_set_transition_log(m_h, kLogRows), m_h, "mppi_set_transition_log");
     }
     ControllerBase(const ControllerBase &) = delete;
     ControllerBase &operator=(const ControllerBase &) = delete;

@@ -45,7 +45,8 @@ typedef enum {
     MPPI_ERR_UNSUPPORTED = 4,    /* shape / option outside what the kernels implement */
     MPPI_ERR_SINGULAR_SIGMA = 5, /* Σ not invertible (ref: MatrixInverse fails, cost_base.cpp:39) */
     MPPI_ERR_ALLOC = 6,
-    MPPI_ERR_IO = 7
+    MPPI_ERR_IO = 7,
+    MPPI_ERR_EXCHANGE = 8        /* direct record exchange: a packet missed its deadline (mppi_shard_p2p_step) */
 } mppi_status;
 
 enum { MPPI_MODEL_POINT_MASS = 0, /* x' = A x + (B/m) v, src/model_base.cpp:53-82 */
@@ -61,7 +62,10 @@ enum { MPPI_FLAG_UPSILON_SCALES_NOISE = 1, /* Py build_noise: eps = (υΣ)·z wh
                                    fp32 operand split into two bf16 values and three products per term (fp32
                                    accumulate): ~2x the rounding error of the exact-fp32 path (sample costs within
                                    1e-6 relative of fp64 on the synthetic network), several times its speed. Off by
-                                   default: the default MLP path is exact fp32 (v_mfma_f32_32x32x2_f32). */ };
+                                   default: the default MLP path is exact fp32 (v_mfma_f32_32x32x2_f32). */,
+       MPPI_FLAG_MLP_BF16X3_PIPELINED = 4 /* implies MPPI_FLAG_MLP_BF16X3: the two-set software-pipelined form of that
+                                   kernel (128 rollouts per workgroup, one set's scalar chain inside the other's MFMA
+                                   stream); sample costs bit-identical to MPPI_FLAG_MLP_BF16X3. */ };
 
 /* what mppi_debug_get returns (observer_base.py:101-187 logs the same intermediates) */
 enum { MPPI_DBG_COSTS = 0,    /* c[K_local]         sample costs of the last step            */
@@ -135,9 +139,20 @@ mppi_status mppi_next(mppi_handle *h, const float *x, int n_x, float *u_out, int
  * test_controller.cpp:24-35): eps is [K_local, tau, a] for this handle's shard. */
 mppi_status mppi_next_with_noise(mppi_handle *h, const float *x, int n_x, const float *eps, size_t n_eps,
                                  float *u_out, int n_u);
-/* replaces ControllerBase::saveNext / toCSV (controller_base.cpp:155-164) — host bookkeeping */
+/* The transition log (m_db, data_base.cpp:14-71). The reference appends to it on every next(); here it is a
+ * preallocated ring of max_rows rows that must be switched on (the C++ / Python ControllerBase mirrors do so in their
+ * constructors): 0 = off (default, nothing is recorded and mppi_next allocates nothing). Clears the log. When full
+ * the oldest row is overwritten. */
+mppi_status mppi_set_transition_log(mppi_handle *h, int max_rows);
+/* replaces ControllerBase::saveNext (controller_base.cpp:155-163): x_next is the successor of the LAST logged (x, u);
+ * a row whose saveNext was skipped is left out of the CSV instead of shifting the later rows. */
 mppi_status mppi_save_next(mppi_handle *h, const float *x_next, int n);
+/* replaces ControllerBase::toCSV -> DataBase::toCSV (controller_base.cpp:164, data_base.cpp:52-71), byte for byte:
+ * header cells and values each followed by ',' (lines end with a comma), values as std::to_string(float) = "%f". */
 mppi_status mppi_to_csv(mppi_handle *h, const char *filename);
+enum { MPPI_CSV_REFERENCE = 0,  /* the reference's bytes (see mppi_to_csv)                     */
+       MPPI_CSV_ROUNDTRIP = 1 };/* "%.9g" values (fp32 round-trips), no trailing commas        */
+mppi_status mppi_to_csv_format(mppi_handle *h, const char *filename, int format);
 
 /* ---- options of the Python reference's update ------------------------- */
 /* clip_act (controller_base.py:500-504; the call at :453 is commented out in the reference, so off
@@ -221,8 +236,14 @@ mppi_status mppi_synchronize(mppi_handle *h);
  *   mppi_shard_p2p_probe    one self-test round (known payload, same stores/spins); run it a few
  *                           times on every rank and agree on the outcome before trusting the path
  * then per control step mppi_shard_p2p_step on every rank (same number of calls everywhere: packets
- * carry a call sequence number). Every spin has a deadline (timeout_ms at attach): on expiry the
- * step completes with garbage and mppi_shard_p2p_status reports it; nothing hangs. */
+ * carry a call sequence number). Every spin has a deadline (timeout_ms at attach); nothing hangs and nothing is
+ * filled with garbage: a finish-kernel workgroup whose packets did not all arrive applies a ZERO update to its column
+ * of U (the sequence still shifts, the step counter still advances) and raises a flag; launches already queued behind
+ * it skip the exchange (zero updates); the next mppi_shard_p2p_step call returns MPPI_ERR_EXCHANGE and so does every
+ * later one (the direct path is closed for the handle). Controls returned since the failing step are zero-update
+ * controls, and U / the step counter may then differ between ranks: re-synchronise them (mppi_get/set_action_sequence,
+ * mppi_get/set_step_counter from one rank) and continue with mppi_shard_partial / mppi_shard_finish, which is what
+ * ShardedController.resync does. */
 #define MPPI_MAX_SHARD_PEERS 16
 #define MPPI_IPC_HANDLE_BYTES 64
 mppi_status mppi_shard_p2p_export(mppi_handle *h, void *ipc_handle_out /* 64 B, may be NULL */, void **inbox_dev_out);
@@ -233,9 +254,20 @@ mppi_status mppi_shard_p2p_attach(mppi_handle *h, void *const *inboxes, int n, i
 mppi_status mppi_shard_p2p_probe(mppi_handle *h, void *stream, int *ok_out);
 /* One whole sharded step, enqueue only: rollouts of this shard, exchange, update; x_dev[s] -> u_dev[a]. */
 mppi_status mppi_shard_p2p_step(mppi_handle *h, const float *x_dev, float *u_dev, void *stream);
-/* timed_out = 1 if any spin of any step since attach hit its deadline (read after synchronising
- * the stream the steps ran on). */
+/* timed_out = 1 if any spin of any step since attach hit its deadline (complete for a step once the stream it ran
+ * on has been synchronised). */
 mppi_status mppi_shard_p2p_status(mppi_handle *h, int *timed_out);
+
+/* ---- diagnostic switches (A/B timing, fault injection for the fallback tests) ----------------
+ * Never needed for correct operation. The library reads NO environment variable: what a process inherits cannot
+ * change kernels or inject faults; these calls are the only way. */
+enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instead of the producer/consumer one          */
+       MPPI_TUNE_PC_PRODUCERS = 1,      /* 3 or 5 producer waves per workgroup (default: by tiles per CU)               */
+       MPPI_TUNE_PC_BALANCE = 2,        /* 0: no SIMD-true role placement / progress priorities                         */
+       MPPI_TUNE_PC_LDS_MIN = 3,        /* pad the rollout kernel's LDS to this many bytes (caps workgroups per CU)     */
+       MPPI_TUNE_SYNC_SPIN = 4,         /* 0: mppi_next waits for the stream instead of watching the pinned u slot      */
+       MPPI_TUNE_P2P_FAULT = 5 };       /* 1: inbox export fails, 2: probe reports failure (exercise the RCCL fallback) */
+mppi_status mppi_set_tuning(mppi_handle *h, int what, int value);
 
 /* ---- measurement (the reference only has a commented-out chrono loop, main.cpp:55-64) ------ */
 /* Bracket the rollout kernel and the finish kernel of the next <= max_steps steps with HIP

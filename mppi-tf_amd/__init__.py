@@ -10,10 +10,10 @@ hand-written HIP for gfx950 in csrc/, reached through the C-ABI of include/mppi_
   distributed.py   K-sharding across GPUs (one process per GPU, one all-gather per step)
 """
 from . import build as _build  # noqa: F401
-from ._lib import (ACTION_COST_CPP, ACTION_COST_PY, DBG_BETA, DBG_COSTS, DBG_ETA, DBG_NOISE, DBG_U_UPDATED,
-                   DBG_WEIGHTS, Handle, MppiError, load)
+from ._lib import (ACTION_COST_CPP, ACTION_COST_PY, CSV_REFERENCE, CSV_ROUNDTRIP, DBG_BETA, DBG_COSTS, DBG_ETA, DBG_NOISE,
+                   DBG_U_UPDATED, DBG_WEIGHTS, Handle, MppiError, load)
 from .controller import ControllerBase, ControllerBaseCpp, CostBase, PointMassModel, StaticCost
 
 __all__ = ["Handle", "MppiError", "load", "ControllerBase", "ControllerBaseCpp", "CostBase", "PointMassModel",
            "StaticCost", "ACTION_COST_CPP", "ACTION_COST_PY", "DBG_COSTS", "DBG_BETA", "DBG_ETA", "DBG_WEIGHTS",
-           "DBG_NOISE", "DBG_U_UPDATED"]
+           "DBG_NOISE", "DBG_U_UPDATED", "CSV_REFERENCE", "CSV_ROUNDTRIP"]

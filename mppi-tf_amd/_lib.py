@@ -14,10 +14,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # MPPI_SO_PATH selects a variant build of the SAME library (tools/ablate.py); never a different backend.
 SO_PATH = os.environ.get("MPPI_SO_PATH") or os.path.join(HERE, "libmppi_hip.so")
 
-OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_SINGULAR_SIGMA, ERR_ALLOC, ERR_IO = range(8)
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_SINGULAR_SIGMA, ERR_ALLOC, ERR_IO, ERR_EXCHANGE = range(9)
 MODEL_POINT_MASS, MODEL_MLP = 0, 1
 ACTION_COST_CPP, ACTION_COST_PY = 0, 1
 DBG_COSTS, DBG_BETA, DBG_ETA, DBG_WEIGHTS, DBG_NOISE, DBG_U_UPDATED = range(6)
+CSV_REFERENCE, CSV_ROUNDTRIP = 0, 1
+# mppi_set_tuning items (diagnostics; the library reads no environment variable)
+TUNING = {"force_tile_kernel": 0, "pc_producers": 1, "pc_balance": 2, "pc_lds_min": 3, "sync_spin": 4, "p2p_fault": 5}
+P2P_FAULTS = {"": 0, "export": 1, "probe": 2}
 
 FP = C.POINTER(C.c_float)
 
@@ -62,6 +66,9 @@ SIGNATURES = {
     "mppi_next_with_noise": (C.c_int, [_H, FP, C.c_int, FP, C.c_size_t, FP, C.c_int]),
     "mppi_save_next": (C.c_int, [_H, FP, C.c_int]),
     "mppi_to_csv": (C.c_int, [_H, C.c_char_p]),
+    "mppi_to_csv_format": (C.c_int, [_H, C.c_char_p, C.c_int]),
+    "mppi_set_transition_log": (C.c_int, [_H, C.c_int]),
+    "mppi_set_tuning": (C.c_int, [_H, C.c_int, C.c_int]),
     "mppi_get_action_sequence": (C.c_int, [_H, FP, C.c_int]),
     "mppi_set_action_sequence": (C.c_int, [_H, FP, C.c_int]),
     "mppi_get_step_counter": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
@@ -131,16 +138,19 @@ class Handle:
     def __init__(self, k, tau, s_dim, a_dim, dt=0.1, mass=1.0, lam=1.0, gamma=1.0, upsilon=1.0,
                  sigma=None, goal=None, Q=None, q_is_full=None, action_cost=ACTION_COST_CPP,
                  normalize_cost=False, seed=1, device=0, shard_rank=0, shard_count=1, mlp=None,
-                 upsilon_scales_noise=False, mlp_bf16x3=False):
+                 upsilon_scales_noise=False, mlp_bf16x3=False, mlp_bf16x3_pipelined=False, tuning=None, log_rows=0):
         """mlp: dict(W=[W1,W2,W3], b=[b1,b2,b3], xmean=, xstd=, ymean=, ystd=) selects the learned
-        model_base (Dense(256,relu) x2 + Dense(s_dim); Keras [in x out] kernels)."""
+        model_base (Dense(256,relu) x2 + Dense(s_dim); Keras [in x out] kernels).
+        tuning: dict of diagnostic switches (keys of TUNING) applied with mppi_set_tuning right after creation.
+        log_rows: capacity of the transition log (mppi_set_transition_log); 0 = off."""
         lib = self.lib = load()
         cfg = Config()
         self._check(lib.mppi_config_init(C.byref(cfg), k, tau, dt, mass, s_dim, a_dim), None)
         cfg.lam, cfg.gamma, cfg.upsilon = lam, gamma, upsilon
         cfg.action_cost_kind, cfg.normalize_cost = action_cost, int(bool(normalize_cost))
         cfg.seed, cfg.device, cfg.shard_rank, cfg.shard_count = seed, device, shard_rank, shard_count
-        cfg.flags = (1 if upsilon_scales_noise else 0) | (2 if mlp_bf16x3 else 0)  # MPPI_FLAG_UPSILON_SCALES_NOISE | MPPI_FLAG_MLP_BF16X3
+        # MPPI_FLAG_UPSILON_SCALES_NOISE | MPPI_FLAG_MLP_BF16X3 | MPPI_FLAG_MLP_BF16X3_PIPELINED
+        cfg.flags = (1 if upsilon_scales_noise else 0) | (2 if (mlp_bf16x3 or mlp_bf16x3_pipelined) else 0) | (4 if mlp_bf16x3_pipelined else 0)
         keep = []
         if sigma is not None:
             keep.append(f32(sigma, (a_dim, a_dim)))
@@ -180,6 +190,18 @@ class Handle:
         self._stage = None
         self.k_offset = lib.mppi_sample_offset(self.h)
         self.record_size = lib.mppi_record_size(self.h)
+        for key, val in (tuning or {}).items():
+            self.set_tuning(key, val)
+        if log_rows:
+            self.set_transition_log(log_rows)
+
+    def set_tuning(self, key, value):
+        if key == "p2p_fault" and isinstance(value, str):
+            value = P2P_FAULTS[value]
+        self._check(self.lib.mppi_set_tuning(self.h, TUNING[key], int(value)))
+
+    def set_transition_log(self, max_rows):
+        self._check(self.lib.mppi_set_transition_log(self.h, int(max_rows)))
 
     def _check(self, st, h=True):
         if st != OK:
@@ -225,8 +247,9 @@ class Handle:
         x = f32(x_next).ravel()
         self._check(self.lib.mppi_save_next(self.h, fp(x), x.size))
 
-    def to_csv(self, filename):
-        self._check(self.lib.mppi_to_csv(self.h, os.fsencode(filename)))
+    def to_csv(self, filename, fmt=CSV_REFERENCE):
+        """DataBase::toCSV; fmt = CSV_REFERENCE (the reference's bytes) or CSV_ROUNDTRIP (%.9g, no trailing commas)"""
+        self._check(self.lib.mppi_to_csv_format(self.h, os.fsencode(filename), fmt))
 
     # ---- state -----------------------------------------------------------------------
     def get_action_sequence(self):

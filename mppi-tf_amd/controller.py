@@ -28,6 +28,9 @@ def _flat(x, n):
     return np.asarray(x, np.float32).reshape(-1, n)
 
 
+# capacity of the transition log the controller mirrors switch on (the reference's m_db grows without bound)
+LOG_ROWS = 1 << 16
+
 class PointMassModel:
     """x' = A x + (B/m) u ; A = I⊗[[1,dt],[0,1]], B = I⊗[[dt²/2],[dt]]  (point_mass_model.py:28-151,
     src/model_base.cpp:53-82). Positional signature is the one the reference's tests use
@@ -193,7 +196,7 @@ class ControllerBase:
                          action_cost=cost._action_cost_kind, normalize_cost=self._normalizeCost,
                          seed=seed, device=device,
                          # build_noise: noises = (υΣ)·z (controller_base.py:362-368); the cost keeps Σ⁻¹ of Σ
-                         upsilon_scales_noise=True)
+                         upsilon_scales_noise=True, log_rows=LOG_ROWS)
         if abs(getattr(cost, "upsilon", self._upsilon) - self._upsilon) > 0:
             raise AssertionError("controller and cost must be built with the same upsilon")
         initSeq = np.asarray(initSeq, np.float32)
@@ -296,6 +299,7 @@ class ControllerBaseCpp:
         self.m_k, self.m_tau, self.m_s_dim, self.m_a_dim, self.m_dt, self.m_mass = k, tau, s_dim, a_dim, dt, mass
         kw = dict(k=k, tau=tau, s_dim=s_dim, a_dim=a_dim, dt=dt, mass=1.0, device=device, seed=seed)
         kw.update(overrides)
+        kw.setdefault("log_rows", LOG_ROWS)  # m_db.addX / addU on every next(), controller_base.cpp:146-147
         self._h = Handle(**kw)
 
     def next(self, x):
@@ -314,4 +318,4 @@ class ControllerBaseCpp:
         self._h.save_next(x_next)
 
     def toCSV(self, filename):
-        self._h.to_csv(filename)
+        self._h.to_csv(filename)  # DataBase::toCSV's bytes (data_base.cpp:36-71)

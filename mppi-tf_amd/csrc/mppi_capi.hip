@@ -34,8 +34,15 @@ struct mppi_handle {
     size_t tile_lds = 0;
     int normalize = 0;
     int sigma_diag = 0; // Σ and Σ⁻¹ are exactly diagonal (the DIAG kernel instances are bit-identical then)
-    int pc_np = 5;      // producer waves per workgroup of k_rollout_pc (MPPI_PC_PRODUCERS=3 selects the 4-wave variant)
-    int force_tile = 0; // MPPI_FORCE_TILE_KERNEL=1: run the LDS-tile kernel instead of the producer/consumer one (A/B timing)
+    int pc_np = 5;      // producer waves per workgroup of k_rollout_pc (chosen by tiles per CU; MPPI_TUNE_PC_PRODUCERS overrides)
+    // diagnostic switches, set only through mppi_set_tuning (the library reads no environment variable)
+    int force_tile = 0;   // MPPI_TUNE_FORCE_TILE_KERNEL: the LDS-tile kernel instead of the producer/consumer one (A/B timing)
+    int pc_no_balance = 0; // MPPI_TUNE_PC_BALANCE = 0: no SIMD-true roles / progress priorities
+    int pc_lds_min = 0;   // MPPI_TUNE_PC_LDS_MIN: pad the dynamic LDS (caps workgroups per CU)
+    int sync_spin = 1;    // MPPI_TUNE_SYNC_SPIN: the synchronous step watches the pinned u slot (0: waits for the stream)
+    int p2p_fault = 0;    // MPPI_TUNE_P2P_FAULT: 1 = inbox export refused, 2 = probe reports failure (fallback tests)
+    unsigned attr_done = 0; // kernels whose dynamic-LDS ceiling has been raised ON THIS HANDLE'S DEVICE (bit per kernel family)
+    size_t tile_attr_set = 0;
     float *d_x = nullptr, *d_u = nullptr, *d_cost = nullptr, *d_cost2 = nullptr;
     // The nominal sequence lives in one of two buffers of tau*a + a floats whose last a floats stay zero. A step
     // reads U from ubuf[u_cur] + u_off and writes U' to the other buffer at offset 0; the shifted sequence
@@ -67,8 +74,11 @@ struct mppi_handle {
     // carry the dispatch's own begin/end timestamps (what rocprofv3 reports), not the stream-level gaps around it
     hipEvent_t kev0 = nullptr, kev1 = nullptr;
     std::string no_rollout; // non-empty: why this handle cannot run rollouts (helpers still work)
-    // transition log (m_db of the reference: addX/addU/addNext/toCSV, data_base.cpp:29-71)
-    std::vector<float> log_x, log_u, log_next;
+    // transition log (m_db of the reference: addX/addU/addNext/toCSV, data_base.cpp:29-71): off until
+    // mppi_set_transition_log gives it a capacity; a ring of rows (x | u | x_next | has_next), allocated once there
+    std::vector<float> log_rows;
+    size_t log_cap = 0, log_count = 0, log_head = 0; // capacity in rows, rows held, index of the oldest row
+    size_t log_stride() const { return (size_t)2 * s + a + 1; }
     // direct record exchange (mppi_shard_p2p_*): own inbox, the peers' mapped inboxes, call sequence number
     unsigned long long *xchg_inbox = nullptr;
     XchgPeers xchg_peers{};
@@ -76,7 +86,8 @@ struct mppi_handle {
     bool xchg_attached = false;
     unsigned xchg_seq = 0, probe_seq = 0;
     long long xchg_timeout_ticks = 0;
-    unsigned *h_xchg_status = nullptr, *d_xchg_status = nullptr; // pinned, device-mapped
+    unsigned *h_xchg_status = nullptr, *d_xchg_status = nullptr; // pinned, device-mapped: deadline flag for the host
+    unsigned *d_xchg_dead = nullptr;                             // the same flag in device memory, read by every launch
     float *d_probe_got = nullptr;
     size_t xchg_step_slots() const { return (size_t)2 * HA * shard_count * 3; }
     size_t xchg_inbox_bytes() const { return sizeof(unsigned long long) * (xchg_step_slots() + (size_t)2 * shard_count); }
@@ -114,6 +125,7 @@ extern "C" const char *mppi_status_string(mppi_status st)
     case MPPI_ERR_SINGULAR_SIGMA: return "sigma is singular";
     case MPPI_ERR_ALLOC: return "allocation failed";
     case MPPI_ERR_IO: return "i/o error";
+    case MPPI_ERR_EXCHANGE: return "direct exchange deadline missed";
     }
     return "unknown status";
 }
@@ -193,6 +205,7 @@ extern "C" void mppi_destroy(mppi_handle *h)
     for (void *p : h->xchg_opened) (void)hipIpcCloseMemHandle(p);
     if (h->xchg_inbox) (void)hipFree(h->xchg_inbox);
     if (h->h_xchg_status) (void)hipHostFree(h->h_xchg_status);
+    if (h->d_xchg_dead) (void)hipFree(h->d_xchg_dead);
     if (h->d_probe_got) (void)hipFree(h->d_probe_got);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -237,11 +250,9 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     if (h->K_local <= 0) { delete h; return fail(nullptr, MPPI_ERR_INVALID_ARG, "shard owns no samples"); }
     h->H = cfg->tau; h->s = s; h->a = a; h->HA = cfg->tau * a;
     h->normalize = cfg->normalize_cost;
-    { const char *e = std::getenv("MPPI_FORCE_TILE_KERNEL"); h->force_tile = (e && e[0] == '1') ? 1 : 0; }
     // 5 producers shorten a lone tile's pipeline (15.6 vs 18.3 us at 1 tile/CU) but cost throughput once
-    // >= 4 tiles share a CU (the kernel is VALU-issue bound there): pick by tiles per CU. MPPI_PC_PRODUCERS overrides.
+    // >= 4 tiles share a CU (the kernel is VALU-issue bound there): pick by tiles per CU.
     h->pc_np = ((h->K_local + 63) / 64 <= 2 * 256) ? 5 : 3;
-    { const char *e = std::getenv("MPPI_PC_PRODUCERS"); if (e && (e[0] == '3' || e[0] == '5')) h->pc_np = e[0] - '0'; }
 
     DevConsts &c = h->hc;
     c.K_local = h->K_local; c.k_offset = h->k_offset; c.H = h->H; c.s = s; c.a = a;
@@ -297,9 +308,8 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     h->R = R; h->nb = (h->K_local + R - 1) / R; h->tile_lds = tile_lds_floats(h->HA, R) * 4;
     h->nb_mlp = cfg->model_kind == MPPI_MODEL_MLP ? (h->K_local + kMlpR - 1) / kMlpR : 0;
     h->mlp_bx3 = (cfg->model_kind == MPPI_MODEL_MLP && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) ? 1 : 0;
-    if (getenv("MPPI_MLP_BF16X3") && cfg->model_kind == MPPI_MODEL_MLP) h->mlp_bx3 = atoi(getenv("MPPI_MLP_BF16X3")) != 0; // A/B runs
     // the two-set software-pipelined variant (k_rollout_mlp_bx3p): 128 rollouts per workgroup
-    if (h->mlp_bx3 && getenv("MPPI_MLP_BX3_PIPE") && atoi(getenv("MPPI_MLP_BX3_PIPE")) != 0) {
+    if (cfg->model_kind == MPPI_MODEL_MLP && (cfg->flags & MPPI_FLAG_MLP_BF16X3_PIPELINED)) {
         h->mlp_bx3 = 2;
         h->nb_mlp = (h->K_local + kMlpR2 - 1) / kMlpR2;
     }
@@ -367,11 +377,11 @@ static hipError_t launch_tile_inst(mppi_handle *h, hipStream_t st, const float *
                                    const float *eps, float *cost, float *part, float *noise_out)
 {
     auto kern = k_rollout_tile<A, R, QFULL, SRC, MODE>;
-    static thread_local size_t attr_set = 0; // raise the dynamic-LDS ceiling above 64 KiB once per size
-    if (h->tile_lds > 48 * 1024 && attr_set < h->tile_lds) {
+    // raise the dynamic-LDS ceiling above the default: per launch (the attribute belongs to the (kernel, device) pair and
+    // several handles / devices share a template instance; the call is a table update on the host, ~0.2 us)
+    if (h->tile_lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tile_lds);
         if (e != hipSuccess) return e;
-        attr_set = h->tile_lds;
     }
     hipLaunchKernelGGL(kern, dim3(h->nb), dim3(kThreads), h->tile_lds, st, h->dC, x_dev, U_dev, eps, h->d_step, cost, part, noise_out, 1, h->nb);
     return hipGetLastError();
@@ -389,6 +399,7 @@ static hipError_t launch_tile_ar(mppi_handle *h, hipStream_t st, int src, int mo
     MPPI_TILE_CASE(SRC_HBM, MODE_COSTS_GIVEN)
     MPPI_TILE_CASE(SRC_PHILOX, MODE_COST_ONLY)
     MPPI_TILE_CASE(SRC_HBM, MODE_COST_ONLY)
+    MPPI_TILE_CASE(SRC_PHILOX, MODE_NOISE_ONLY)
 #undef MPPI_TILE_CASE
     return hipErrorInvalidValue;
 }
@@ -425,14 +436,12 @@ static hipError_t launch_tile(mppi_handle *h, hipStream_t st, int src, int mode,
 template <int A, int NP, int NSLOT>
 static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_dev)
 {
-    static const size_t lds_min = getenv("MPPI_PC_LDS_MIN") ? (size_t)atol(getenv("MPPI_PC_LDS_MIN")) : 0; // tuning knob: caps workgroups per CU
-    const size_t lds = std::max(pc_lds_floats(A, NP) * 4, lds_min);
+    const size_t lds = std::max(pc_lds_floats(A, NP) * 4, (size_t)h->pc_lds_min);
     const int nb = (h->K_local + 63) / 64;
     const dim3 g(nb), b(64 * (NP + 1));
     // tile records go out column-major ([2+HA][nb]): the finish kernel reads one column per workgroup
     // one round of workgroups (<= 4 per CU, all resident from the start): SIMD-true roles + progress priorities
-    static const int no_balance = getenv("MPPI_PC_NO_BALANCE") ? atoi(getenv("MPPI_PC_NO_BALANCE")) : 0; // A/B timing
-    const int balance = (nb <= 4 * 256 && !no_balance) ? 1 : 0;
+    const int balance = (nb <= 4 * 256 && !h->pc_no_balance) ? 1 : 0;
     const DevConsts *dC = h->dC;
     const float *U = h->U_cur();
     const unsigned long long *stp = h->d_step;
@@ -475,11 +484,10 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
 #define MPPI_MLP_L(KERN, BIT)                                                                                           \
     do {                                                                                                                \
         auto kern = KERN;                                                                                               \
-        static thread_local int attr_done = 0;                                                                          \
-        if (!(attr_done & BIT)) {                                                                                       \
+        if (!(h->attr_done & BIT)) { /* per handle = per device: the attribute belongs to the (kernel, device) pair */    \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e_ != hipSuccess) return e_;                                                                            \
-            attr_done |= BIT;                                                                                           \
+            h->attr_done |= BIT;                                                                                        \
         }                                                                                                               \
         hipExtLaunchKernelGGL(kern, g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, x_dev, U_dev, eps, \
                               (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp);                \
@@ -528,7 +536,7 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
     if (xchg)
         hipLaunchKernelGGL(k_finish_cols_xchg, dim3(h->HA), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
                            U_in, U_out, u_out, h->d_step, h->d_dbg, h->xchg_peers, h->shard_count, h->shard_rank, ++h->xchg_seq,
-                           h->xchg_timeout_ticks, h->d_xchg_status, h->d_clip);
+                           h->xchg_timeout_ticks, h->d_xchg_status, h->d_xchg_dead, h->d_clip);
     else
         hipLaunchKernelGGL(k_finish_cols, dim3(h->HA), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
                            U_in, U_out, u_out, record_out, apply, h->d_step, h->d_dbg, h->d_clip);
@@ -668,8 +676,11 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
     if (h->shard_count != 1) return fail(h, MPPI_ERR_UNSUPPORTED, "normalize_cost needs the global max cost: unsharded handles only");
     // Py normalizeCost (controller_base.py:468-474): costs, global min/max, then the update on
     // c' = (c-min)/(max-min) with the SAME noise (regenerated from the same Philox counters).
+    const bool prof_n = h->prof_n < h->prof_cap; // a profiled step brackets the cost pass (the dominant launch) here
+    if (prof_n) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 0], st));
     if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost));
     else HIP_TRY(h, launch_tile(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out));
+    if (prof_n) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 1], st));
     hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(kFinishThreads), 0, st, h->d_cost, h->K_local, h->d_mm);
     HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(k_cost_normalize, dim3((h->K_local + 255) / 256), dim3(256), 0, st, h->d_cost, h->K_local, h->d_mm, h->d_cost2);
@@ -786,8 +797,8 @@ extern "C" mppi_status mppi_shard_p2p_export(mppi_handle *h, void *ipc_handle_ou
 {
     if (!h || !inbox_dev_out) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL inbox_dev_out") : MPPI_ERR_INVALID_ARG;
     if (h->shard_count > kMaxPeers) return fail(h, MPPI_ERR_UNSUPPORTED, "direct exchange supports at most 16 shards");
-    // fault injection for the fallback tests: MPPI_P2P_FAULT=export|probe
-    if (getenv("MPPI_P2P_FAULT") && !strcmp(getenv("MPPI_P2P_FAULT"), "export")) return fail(h, MPPI_ERR_HIP, "injected fault: inbox export refused");
+    // fault injection for the fallback tests: mppi_set_tuning(MPPI_TUNE_P2P_FAULT, 1 = export | 2 = probe)
+    if (h->p2p_fault == 1) return fail(h, MPPI_ERR_HIP, "injected fault: inbox export refused");
     HIP_TRY(h, hipSetDevice(h->device));
     if (!h->xchg_inbox) {
         // uncached: peer stores land in memory and the local spin loads see them without any cache maintenance
@@ -796,6 +807,8 @@ extern "C" mppi_status mppi_shard_p2p_export(mppi_handle *h, void *ipc_handle_ou
         HIP_TRY(h, hipHostMalloc((void **)&h->h_xchg_status, sizeof(unsigned), hipHostMallocMapped));
         *h->h_xchg_status = 0u;
         HIP_TRY(h, hipHostGetDevicePointer((void **)&h->d_xchg_status, h->h_xchg_status, 0));
+        HIP_TRY(h, hipMalloc((void **)&h->d_xchg_dead, sizeof(unsigned)));
+        HIP_TRY(h, hipMemset(h->d_xchg_dead, 0, sizeof(unsigned)));
         HIP_TRY(h, hipMalloc((void **)&h->d_probe_got, sizeof(float) * kMaxPeers));
         HIP_TRY(h, hipDeviceSynchronize());
     }
@@ -848,14 +861,14 @@ extern "C" mppi_status mppi_shard_p2p_probe(mppi_handle *h, void *stream, int *o
     const int G = h->shard_count;
     auto payload = [&](int g) { return (float)(1000 * (int)(seq % 1000u) + g + 1); };
     hipLaunchKernelGGL(k_xchg_probe, dim3(1), dim3(64), 0, st, h->xchg_peers, h->xchg_step_slots(), G, h->shard_rank, seq,
-                       payload(h->shard_rank), h->xchg_timeout_ticks, h->d_xchg_status, h->d_probe_got);
+                       payload(h->shard_rank), h->xchg_timeout_ticks, h->d_xchg_status, h->d_xchg_dead, h->d_probe_got);
     HIP_TRY(h, hipGetLastError());
     float got[kMaxPeers];
     HIP_TRY(h, hipMemcpyAsync(got, h->d_probe_got, sizeof(float) * G, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     int ok = (*(volatile unsigned *)h->h_xchg_status & 1u) ? 0 : 1;
     for (int g = 0; g < G; ++g) ok &= got[g] == payload(g);
-    if (getenv("MPPI_P2P_FAULT") && !strcmp(getenv("MPPI_P2P_FAULT"), "probe")) ok = 0;
+    if (h->p2p_fault == 2) ok = 0;
     *ok_out = ok;
     return MPPI_OK;
 }
@@ -864,6 +877,10 @@ extern "C" mppi_status mppi_shard_p2p_step(mppi_handle *h, const float *x_dev, f
 {
     if (!h || !x_dev || !u_dev) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL device pointer") : MPPI_ERR_INVALID_ARG;
     if (!h->xchg_attached) return fail(h, MPPI_ERR_INVALID_ARG, "inboxes not attached");
+    // a deadline missed by any earlier step: refuse (the steps enqueued since then applied zero updates; U and the step
+    // counter may differ between ranks until they are re-synchronised — ShardedController.resync)
+    if (*(volatile unsigned *)h->h_xchg_status & 1u)
+        return fail(h, MPPI_ERR_EXCHANGE, "direct exchange: a packet missed its deadline; the direct path is closed for this handle");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     int nrec = 0;
@@ -903,8 +920,7 @@ static mppi_status step_host(mppi_handle *h, const float *x, int n_x, const floa
     const float *x_arg = h->d_pin + h->pin_slot * kMaxS;
     float *u_arg = h->d_pin + 2 * kMaxS;
     constexpr uint32_t kUSentinel = 0x7fc0deadu;
-    static const bool spin_env = !(getenv("MPPI_SYNC_SPIN") && atoi(getenv("MPPI_SYNC_SPIN")) == 0);
-    const bool spin_u = spin_env && h->sg_window == 0; // with a sequence filter the step has one more kernel after u
+    const bool spin_u = h->sync_spin && h->sg_window == 0; // with a sequence filter the step has one more kernel after u
     if (spin_u) for (int j = 0; j < h->a; ++j) reinterpret_cast<volatile uint32_t *>(h->h_pin + 2 * kMaxS)[j] = kUSentinel;
     int nrec = 0;
     mppi_status s = enqueue_partials(h, h->stream, src, x_arg, h->d_eps, nullptr, &nrec);
@@ -927,9 +943,17 @@ static mppi_status step_host(mppi_handle *h, const float *x, int n_x, const floa
     }
     if (!seen) HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::memcpy(u_out, h->h_pin + 2 * kMaxS, sizeof(float) * h->a);
-    // m_db.addX(s); m_db.addU(out_tensor[1])  controller_base.cpp:146-147
-    h->log_x.insert(h->log_x.end(), x, x + h->s);
-    h->log_u.insert(h->log_u.end(), u_out, u_out + h->a);
+    // m_db.addX(s); m_db.addU(out_tensor[1])  controller_base.cpp:146-147 — only when a log was asked for
+    // (mppi_set_transition_log): a preallocated ring, no allocation on this path
+    if (h->log_cap) {
+        size_t r;
+        if (h->log_count < h->log_cap) r = (h->log_head + h->log_count++) % h->log_cap;
+        else { r = h->log_head; h->log_head = (h->log_head + 1) % h->log_cap; } // full: the oldest row is overwritten
+        float *row = h->log_rows.data() + r * h->log_stride();
+        std::memcpy(row, x, sizeof(float) * h->s);
+        std::memcpy(row + h->s, u_out, sizeof(float) * h->a);
+        row[2 * h->s + h->a] = 0.0f; // x_next not known yet
+    }
     return MPPI_OK;
 }
 
@@ -944,30 +968,88 @@ extern "C" mppi_status mppi_next_with_noise(mppi_handle *h, const float *x, int 
     return step_host(h, x, n_x, eps, n_eps, u_out, n_u);
 }
 
+extern "C" mppi_status mppi_set_transition_log(mppi_handle *h, int max_rows)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (max_rows < 0) return fail(h, MPPI_ERR_INVALID_ARG, "max_rows must be >= 0");
+    try {
+        std::vector<float> rows((size_t)max_rows * h->log_stride());
+        h->log_rows.swap(rows);
+    } catch (const std::bad_alloc &) {
+        return fail(h, MPPI_ERR_ALLOC, "transition log: out of host memory");
+    }
+    h->log_cap = (size_t)max_rows; h->log_count = 0; h->log_head = 0;
+    return MPPI_OK;
+}
+
 extern "C" mppi_status mppi_save_next(mppi_handle *h, const float *x_next, int n)
 {
     if (!h) return MPPI_ERR_INVALID_ARG;
     if (!x_next || n != h->s) return fail(h, MPPI_ERR_INVALID_ARG, "x_next must have s_dim floats");
-    h->log_next.insert(h->log_next.end(), x_next, x_next + n); // m_db.addNext controller_base.cpp:159-163
+    if (!h->log_cap) return MPPI_OK; // logging is off
+    if (!h->log_count) return fail(h, MPPI_ERR_INVALID_ARG, "saveNext before the first next()");
+    // m_db.addNext controller_base.cpp:159-163: the successor of the LAST logged (x, u) — a skipped saveNext leaves that
+    // row without a successor (it is then not written) instead of shifting every later row
+    float *row = h->log_rows.data() + ((h->log_head + h->log_count - 1) % h->log_cap) * h->log_stride();
+    std::memcpy(row + h->s + h->a, x_next, sizeof(float) * h->s);
+    row[2 * h->s + h->a] = 1.0f;
     return MPPI_OK;
 }
 
-// data_base.cpp:52-71 toCSV: one row per transition, columns x | u | x_next.
-extern "C" mppi_status mppi_to_csv(mppi_handle *h, const char *filename)
+// data_base.cpp:36-71 toCSV: header x0,..,u0,..,x_next0,.. then one row per transition, columns x | u | x_next.
+// MPPI_CSV_REFERENCE writes the reference's exact bytes: every header cell and every value followed by a comma
+// (tensor2CSV / csvHeader append "," after each element, so lines END with a comma), values as std::to_string(float)
+// = "%f" (6 decimals). MPPI_CSV_ROUNDTRIP writes "%.9g" (fp32 round-trips) without the trailing comma.
+extern "C" mppi_status mppi_to_csv_format(mppi_handle *h, const char *filename, int format)
 {
     if (!h || !filename) return h ? fail(h, MPPI_ERR_INVALID_ARG, "filename is NULL") : MPPI_ERR_INVALID_ARG;
+    if (format != MPPI_CSV_REFERENCE && format != MPPI_CSV_ROUNDTRIP) return fail(h, MPPI_ERR_INVALID_ARG, "unknown CSV format");
+    if (!h->log_cap) return fail(h, MPPI_ERR_INVALID_ARG, "the transition log is off: call mppi_set_transition_log first");
     FILE *f = std::fopen(filename, "w");
     if (!f) return fail(h, MPPI_ERR_IO, std::string("cannot open ") + filename);
-    const size_t n = std::min(h->log_x.size() / h->s, std::min(h->log_u.size() / h->a, h->log_next.size() / h->s));
-    for (int i = 0; i < h->s; ++i) std::fprintf(f, "x%d,", i);
-    for (int i = 0; i < h->a; ++i) std::fprintf(f, "u%d,", i);
-    for (int i = 0; i < h->s; ++i) std::fprintf(f, "x_next%d%s", i, i + 1 < h->s ? "," : "\n");
-    for (size_t r = 0; r < n; ++r) {
-        for (int i = 0; i < h->s; ++i) std::fprintf(f, "%.9g,", h->log_x[r * h->s + i]);
-        for (int i = 0; i < h->a; ++i) std::fprintf(f, "%.9g,", h->log_u[r * h->a + i]);
-        for (int i = 0; i < h->s; ++i) std::fprintf(f, "%.9g%s", h->log_next[r * h->s + i], i + 1 < h->s ? "," : "\n");
+    const bool ref = format == MPPI_CSV_REFERENCE;
+    const int s = h->s, a = h->a;
+    for (int i = 0; i < s; ++i) std::fprintf(f, "x%d,", i);
+    for (int i = 0; i < a; ++i) std::fprintf(f, "u%d,", i);
+    for (int i = 0; i < s; ++i) std::fprintf(f, (ref || i + 1 < s) ? "x_next%d," : "x_next%d", i);
+    std::fputc('\n', f);
+    for (size_t q = 0; q < h->log_count; ++q) {
+        const float *row = h->log_rows.data() + ((h->log_head + q) % h->log_cap) * h->log_stride();
+        if (row[2 * s + a] == 0.0f) continue; // no successor recorded
+        const int n = 2 * s + a;
+        for (int i = 0; i < n; ++i) {
+            if (ref) std::fprintf(f, "%f,", (double)row[i]); // std::to_string(float)
+            else std::fprintf(f, i + 1 < n ? "%.9g," : "%.9g", (double)row[i]);
+        }
+        std::fputc('\n', f);
     }
-    std::fclose(f);
+    if (std::fclose(f) != 0) return fail(h, MPPI_ERR_IO, std::string("write failed: ") + filename);
+    return MPPI_OK;
+}
+
+// replaces ControllerBase::toCSV (controller_base.cpp:164): the reference's format
+extern "C" mppi_status mppi_to_csv(mppi_handle *h, const char *filename) { return mppi_to_csv_format(h, filename, MPPI_CSV_REFERENCE); }
+
+// diagnostic switches (A/B timing, fault injection for the fallback tests). The library reads NO environment variable:
+// what a process inherits cannot change kernels or inject faults.
+extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    switch (what) {
+    case MPPI_TUNE_FORCE_TILE_KERNEL: h->force_tile = value != 0; break;
+    case MPPI_TUNE_PC_PRODUCERS:
+        if (value != 3 && value != 5) return fail(h, MPPI_ERR_INVALID_ARG, "producer waves per workgroup: 3 or 5");
+        h->pc_np = value; break;
+    case MPPI_TUNE_PC_BALANCE: h->pc_no_balance = value == 0; break;
+    case MPPI_TUNE_PC_LDS_MIN:
+        if (value < 0 || value > 64 * 1024) return fail(h, MPPI_ERR_INVALID_ARG, "LDS bytes out of range (0..65536)");
+        h->pc_lds_min = value; break;
+    case MPPI_TUNE_SYNC_SPIN: h->sync_spin = value != 0; break;
+    case MPPI_TUNE_P2P_FAULT:
+        if (value < 0 || value > 2) return fail(h, MPPI_ERR_INVALID_ARG, "fault: 0 none, 1 export, 2 probe");
+        h->p2p_fault = value; break;
+    default: return fail(h, MPPI_ERR_INVALID_ARG, "unknown tuning item");
+    }
     return MPPI_OK;
 }
 
@@ -1051,7 +1133,8 @@ extern "C" mppi_status mppi_debug_get(mppi_handle *h, int what, float *out, size
         if (cur == 0) return fail(h, MPPI_ERR_INVALID_ARG, "no step has run yet");
         unsigned long long prev = cur - 1;
         HIP_TRY(h, hipMemcpyAsync(h->d_step, &prev, sizeof(prev), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, launch_tile(h, h->stream, SRC_PHILOX, MODE_COST_ONLY, h->d_x, h->U_cur(), nullptr, h->d_cost2, h->d_part, h->d_eps));
+        // noise-only pass of the tile kernel: reads neither x nor any cost buffer and writes nothing but d_eps
+        HIP_TRY(h, launch_tile(h, h->stream, SRC_PHILOX, MODE_NOISE_ONLY, h->d_x, h->U_cur(), nullptr, nullptr, nullptr, h->d_eps));
         HIP_TRY(h, hipMemcpyAsync(h->d_step, &cur, sizeof(cur), hipMemcpyHostToDevice, h->stream));
         src = h->d_eps;
         break;

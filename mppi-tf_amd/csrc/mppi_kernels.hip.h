@@ -12,7 +12,8 @@ enum NoiseSrc { SRC_PHILOX = 0, SRC_HBM = 1 };
 enum TileMode {
     MODE_ROLLOUT = 0,     // phase A + B (costs) + C (tile soft-min record)
     MODE_COSTS_GIVEN = 1, // phase A + C with costs read from `cost` (mUpdate on given costs; normalize pass 2)
-    MODE_COST_ONLY = 2    // phase A + B, no record (mBuildModelGraph alone; normalize pass 1)
+    MODE_COST_ONLY = 2,   // phase A + B, no record (mBuildModelGraph alone; normalize pass 1)
+    MODE_NOISE_ONLY = 3   // phase A + the noise export only: reads neither x nor cost, writes only noise_out (MPPI_DBG_NOISE)
 };
 
 // LDS floats a tile needs: eps[HA][R+1] (padded: lane-per-rollout reads AND lane-per-column reads
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
             if (k0 + kl < K) noise_out[slab + i] = eps_s[c * RP + kl];
         }
     }
+    if (MODE == MODE_NOISE_ONLY) return;
 
     // ---- phase B: one lane per rollout, wave 0 ---------------------------------------------
     if (tid < 64) {
@@ -589,59 +591,77 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols(
 //   on every rank, and bit-identical to the all-gather path (same floats through the same code).
 // No workgroup waits on anything a peer sends only after receiving from it (every send precedes the wait), so there is
 // no circular wait. Slot reuse is safe with two parities: a rank sends seq+2 only after it has received seq+1 from
-// everyone, which they sent after they finished reading seq. Every spin has a wall-clock deadline; on expiry it sets
-// *status and falls through (the result is then garbage, the host sees the flag).
+// everyone, which they sent after they finished reading seq. Every spin has a wall-clock deadline; what happens on
+// expiry is described at the kernel below (zero update + flag, never garbage).
 constexpr int kMaxPeers = 16;
 struct XchgPeers { unsigned long long *inbox[kMaxPeers]; };
 
-__device__ __forceinline__ unsigned long long xchg_wait(const unsigned long long *slot, unsigned seq, long long timeout_ticks, unsigned *status)
+// Returns the packet; *ok = false if the deadline passed first (the flag words are then raised: `status` in mapped host
+// memory for the host, `status_dev` in device memory for later launches).
+__device__ __forceinline__ unsigned long long xchg_wait(const unsigned long long *slot, unsigned seq, long long timeout_ticks,
+                                                        unsigned *status, unsigned *status_dev, bool *ok)
 {
     const long long t0 = wall_clock64();
     for (;;) {
         const unsigned long long got = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((unsigned)(got >> 32) == seq) return got;
+        if ((unsigned)(got >> 32) == seq) { *ok = true; return got; }
         if (wall_clock64() - t0 > timeout_ticks) {
             __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(status_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *ok = false;
             return got;
         }
         __builtin_amdgcn_s_sleep(1);
     }
 }
 
+// A missed deadline must not put garbage into the controller: a workgroup whose packets did not all arrive applies a
+// ZERO update to its column (U'[c] = U[c]; the sequence still shifts and the Philox step counter still advances, so
+// the handle's host-side bookkeeping and the noise streams of the ranks stay aligned) and raises the flag. Once the
+// flag is up (`status_dev`, read at the start of every launch) later launches skip the exchange altogether — no sends,
+// no spins, zero update — instead of burning one deadline per queued step; mppi_shard_p2p_step refuses further steps
+// as soon as the host sees the flag (MPPI_ERR_EXCHANGE), and ShardedController re-synchronises U and the step counter
+// from rank 0 before it continues on the all-gather path (distributed.py).
 __global__ __launch_bounds__(kThreads) void k_finish_cols_xchg(
     const float *__restrict__ recs, int sb, int sc, int nb, int HA, int a, float neg_inv_lambda,
     const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
     unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg,
-    XchgPeers peers, int G, int rank, unsigned seq, long long timeout_ticks, unsigned *status, const float *__restrict__ clip)
+    XchgPeers peers, int G, int rank, unsigned seq, long long timeout_ticks, unsigned *status, unsigned *status_dev,
+    const float *__restrict__ clip)
 {
     __shared__ float red_f[kThreads / 64];
     __shared__ double red_d[2][kThreads / 64];
     __shared__ float mine[3];
     __shared__ float theirs[3][kMaxPeers];
+    __shared__ int bad_s;
     const int c = blockIdx.x, tid = threadIdx.x;
     const float u_old = U_in[c];
     const unsigned long long step_old = step_ctr[0];
+    const unsigned dead = __hip_atomic_load(status_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // requested early, used late
     float lo = -INFINITY, hi = INFINITY;
     if (clip != nullptr) { lo = clip[c % a]; hi = clip[a + c % a]; }
     float beta;
     double eta, V;
     column_combine([&](int b, int j) { return recs[(size_t)b * sb + (size_t)(j == 2 ? 2 + c : j) * sc]; },
                    nb, neg_inv_lambda, red_f, red_d, beta, eta, V);
-    if (tid == 0) { mine[0] = beta; mine[1] = (float)eta; mine[2] = (float)V; }
+    if (tid == 0) { mine[0] = beta; mine[1] = (float)eta; mine[2] = (float)V; bad_s = dead ? 1 : 0; }
     __syncthreads();
     const size_t slot0 = ((size_t)(seq & 1u) * HA + c) * G;
-    if (tid < 3 * G) {
+    if (!dead && tid < 3 * G) {
         const int p = tid / 3, j = tid - 3 * p;
         const unsigned long long pkt = ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(mine[j]);
         __hip_atomic_store(peers.inbox[p] + (slot0 + rank) * 3 + j, pkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned long long got = xchg_wait(peers.inbox[rank] + (slot0 + p) * 3 + j, seq, timeout_ticks, status);
+        bool ok;
+        const unsigned long long got = xchg_wait(peers.inbox[rank] + (slot0 + p) * 3 + j, seq, timeout_ticks, status, status_dev, &ok);
         theirs[j][p] = __uint_as_float((unsigned)got);
+        if (!ok) bad_s = 1;
     }
     __syncthreads();
-    column_combine([&](int b, int j) { return theirs[j][b]; }, G, neg_inv_lambda, red_f, red_d, beta, eta, V);
+    const bool bad = bad_s != 0; // workgroup-uniform
+    if (!bad) column_combine([&](int b, int j) { return theirs[j][b]; }, G, neg_inv_lambda, red_f, red_d, beta, eta, V);
     if (tid == 0) {
-        if (c == 0 && dbg != nullptr) { dbg[0] = beta; dbg[1] = (float)eta; }
-        const float un = fminf(fmaxf(u_old + (float)(V / eta), lo), hi);
+        if (c == 0 && dbg != nullptr && !bad) { dbg[0] = beta; dbg[1] = (float)eta; }
+        const float un = bad ? u_old : fminf(fmaxf(u_old + (float)(V / eta), lo), hi);
         U_out[c] = un;
         if (c < a) u_out[c] = un;
         if (c == 0) step_ctr[0] = step_old + 1ull;
@@ -668,15 +688,16 @@ __global__ void k_savgol(const float *__restrict__ in, float *__restrict__ out, 
 // same packets, stores and spins on a separate probe region of the inbox (after the 2*HA*G*3 step slots), with a
 // known payload. got[g] = the value received from rank g (the host checks got[g] == payload(g, seq)).
 __global__ void k_xchg_probe(XchgPeers peers, size_t probe_off, int G, int rank, unsigned seq, float payload,
-                             long long timeout_ticks, unsigned *status, float *got)
+                             long long timeout_ticks, unsigned *status, unsigned *status_dev, float *got)
 {
     const int p = threadIdx.x;
     if (p >= G) return;
     const size_t slot0 = probe_off + (size_t)(seq & 1u) * G;
     const unsigned long long pkt = ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(payload);
     __hip_atomic_store(peers.inbox[p] + slot0 + rank, pkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const unsigned long long r = xchg_wait(peers.inbox[rank] + slot0 + p, seq, timeout_ticks, status);
-    got[p] = __uint_as_float((unsigned)r);
+    bool ok;
+    const unsigned long long r = xchg_wait(peers.inbox[rank] + slot0 + p, seq, timeout_ticks, status, status_dev, &ok);
+    got[p] = ok ? __uint_as_float((unsigned)r) : __uint_as_float(0x7fc00000u);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -20,6 +20,10 @@ import torch
 import torch.distributed as dist
 
 
+class ExchangeTimeout(RuntimeError):
+    """The direct record exchange missed a deadline; see ShardedController.next / resync."""
+
+
 class HipShardBackend:
     """The product backend: this rank's shard on its GPU through the C-ABI (mppi_shard_partial /
     mppi_shard_finish). Fails loudly when the HIP library or the GPU is missing."""
@@ -68,6 +72,15 @@ class HipShardBackend:
     def action_sequence(self):
         torch.cuda.current_stream(self.device).synchronize()
         return torch.from_numpy(self.h.get_action_sequence())
+
+    def step_counter(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        return self.h.get_step_counter()
+
+    def set_state(self, U, step):
+        torch.cuda.current_stream(self.device).synchronize()
+        self.h.set_action_sequence(U.numpy())
+        self.h.set_step_counter(step)
 
 
 class ShardedController:
@@ -143,12 +156,25 @@ class ShardedController:
 
     def next(self, x):
         """x: float32 tensor [s] on the backend's device (replicated on every rank). Returns u [a]
-        (device tensor, valid in stream order; identical on every rank)."""
+        (device tensor, valid in stream order; identical on every rank).
+
+        Direct exchange: a packet that misses its deadline never hangs the step and never writes garbage — the
+        affected columns of U get a zero update and a flag is raised (include/mppi_c.h). The flag is looked at when the
+        NEXT step is enqueued (and by check()): next() then raises ExchangeTimeout on this rank. Every rank that
+        depends on the late or dead peer runs into its own deadline within one more step and raises too. Controls
+        returned since the failing step are zero-update controls; U and the step counter may differ between ranks
+        until resync() (a collective: call it on every rank) has copied them from rank 0 — the controller then
+        continues on the all-gather path."""
         if self.world == 1 and hasattr(self.backend, "step") and not self.force_exchange:
             self.backend.step(x, self.u)
             return self.u
         if self.p2p:
-            self.backend.p2p_step(x, self.u)
+            try:
+                self.backend.p2p_step(x, self.u)
+            except Exception as e:
+                if getattr(e, "status", None) == 8:  # MPPI_ERR_EXCHANGE: refused before anything was enqueued
+                    raise ExchangeTimeout(str(e)) from None
+                raise
             return self.u
         self.backend.partial(x, self.record)
         if self.world > 1 or (self.force_exchange and dist.is_initialized()):
@@ -159,9 +185,26 @@ class ShardedController:
         return self.u
 
     def check(self):
-        """After synchronising: raise if a direct-exchange spin ever hit its deadline (results are invalid then)."""
+        """After synchronising the stream: raise if a direct-exchange spin ever hit its deadline (the controls since
+        then are zero-update controls; see next())."""
         if self.p2p and self.backend.p2p_timed_out():
-            raise RuntimeError("direct exchange: a packet did not arrive before the deadline")
+            raise ExchangeTimeout("direct exchange: a packet did not arrive before the deadline")
+
+    def resync(self):
+        """Collective (every rank): leave the direct exchange for good, copy rank 0's nominal sequence and Philox
+        step counter to every rank, continue on the all-gather path. Call it on all ranks after ExchangeTimeout."""
+        self.p2p, self.exchange = False, "rccl"
+        self.p2p_note = "closed after a missed deadline"
+        U = self.backend.action_sequence()
+        step = torch.tensor([self.backend.step_counter()], dtype=torch.int64)
+        if dist.is_initialized() and self.world > 1:
+            on_gpu = dist.get_backend(self.group) == "nccl"
+            dev = self.backend.device if on_gpu else "cpu"
+            U, step = U.to(dev), step.to(dev)
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast(U, src=src, group=self.group)
+            dist.broadcast(step, src=src, group=self.group)
+        self.backend.set_state(U.cpu(), int(step.item()))
 
 
 def shard_bounds(k, rank, world):

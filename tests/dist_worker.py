@@ -54,7 +54,7 @@ class P2PDoubleBackend(OracleShardBackend):
     def __init__(self, rank, world, mode, **cfg):
         super().__init__(rank, world, **cfg)
         self.rank, self.world, self.mode = rank, world, mode
-        self.attached, self.probes, self.p2p_steps = None, 0, 0
+        self.attached, self.probes, self.p2p_steps, self.failed = None, 0, 0, False
 
     def p2p_export(self):
         return 1000 + self.rank, b"ipc-handle-of-rank-%02d" % self.rank
@@ -74,6 +74,15 @@ class P2PDoubleBackend(OracleShardBackend):
         return not (self.mode == "probe_fails" and self.rank == self.world - 1)
 
     def p2p_step(self, x, u):
+        if self.mode == "deadline" and self.p2p_steps == 1 and not self.failed:
+            # what HipShardBackend does when the pinned flag is up (MPPI_ERR_EXCHANGE): refuse before enqueuing. Here the
+            # ranks have meanwhile drifted apart the way zero-update steps let them (a different U and counter per rank).
+            self.failed = True
+            self.U = self.U + np.float32(1e-3 * (self.rank + 1))
+            self.step_no += self.rank
+            e = RuntimeError("mppi status 8: direct exchange: a packet missed its deadline")
+            e.status = 8
+            raise e
         self.p2p_steps += 1
         rec = torch.zeros(self.record_size)
         recs = torch.zeros(self.world * self.record_size)
@@ -84,9 +93,19 @@ class P2PDoubleBackend(OracleShardBackend):
     def p2p_timed_out(self):
         return False
 
+    # state hand-over used by ShardedController.resync
+    def action_sequence(self):
+        return torch.from_numpy(self.U.copy())
+
+    def step_counter(self):
+        return self.step_no
+
+    def set_state(self, U, step):
+        self.U, self.step_no = U.numpy().astype(np.float32).copy(), int(step)
+
 
 def run(cfg, n_steps, world_override=None):
-    from mppi_tf_amd.distributed import ShardedController
+    from mppi_tf_amd.distributed import ExchangeTimeout, ShardedController
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     mode = os.environ.get("MPPI_TEST_P2P", "")
@@ -95,13 +114,20 @@ def run(cfg, n_steps, world_override=None):
     A, B = orc.pm_matrices(0.1, 1.0, cfg["s_dim"], cfg["a_dim"])
     x = np.zeros(cfg["s_dim"], np.float32)
     us = []
+    resyncs = 0
     for _ in range(n_steps):
-        u = ctl.next(torch.from_numpy(x.copy())).numpy().copy()
+        try:
+            u = ctl.next(torch.from_numpy(x.copy())).numpy().copy()
+        except ExchangeTimeout:  # every rank: drop the direct path, adopt rank 0's U and step counter, go on over the all-gather
+            ctl.resync()
+            resyncs += 1
+            u = ctl.next(torch.from_numpy(x.copy())).numpy().copy()
         us.append(u.tolist())
         x = orc.model_step(A, B, x[None], u[None])[0]
     ctl.check()
     return dict(rank=rank, world=world, lo=be.lo, hi=be.hi, u=us, U=be.U.tolist(), exchange=ctl.exchange, note=ctl.p2p_note,
-                p2p_steps=getattr(be, "p2p_steps", 0), probes=getattr(be, "probes", 0))
+                p2p_steps=getattr(be, "p2p_steps", 0), probes=getattr(be, "probes", 0), resyncs=resyncs,
+                step_no=be.step_no)
 
 
 if __name__ == "__main__":

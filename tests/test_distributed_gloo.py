@@ -65,6 +65,20 @@ def test_direct_exchange_bring_up_votes_and_falls_back(mode, tmp_path, unsharded
     np.testing.assert_allclose(res[0]["u"], unsharded["u"], rtol=0, atol=2e-6)
 
 
+def test_missed_deadline_raises_and_resync_realigns_the_ranks(tmp_path):
+    """The direct exchange's failure path on CPU (test double): when the product backend refuses a step because a packet
+    missed its deadline (MPPI_ERR_EXCHANGE), ShardedController.next raises ExchangeTimeout on every rank; resync() (a
+    collective) leaves the direct path, copies rank 0's nominal sequence and Philox step counter to every rank — the
+    double lets them drift apart first, as zero-update steps can — and the loop continues over the all-gather with
+    bit-identical controls on every rank."""
+    res = launch(3, tmp_path, steps=4, p2p="deadline")
+    assert [r["exchange"] for r in res] == ["rccl"] * 3 and [r["resyncs"] for r in res] == [1] * 3
+    assert all(r["p2p_steps"] == 1 for r in res)  # one good direct step, the second was refused
+    for r in res[1:]:
+        assert r["U"] == res[0]["U"] and r["step_no"] == res[0]["step_no"]
+        assert r["u"][1:] == res[0]["u"][1:]  # from the resync on: replicated again
+
+
 def test_shard_bounds_cover_everything():
     from mppi_tf_amd.distributed import shard_bounds
     for k in (1, 7, 64, 65536, 524288, 1000003):

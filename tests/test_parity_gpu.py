@@ -268,13 +268,11 @@ DENSE_SIGMA3 = np.array([[0.3, 0.05, 0.0], [0.02, 0.2, -0.04], [0.0, 0.03, 0.25]
     (70000, 16, 3, None),          # > 1024 tiles: several rounds, roles by wave index, no priorities
     (5000, 24, 3, DENSE_SIGMA3),   # dense Σ: the non-diagonal instances
 ])
-def test_producer_consumer_kernel_equals_tile_kernel(m, monkeypatch, K, H, a, sigma):
+def test_producer_consumer_kernel_equals_tile_kernel(m, K, H, a, sigma):
     """k_rollout_pc (hot path) vs k_rollout_tile on the same Philox counters: costs bit-identical,
     update within rounding."""
     x = (0.1 * np.arange(2 * a)).astype(F32)
-    monkeypatch.setenv("MPPI_FORCE_TILE_KERNEL", "1")
-    ht, p = make_pair(m, K, H, a, seed=77, sigma=sigma)
-    monkeypatch.setenv("MPPI_FORCE_TILE_KERNEL", "0")
+    ht, p = make_pair(m, K, H, a, seed=77, sigma=sigma, tuning={"force_tile_kernel": 1})
     hp, _ = make_pair(m, K, H, a, seed=77, sigma=sigma)
     for _ in range(2):
         ut, up = ht.next(x), hp.next(x)
@@ -387,7 +385,10 @@ def test_cpp_constructor_defaults_and_host_loop(m, tmp_path):
     f = tmp_path / "data.csv"
     c.toCSV(str(f))
     rows = f.read_text().strip().splitlines()
-    assert rows[0] == "x0,x1,u0,x_next0,x_next1" and len(rows) == 5
+    # DataBase::toCSV's bytes (data_base.cpp:36-71): every cell followed by a comma, values as std::to_string(float)
+    assert rows[0] == "x0,x1,u0,x_next0,x_next1," and len(rows) == 5
+    import re
+    assert all(re.fullmatch(r"(-?\d+\.\d{6},){5}", r) for r in rows[1:]), rows[1:]
     assert c.setGoal([0.5, 0.0]) is True
     c.next(x.tolist())
     assert abs(c._h.debug_get(m.DBG_COSTS).min()) >= 0
@@ -490,35 +491,193 @@ def test_mlp_rollout_costs_within_fp32_of_truth(m, K, H, a, bx3):
     assert err_gpu.max() < (8 if bx3 else 4) * max(err_cpu.max(), 1e-6), (err_gpu.max(), err_cpu.max())
 
 
-@pytest.mark.parametrize("bx3", [False, True], ids=["fp32mfma", "bf16x3"])
-def test_mlp_next_matches_oracle(m, bx3):
-    """One control step of the MLP controller: injected noise, and the fused Philox path on its own noise.
-    Stated tolerance for this (unpinned) row: 1e-4 absolute on U' (costs agree to ~1e-6 relative and the
-    soft-min amplifies a cost error dc into a weight error dc/lambda)."""
-    K, H, a = 4096, 32, 3
-    s = 2 * a
-    mlp = make_mlp(s, a, seed=9)
-    h, p32, p64 = make_mlp_pair(m, K, H, a, mlp, lam=1.0, seed=4, mlp_bf16x3=bx3)
-    x = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
-    rng = np.random.default_rng(6)
-    for step in range(2):
-        U_in = h.get_action_sequence()
+# The three MLP rollout kernels: k_rollout_mlp (exact-fp32 MFMA, the default), k_rollout_mlp_bx3 (MPPI_FLAG_MLP_BF16X3)
+# and k_rollout_mlp_bx3p (MPPI_FLAG_MLP_BF16X3_PIPELINED). Bars on the control update U' (absolute, against the fp64
+# oracle on identical noise): north_star's 1e-5 for the exact-fp32 kernel; 2e-5 for the split-bf16 kernels (their
+# operands carry 16 mantissa bits: measured 2-5x the fp32 kernel's error). Both are ALWAYS held to a small multiple of
+# the error the fp32 CPU oracle itself makes against fp64 (the reference computes in fp32 too): no worse than 4x / 8x.
+# The absolute bar applies where the problem is conditioned for it, i.e. where the fp32 CPU evaluation itself lands
+# within a quarter of the bar of fp64: the soft-min turns a cost error dc into a relative weight error dc/lambda, so
+# with few samples, a long horizon (large costs) and lambda = 1 ANY two fp32 evaluations of the reference's graph
+# differ by more than 1e-5 (the K=512, H=128 case below: fp32 CPU 1.3e-5, this kernel 1.3e-5) — "within 1e-5 of the
+# reference" is then not defined by the reference either.
+MLP_VARIANTS = [("fp32mfma", {}, 1e-5, 4.0), ("bf16x3", dict(mlp_bf16x3=True), 2e-5, 8.0),
+                ("bf16x3p", dict(mlp_bf16x3_pipelined=True), 2e-5, 8.0)]
+MLP_IDS = [v[0] for v in MLP_VARIANTS]
+_oracle_cache = {}
+
+
+def mlp_step_case(K, H, a, seed, lam=1.0):
+    """Inputs and the CPU oracles' answers (fp64 = truth, fp32 = what an fp32 CPU evaluation gives) of ONE control
+    step with injected noise; cached so the three kernel variants share one oracle evaluation."""
+    key = (K, H, a, seed, lam)
+    if key not in _oracle_cache:
+        s = 2 * a
+        mlp = make_mlp(s, a, seed=seed)
+        sigma, goal = 0.25 * np.eye(a), (GOAL3 + [0.25, 0])[:s]
+        kw = dict(tau=H, s=s, a=a, lam=lam, sigma=sigma, goal=goal, mlp=mlp, threads=0)
+        p32, p64 = orc.Problem(**kw), orc.Problem(dtype=np.float64, **kw)
+        rng = np.random.default_rng(seed + 1)
+        x = (0.2 * rng.standard_normal(s)).astype(F32)
+        U = (0.1 * rng.standard_normal((H, a))).astype(F32)
         eps = (0.25 * rng.standard_normal((K, H, a))).astype(F32)
-        u = h.next_with_noise(x, eps)
-        u_ref, U_ref, c_ref = p64.next_with_noise(x, U_in, eps)
-        np.testing.assert_allclose(h.debug_get(m.DBG_COSTS), c_ref, rtol=2e-5)
-        np.testing.assert_allclose(u, u_ref, rtol=0, atol=1e-4)
-        np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=1e-4)
-    U_in = h.get_action_sequence()
-    u = h.next(x)
-    eps = h.debug_get(m.DBG_NOISE)
-    np.testing.assert_allclose(eps, orc.noise(4, 2, 0, K, H, a, 0.25 * np.eye(a)), rtol=0, atol=5e-6)
-    u_ref, U_ref, c_ref = p64.next_with_noise(x, U_in, eps)
-    np.testing.assert_allclose(h.debug_get(m.DBG_COSTS), c_ref, rtol=2e-5)
-    np.testing.assert_allclose(u, u_ref, rtol=0, atol=1e-4)
-    np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=1e-4)
+        u64, U64, c64 = p64.next_with_noise(x, U, eps)
+        u32, U32, c32 = p32.next_with_noise(x, U, eps)
+        _oracle_cache.clear()  # one case at a time: eps is 50 MB at K=65536
+        _oracle_cache[key] = dict(mlp=mlp, sigma=sigma, goal=goal, x=x, U=U, eps=eps, U64=np.asarray(U64, np.float64),
+                                  c64=np.asarray(c64, np.float64), U32=np.asarray(U32, np.float64), c32=np.asarray(c32, np.float64))
+    return _oracle_cache[key]
+
+
+def check_mlp_step(m, K, H, a, seed, kw, u_bar, factor, lam=1.0, well_conditioned=True):
+    cs = mlp_step_case(K, H, a, seed, lam)
+    h = m.Handle(k=K, tau=H, s_dim=2 * a, a_dim=a, lam=lam, sigma=cs["sigma"], goal=cs["goal"], mlp=cs["mlp"], **kw)
+    h.set_action_sequence(cs["U"])
+    u = h.next_with_noise(cs["x"], cs["eps"])
+    Uupd = h.debug_get(m.DBG_U_UPDATED).astype(np.float64)
+    # the oracle returns the SHIFTED sequence: compare the shifted one the handle keeps (and u = U'[0] below)
+    Unext = h.get_action_sequence().astype(np.float64)
+    c = h.debug_get(m.DBG_COSTS).astype(np.float64)
+    rel = lambda got: float((np.abs(got - cs["c64"]) / np.abs(cs["c64"])).max())
+    ec_gpu, ec_cpu = rel(c), rel(cs["c32"])
+    eu_gpu = float(np.abs(Unext - cs["U64"]).max())
+    eu_cpu = float(np.abs(cs["U32"] - cs["U64"]).max())
+    print("K=%d H=%d a=%d: max rel cost error GPU %.3g / fp32 CPU %.3g;  max|dU'| GPU %.3g / fp32 CPU %.3g (bar %.0e)"
+          % (K, H, a, ec_gpu, ec_cpu, eu_gpu, eu_cpu, u_bar))
+    assert ec_gpu < 2e-5 and ec_gpu < factor * max(ec_cpu, 1e-6), (ec_gpu, ec_cpu)
+    assert eu_gpu <= factor * max(eu_cpu, 5e-7), (eu_gpu, eu_cpu)
+    if eu_cpu <= u_bar / 4 or well_conditioned:
+        assert eu_gpu <= u_bar, eu_gpu
+    assert np.abs(u.astype(np.float64) - Uupd[0]).max() == 0  # u is U'[0]
     w = h.debug_get(m.DBG_WEIGHTS).astype(np.float64)
     assert abs(w.sum() - 1) < 1e-5
+    return h
+
+
+@pytest.mark.parametrize("name,kw,u_bar,factor", MLP_VARIANTS, ids=MLP_IDS)
+def test_mlp_next_matches_oracle(m, name, kw, u_bar, factor):
+    """One control step of the MLP controller on injected noise: U' within north_star's 1e-5 of the fp64 oracle for
+    the exact-fp32 kernel (measured value printed), then the fused Philox path against the oracle on its own
+    exported noise."""
+    K, H, a = 4096, 32, 3
+    h = check_mlp_step(m, K, H, a, 9, kw, u_bar, factor)
+    cs = mlp_step_case(K, H, a, 9)
+    p64 = orc.Problem(tau=H, s=2 * a, a=a, lam=1.0, sigma=cs["sigma"], goal=cs["goal"], mlp=cs["mlp"], threads=0, dtype=np.float64)
+    U_in = h.get_action_sequence()
+    x = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
+    u = h.next(x)
+    eps = h.debug_get(m.DBG_NOISE)
+    np.testing.assert_allclose(eps, orc.noise(1, 1, 0, K, H, a, 0.25 * np.eye(a)), rtol=0, atol=5e-6)
+    u_ref, U_ref, c_ref = p64.next_with_noise(x, U_in, eps)
+    np.testing.assert_allclose(h.debug_get(m.DBG_COSTS), c_ref, rtol=2e-5)
+    print("fused path: max|dU'| = %.3g" % np.abs(h.get_action_sequence() - U_ref).max())
+    np.testing.assert_allclose(u, u_ref, rtol=0, atol=u_bar)
+    np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=u_bar)
+
+
+@pytest.mark.parametrize("name,kw,u_bar,factor", MLP_VARIANTS, ids=MLP_IDS)
+@pytest.mark.parametrize("K,H,lam,cond", [(65536, 8, 1.0, True), (8192, 128, 1.0, True), (512, 128, 1.0, False), (1000, 130, 8.0, True)],
+                         ids=["K65536_H8", "K8192_H128", "K512_H128_illconditioned", "K1000_H130_lam8"])
+def test_mlp_baseline_shapes_against_oracle(m, K, H, lam, cond, name, kw, u_bar, factor):
+    """The BASELINE shapes' two long axes, each against the CPU oracle: K = 65536 (configs[3]: 1024 workgroups = 4
+    rounds per CU, a 1024-record finish; 512 for the 128-rollout pipelined kernel) at a horizon the oracle finishes in
+    seconds, and H = 128 (configs[4]) / a ragged 130. The absolute 1e-5 bar holds wherever fp32 itself can hold it; the
+    K=512, H=128, lambda=1 case documents where it cannot (see MLP_VARIANTS) and is held to the fp32 CPU's own error."""
+    check_mlp_step(m, K, H, 3, 100 + H, kw, u_bar, factor, lam=lam, well_conditioned=cond)
+
+
+def mlp_full_size_properties(m, h, p64, x, U_in, n_check=1536):
+    """Size-independent properties of one fused (Philox) MLP step at a BASELINE size, from the exported pieces."""
+    u = h.next(x) if h.k_local == h.k else None
+    c = h.debug_get(m.DBG_COSTS).astype(np.float64)
+    eps = h.debug_get(m.DBG_NOISE)
+    lam = 1.0
+    # (1) a random subset of the rollouts against the fp64 oracle on the noise the step really used
+    idx = np.sort(np.random.default_rng(3).choice(h.k_local, n_check, replace=False))
+    truth = p64.rollout_cost(x, U_in, eps[idx])
+    err = float((np.abs(c[idx] - truth) / np.abs(truth)).max())
+    print("K_local=%d H=%d: max rel cost error on %d sampled rollouts %.3g" % (h.k_local, h.tau, n_check, err))
+    assert err < 2e-5
+    # (2) the weights are the soft-min of the kernel's own costs and sum to 1
+    e = np.exp(-(c - c.min()) / lam)
+    return u, c, eps, e
+
+
+@pytest.mark.parametrize("name,kw,u_bar,factor", MLP_VARIANTS, ids=MLP_IDS)
+def test_full_size_properties_mlp_c4(m, name, kw, u_bar, factor):
+    """BASELINE configs[3] at full size (point_mass3d + 2x256 MLP, K=65536, H=64), fused Philox path: sampled costs
+    against the fp64 oracle, sum(w) = 1, U' = fp64 recombination of the exported noise with the soft-min of the
+    kernel's own costs, and the 8-way K-sharded step equals the unsharded one."""
+    import torch
+    K, H, a = 65536, 64, 3
+    mlp = make_mlp(6, a, seed=0)
+    sigma = 0.25 * np.eye(a)
+    cfg = dict(k=K, tau=H, s_dim=6, a_dim=a, lam=1.0, sigma=sigma, goal=GOAL3, mlp=mlp, seed=1, **kw)
+    h = m.Handle(**cfg)
+    p64 = orc.Problem(tau=H, s=6, a=a, lam=1.0, sigma=sigma, goal=GOAL3, mlp=mlp, threads=0, dtype=np.float64)
+    x = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
+    U_in = (0.05 * np.random.default_rng(1).standard_normal((H, a))).astype(F32)
+    h.set_action_sequence(U_in)
+    u, c, eps, e = mlp_full_size_properties(m, h, p64, x, U_in)
+    w = h.debug_get(m.DBG_WEIGHTS).astype(np.float64)
+    assert abs(w.sum() - 1) < 1e-5 and (w >= 0).all()
+    np.testing.assert_allclose(w, e / e.sum(), rtol=1e-5, atol=1e-12)
+    Uupd = h.debug_get(m.DBG_U_UPDATED).astype(np.float64)
+    want = U_in + np.tensordot(e / e.sum(), eps.astype(np.float64), axes=(0, 0))
+    print("max|U' - fp64 recombination| = %.3g" % np.abs(Uupd - want).max())
+    np.testing.assert_allclose(Uupd, want, rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(u, Uupd[0].astype(F32))
+    np.testing.assert_allclose(eps[:64], orc.noise(1, 0, 0, 64, H, a, sigma), rtol=0, atol=5e-6)
+    # 8 shards of 8192 (the record exchange done by hand): same costs, same control
+    shards = 8
+    hs = [m.Handle(shard_rank=g, shard_count=shards, **cfg) for g in range(shards)]
+    xd = torch.tensor(x, device="cuda")
+    n = hs[0].record_size
+    recs = torch.zeros(shards * n, device="cuda")
+    us = [torch.zeros(a, device="cuda") for _ in range(shards)]
+    for g, hg in enumerate(hs):
+        hg.set_action_sequence(U_in)
+        hg.shard_partial(xd.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
+        hg.synchronize()
+    for g, hg in enumerate(hs):
+        hg.shard_finish(recs.data_ptr(), shards, us[g].data_ptr())
+        hg.synchronize()
+        np.testing.assert_array_equal(us[g].cpu().numpy(), us[0].cpu().numpy())
+        np.testing.assert_allclose(us[g].cpu().numpy(), u, rtol=0, atol=2e-6)
+        np.testing.assert_array_equal(hg.debug_get(m.DBG_COSTS), c[hg.k_offset:hg.k_offset + hg.k_local].astype(F32))
+
+
+@pytest.mark.parametrize("name,kw,u_bar,factor", MLP_VARIANTS, ids=MLP_IDS)
+def test_full_size_properties_mlp_c5_per_gpu_shape(m, name, kw, u_bar, factor):
+    """BASELINE configs[4] as ONE rank sees it: shard 5 of 8 of a K=524288, H=128 MLP controller (65536 rollouts per
+    GPU). Global-k Philox counters (noise = the oracle's stream at k_offset), sampled costs against the fp64 oracle,
+    and the shard record (beta_g, eta_g, V_g) against the fp64 recombination of the exported noise."""
+    import torch
+    K, H, a, rank, shards = 524288, 128, 3, 5, 8
+    mlp = make_mlp(6, a, seed=0)
+    sigma = 0.25 * np.eye(a)
+    h = m.Handle(k=K, tau=H, s_dim=6, a_dim=a, lam=1.0, sigma=sigma, goal=GOAL3, mlp=mlp, seed=1,
+                 shard_rank=rank, shard_count=shards, **kw)
+    assert h.k_local == 65536 and h.k_offset == rank * 65536
+    p64 = orc.Problem(tau=H, s=6, a=a, lam=1.0, sigma=sigma, goal=GOAL3, mlp=mlp, threads=0, dtype=np.float64)
+    x = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
+    U_in = (0.05 * np.random.default_rng(1).standard_normal((H, a))).astype(F32)
+    h.set_action_sequence(U_in)
+    xd = torch.tensor(x, device="cuda")
+    rec = torch.zeros(h.record_size, device="cuda")
+    ud = torch.zeros(a, device="cuda")
+    h.shard_partial(xd.data_ptr(), rec.data_ptr())
+    h.shard_finish(rec.data_ptr(), 1, ud.data_ptr())  # a one-record "gather": also advances the step counter
+    h.synchronize()
+    _, c, eps, e = mlp_full_size_properties(m, h, p64, x, U_in)
+    np.testing.assert_allclose(eps[:32], orc.noise(1, 0, h.k_offset, 32, H, a, sigma), rtol=0, atol=5e-6)
+    r = rec.cpu().numpy().astype(np.float64)
+    assert r[0] == c.min()
+    np.testing.assert_allclose(r[1], e.sum(), rtol=1e-6)
+    V = np.tensordot(e, eps.astype(np.float64), axes=(0, 0)).ravel()
+    print("max|V_g - fp64| / eta = %.3g" % (np.abs(r[2:] - V).max() / e.sum()))
+    np.testing.assert_allclose(r[2:] / r[1], V / e.sum(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(ud.cpu().numpy(), (U_in + (V / e.sum()).reshape(H, a))[0], rtol=0, atol=2e-6)
 
 
 def test_mlp_sharded_equals_unsharded(m):
@@ -579,21 +738,63 @@ def test_python_controller_with_upsilon_and_gamma(m):
 
 def test_reference_shaped_python_entry_point(m, tmp_path):
     """examples/main.py = scripts/main.py's loop (YAML config + task, Simulation, PointMassModel, StaticCost,
-    ControllerBase, save) with the MuJoCo-free plant; must reach the goal and write the transition CSV."""
+    ControllerBase, save) with the MuJoCo-free plant; must reach the goal and write the transition CSV in
+    DataBase::toCSV's bytes. `--new -l` leaves config.yaml / task.yaml in <log_dir>/controller (observer_base.py:39-54)
+    and `--replay --log_dir` (main.py:19-27,68-69; utile.py:53-59) repeats the run from them: identical CSV bytes."""
     import os
+    import re
     import subprocess
     import sys
     from conftest import ROOT
-    csv = tmp_path / "log.csv"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "main.py"), "--new",
+    main_py = os.path.join(ROOT, "examples", "main.py")
+    log = tmp_path / "run"
+    r = subprocess.run([sys.executable, main_py, "--new",
                         "--config", os.path.join(ROOT, "examples", "config", "point_mass3d.yaml"),
                         "--task", os.path.join(ROOT, "examples", "config", "static_task3d.yaml"),
-                        "-s", "80", "--csv", str(csv)], capture_output=True, text=True, timeout=300)
+                        "-s", "80", "-l", "--log_dir", str(log)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     dist = float(r.stdout.split("|x - goal| =")[1].split()[0])
     assert dist < 0.1, r.stdout
-    rows = csv.read_text().strip().splitlines()
-    assert len(rows) == 81 and rows[0].startswith("x0,")
+    logdir = log / "controller"
+    assert (logdir / "config.yaml").exists() and (logdir / "task.yaml").exists()
+    first = (logdir / "transitions.csv").read_text()
+    rows = first.strip().splitlines()
+    assert len(rows) == 81 and rows[0] == "x0,x1,x2,x3,x4,x5,u0,u1,u2,x_next0,x_next1,x_next2,x_next3,x_next4,x_next5,"
+    assert all(re.fullmatch(r"(-?\d+\.\d{6},){15}", row) for row in rows[1:])
+    csv2 = tmp_path / "replayed.csv"
+    r = subprocess.run([sys.executable, main_py, "--replay", "--log_dir", str(logdir), "-s", "80", "--csv", str(csv2)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert csv2.read_text() == first
+    r = subprocess.run([sys.executable, main_py, "--replay", "--log_dir", str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "config.yaml" in r.stderr  # a directory that holds no logged run
+
+
+def test_transition_log_ring_pairing_and_formats(m, tmp_path):
+    """mppi_set_transition_log / mppi_save_next / mppi_to_csv_format: off by default (nothing recorded), a ring of
+    max_rows rows, x_next pairs with the LAST (x, u) so a skipped saveNext drops that one row only, and the two formats
+    (the reference's "%f," cells, data_base.cpp:36-44, and the round-trip "%.9g")."""
+    h = m.Handle(k=256, tau=8, s_dim=2, a_dim=1)
+    x = np.array([0.25, -0.5], F32)
+    h.next(x)
+    with pytest.raises(m.MppiError):
+        h.to_csv(str(tmp_path / "off.csv"))          # the log is off until asked for
+    h.set_transition_log(3)
+    us = []
+    for i in range(5):
+        us.append(h.next(x + i)[0])
+        if i != 3:                                   # skip one saveNext: that row has no successor
+            h.save_next(x + i + 0.125)
+    f = tmp_path / "ring.csv"
+    h.to_csv(str(f), m.CSV_ROUNDTRIP)
+    rows = f.read_text().strip().splitlines()
+    assert rows[0] == "x0,x1,u0,x_next0,x_next1"
+    got = np.array([[float(v) for v in r.split(",")] for r in rows[1:]], F32)
+    want = np.array([[0.25 + i, -0.5 + i, us[i], 0.375 + i, -0.375 + i] for i in (2, 4)], F32)  # ring of 3 = steps 2,3,4; 3 unpaired
+    np.testing.assert_array_equal(got, want)
+    h.to_csv(str(f))                                 # reference bytes
+    rows = f.read_text().splitlines()
+    assert rows[0] == "x0,x1,u0,x_next0,x_next1," and rows[1] == "2.250000,1.500000,%f,2.375000,1.625000," % us[2]
 
 
 def test_written_out_philox_equals_rocrand_engine(m):
@@ -676,16 +877,36 @@ def test_direct_exchange_equals_allgather_path_bit_for_bit(m, shards):
 
 
 def test_direct_exchange_deadline_instead_of_hang(m):
-    """A rank whose peer never sends must come back with the timed-out flag, not hang."""
+    """A rank whose peer never sends must come back with the timed-out flag, not hang — and without garbage: the step
+    applies a ZERO update (U' = U, then the shift), the Philox step counter still advances, a step already queued behind
+    it skips the exchange (no second deadline), and the next mppi_shard_p2p_step is refused with MPPI_ERR_EXCHANGE."""
+    import time
     import torch
     K, H, a = 1024, 8, 3
     hs = [make_pair(m, K, H, a, seed=3, shard_rank=g, shard_count=2)[0] for g in range(2)]
     ptrs = [h.p2p_export(want_ipc=False)[0] for h in hs]
-    hs[0].p2p_attach(ptrs, timeout_ms=50)
+    hs[0].p2p_attach(ptrs, timeout_ms=300)
+    U0 = (0.1 * np.random.default_rng(0).standard_normal((H, a))).astype(F32)
+    hs[0].set_action_sequence(U0)
     xd, u = torch.zeros(6, device="cuda"), torch.zeros(a, device="cuda")
-    hs[0].p2p_step(xd.data_ptr(), u.data_ptr())   # shard 1 never steps
+    t0 = time.perf_counter()
+    hs[0].p2p_step(xd.data_ptr(), u.data_ptr())   # shard 1 never steps: this one runs into the deadline
+    hs[0].p2p_step(xd.data_ptr(), u.data_ptr())   # enqueued before the host can know: must not wait a second time
     hs[0].synchronize()
-    assert hs[0].p2p_timed_out()
+    el = time.perf_counter() - t0
+    assert hs[0].p2p_timed_out() and 0.25 < el < 0.55, el
+    np.testing.assert_array_equal(u.cpu().numpy(), U0[1])                       # u = U'[0] of the second zero-update step
+    np.testing.assert_array_equal(hs[0].get_action_sequence(), np.vstack([U0[2:], np.zeros((2, a), F32)]))
+    assert hs[0].get_step_counter() == 2
+    with pytest.raises(m.MppiError) as e:
+        hs[0].p2p_step(xd.data_ptr(), u.data_ptr())
+    assert e.value.status == 8
+    # the all-gather path stays open on the same handle (what ShardedController.resync continues with)
+    rec = torch.zeros(hs[0].record_size, device="cuda")
+    hs[0].shard_partial(xd.data_ptr(), rec.data_ptr())
+    hs[0].shard_finish(rec.data_ptr(), 1, u.data_ptr())
+    hs[0].synchronize()
+    assert np.isfinite(u.cpu().numpy()).all() and hs[0].get_step_counter() == 3
     with pytest.raises(m.MppiError):
         hs[1].p2p_step(xd.data_ptr(), u.data_ptr())  # not attached
     with pytest.raises(m.MppiError):
@@ -771,8 +992,8 @@ def test_sequence_filter_matches_scipy_savgol(m, window, order):
             h.set_sequence_filter(*bad)
 
 
-def test_mlp_bf16x3_pipelined_variant_is_bit_identical(m, monkeypatch):
-    """k_rollout_mlp_bx3p (MPPI_MLP_BX3_PIPE=1: two 64-rollout sets per workgroup, the scalar chain of one inside the
+def test_mlp_bf16x3_pipelined_variant_is_bit_identical(m):
+    """k_rollout_mlp_bx3p (MPPI_FLAG_MLP_BF16X3_PIPELINED: two 64-rollout sets per workgroup, the scalar chain of one inside the
     MFMA stream of the other) must give the SAME bits as k_rollout_mlp_bx3, run after run. This is the regression test
     of a hardware hazard found while building it: a vector instruction that overwrites an MFMA's source registers right
     after the MFMA issues (across a branch, where hipcc pads nothing) corrupts 16-lane groups of rollouts at random."""
@@ -780,11 +1001,8 @@ def test_mlp_bf16x3_pipelined_variant_is_bit_identical(m, monkeypatch):
     for K, H in [(2048, 32), (300, 64), (4096, 17)]:
         mlp = make_mlp(s, a, seed=K)
         cfg = dict(k=K, tau=H, s_dim=s, a_dim=a, lam=1.0, sigma=0.25 * np.eye(a), goal=GOAL3, mlp=mlp, mlp_bf16x3=True, seed=3)
-        monkeypatch.delenv("MPPI_MLP_BX3_PIPE", raising=False)
         h0 = m.Handle(**cfg)
-        monkeypatch.setenv("MPPI_MLP_BX3_PIPE", "1")
-        h1 = m.Handle(**cfg)
-        monkeypatch.delenv("MPPI_MLP_BX3_PIPE", raising=False)
+        h1 = m.Handle(mlp_bf16x3_pipelined=True, **cfg)
         rng = np.random.default_rng(5)
         x0 = (0.2 * rng.standard_normal(s)).astype(F32)
         U = (0.1 * rng.standard_normal((H, a))).astype(F32)
@@ -808,13 +1026,9 @@ def test_sharded_controller_falls_back_when_the_direct_exchange_cannot_come_up(m
     from mppi_tf_amd.distributed import ShardedController
     monkeypatch.setenv("MPPI_FORCE_EXCHANGE", "1")
     monkeypatch.delenv("MPPI_EXCHANGE", raising=False)
-    if fault:
-        monkeypatch.setenv("MPPI_P2P_FAULT", fault)
-    else:
-        monkeypatch.delenv("MPPI_P2P_FAULT", raising=False)
     K, H, a = 4096, 32, 3
     cfg = dict(k=K, tau=H, s_dim=6, a_dim=a, sigma=0.25 * np.eye(a), goal=GOAL3, seed=11)
-    ctl = ShardedController(**cfg)
+    ctl = ShardedController(tuning={"p2p_fault": fault}, **cfg)  # mppi_set_tuning(MPPI_TUNE_P2P_FAULT)
     assert ctl.exchange == ("rccl" if fault else "p2p"), ctl.p2p_note
     ref = m.Handle(**cfg)
     x = torch.tensor([0.2, 0.1, -0.3, 0, 0.5, -0.1], device="cuda")
@@ -825,7 +1039,7 @@ def test_sharded_controller_falls_back_when_the_direct_exchange_cannot_come_up(m
         np.testing.assert_allclose(u.cpu().numpy(), ref.next(x.cpu().numpy()), rtol=0, atol=2e-6)
     if fault == "export":
         with pytest.raises(RuntimeError):
-            ShardedController(exchange="p2p", **cfg)
+            ShardedController(exchange="p2p", tuning={"p2p_fault": fault}, **cfg)
 
 
 def test_device_resident_steps_replay_from_a_hipgraph(m):
