@@ -62,10 +62,7 @@ enum { MPPI_FLAG_UPSILON_SCALES_NOISE = 1, /* Py build_noise: eps = (υΣ)·z wh
                                    fp32 operand split into two bf16 values and three products per term (fp32
                                    accumulate): ~2x the rounding error of the exact-fp32 path (sample costs within
                                    1e-6 relative of fp64 on the synthetic network), several times its speed. Off by
-                                   default: the default MLP path is exact fp32 (v_mfma_f32_32x32x2_f32). */,
-       MPPI_FLAG_MLP_BF16X3_PIPELINED = 4 /* implies MPPI_FLAG_MLP_BF16X3: the two-set software-pipelined form of that
-                                   kernel (128 rollouts per workgroup, one set's scalar chain inside the other's MFMA
-                                   stream); sample costs bit-identical to MPPI_FLAG_MLP_BF16X3. */ };
+                                   default: the default MLP path is exact fp32 (v_mfma_f32_32x32x2_f32). */ };
 
 /* what mppi_debug_get returns (observer_base.py:101-187 logs the same intermediates) */
 enum { MPPI_DBG_COSTS = 0,    /* c[K_local]         sample costs of the last step            */

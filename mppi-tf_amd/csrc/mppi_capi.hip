@@ -308,11 +308,6 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     h->R = R; h->nb = (h->K_local + R - 1) / R; h->tile_lds = tile_lds_floats(h->HA, R) * 4;
     h->nb_mlp = cfg->model_kind == MPPI_MODEL_MLP ? (h->K_local + kMlpR - 1) / kMlpR : 0;
     h->mlp_bx3 = (cfg->model_kind == MPPI_MODEL_MLP && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) ? 1 : 0;
-    // the two-set software-pipelined variant (k_rollout_mlp_bx3p): 128 rollouts per workgroup
-    if (cfg->model_kind == MPPI_MODEL_MLP && (cfg->flags & MPPI_FLAG_MLP_BF16X3_PIPELINED)) {
-        h->mlp_bx3 = 2;
-        h->nb_mlp = (h->K_local + kMlpR2 - 1) / kMlpR2;
-    }
 
     mppi_status st = MPPI_OK;
     auto body = [&]() -> mppi_status {
@@ -478,7 +473,7 @@ template <int A>
 static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
                                const float *eps, float *cost)
 {
-    const size_t lds = (h->mlp_bx3 == 2 ? mlp_bx3p_lds_floats(2 * A, A) : mlp_lds_floats(2 * A, A)) * 4;
+    const size_t lds = mlp_lds_floats(2 * A, A) * 4;
     const dim3 g(h->nb_mlp), b(kMlpThreads);
     if (mode != MODE_ROLLOUT && mode != MODE_COST_ONLY) return hipErrorInvalidValue;
 #define MPPI_MLP_L(KERN, BIT)                                                                                           \
@@ -492,10 +487,7 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
         hipExtLaunchKernelGGL(kern, g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, x_dev, U_dev, eps, \
                               (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp);                \
     } while (0)
-    if (h->mlp_bx3 == 2) {
-        if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp_bx3p<A, true>), 32);
-        else MPPI_MLP_L((k_rollout_mlp_bx3p<A, false>), 64);
-    } else if (h->mlp_bx3) {
+    if (h->mlp_bx3) {
         if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp_bx3<A, true>), 8);
         else MPPI_MLP_L((k_rollout_mlp_bx3<A, false>), 16);
     } else if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp<A, true>), 2);

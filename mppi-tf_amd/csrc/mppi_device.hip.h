@@ -340,60 +340,85 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
 }
 
 // ----------------------------------------------------------------------------------------
-// Transposing butterfly: sums N per-lane values ACROSS the 64 lanes for N independent columns
-// at once. Each level pairs lanes (l, l^p) and halves the live registers: the lane whose role
-// bit is 0 keeps the even register of a pair, the other keeps the odd one, each adds its
-// partner's copy. After 6 levels lane l holds, in out[m], the 64-lane total of column
-//   n = 64*m + r0 + 2 r1 + 4 r2 + 8 r3 + 16 r4 + 32 r5
-// with role bits r0=b0^b2, r1=b1^b2, r2=b2^b3, r3=b3, r4=b4, r5=b5 of its lane id (the roles
-// follow from the DPP partners 1, 2, 7 (row_half_mirror), 15 (row_mirror): a partner must keep
-// the same roles at all earlier levels). ~3 instructions per pair instead of a full 11-instruction
-// reduction per column. Fixed association -> deterministic.
-template <int LEVEL>
-__device__ __forceinline__ float lane_xchg(float v)
-{
-    if (LEVEL == 0) return dpp_mov<0xB1>(v);  // l ^ 1
-    if (LEVEL == 1) return dpp_mov<0x4E>(v);  // l ^ 2
-    if (LEVEL == 2) return dpp_mov<0x141>(v); // l ^ 7
-    if (LEVEL == 3) return dpp_mov<0x140>(v); // l ^ 15
-    if (LEVEL == 4) return __shfl_xor(v, 16, 64);
-    return __shfl_xor(v, 32, 64);
-}
-
-__device__ __forceinline__ int lane_role(int lane, int level)
-{
-    const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1;
-    switch (level) {
-    case 0: return (lane & 1) ^ b2;
-    case 1: return ((lane >> 1) & 1) ^ b2;
-    case 2: return b2 ^ b3;
-    case 3: return b3;
-    case 4: return (lane >> 4) & 1;
-    default: return (lane >> 5) & 1;
-    }
-}
-
-// column index a lane ends up owning in out[m] (see above)
+// Transposing butterfly: sums N per-lane values ACROSS the 64 lanes for N independent columns at once. Each level
+// pairs lanes (l, l^p) and halves the live registers: of a register pair (lo, hi) the lane whose role bit is 0 ends up
+// with lo_self + lo_partner, the other with hi_self + hi_partner. After the 6 levels lane l holds, in out[m], the
+// 64-lane total of column   n = 64*m + lane_column(l).   Fixed association -> deterministic.
+//
+// Instruction choice, from tools/micro/valu_issue.hip on this part (cycles per wave-instruction per SIMD, several
+// waves resident): v_add/v_mul 2.3, v_fma 2.5, DPP forms 4.2, v_cndmask_b32 with the mask in an SGPR pair 4.2 but with
+// the mask in VCC (what hipcc picks for `role ? a : b`) 19.4, ds_bpermute_b32 (= __shfl_xor) 24. The first version of
+// this butterfly (quad swaps and row mirrors + two selects per pair, __shfl_xor for the strides 16 and 32) cost
+// ~3100 cycles per producer wave at N = 72, a quarter of the rollout kernel; this one ~550:
+//   level 0, stride 32: v_permlane32_swap (lanes 32-63 of lo <-> lanes 0-31 of hi), then lo + hi      role = lane bit 5
+//   level 1, stride 16: v_permlane16_swap (odd rows of lo <-> even rows of hi), then lo + hi            role = bit 4
+//   level 2, stride 8 : two v_add_f32_dpp row_ror:8 writing complementary banks (bank = 4 lanes)        role = bit 3
+//   level 3, stride 4 : two v_add_f32_dpp, row_ror:12 on banks {0,2} / row_ror:4 on banks {1,3}         role = bit 2
+//   level 4, stride 2 : lo + quad_perm[2,3,0,1](lo), hi + ..(hi), bitwise select by a lane-mask register role = bit 1
+//   level 5, stride 1 : the same with quad_perm[1,0,3,2]                                                 role = bit 0
+// No selects on a condition register anywhere; the big strides come first, while there are many registers.
+// The swaps and the bank-masked adds are inline asm: hipcc mis-compiles `r[0] + r[1]` of __builtin_amdgcn_permlane32_swap
+// (ROCm 7.2: emits v_add_f32 v1, v1, v1) and has no builtin for a DPP add that leaves the other banks of its
+// destination alone. Each statement opens with the wait states its DPP / permlane reads need after a VALU write
+// (2; hipcc does not look inside an asm string).
 __device__ __forceinline__ int lane_column(int lane)
 {
-    int n = 0;
-#pragma unroll
-    for (int lv = 0; lv < 6; ++lv) n |= lane_role(lane, lv) << lv;
-    return n;
+    return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) |
+           (((lane >> 1) & 1) << 4) | ((lane & 1) << 5);
+}
+
+// lane-mask registers for the bitwise selects of levels 4 and 5: all ones where the role bit is set. Made opaque so that
+// hipcc keeps the and/or form (v_bfi_b32) instead of rebuilding a v_cndmask on VCC.
+struct ButterflyMasks {
+    unsigned m1, m0;
+    __device__ __forceinline__ explicit ButterflyMasks(int lane)
+    {
+        m1 = (lane & 2) ? 0xffffffffu : 0u;
+        m0 = (lane & 1) ? 0xffffffffu : 0u;
+        asm volatile("" : "+v"(m1), "+v"(m0));
+    }
+};
+
+__device__ __forceinline__ float bit_select(unsigned mask, float if_set, float if_clear)
+{
+    return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, if_set) & mask) | (__builtin_bit_cast(unsigned, if_clear) & ~mask));
+}
+
+template <int LEVEL>
+__device__ __forceinline__ float tfold_pair(float lo, float hi, const ButterflyMasks &bm)
+{
+    if constexpr (LEVEL == 0) {
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        return lo + hi;
+    } else if constexpr (LEVEL == 1) {
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        return lo + hi;
+    } else if constexpr (LEVEL == 2) {
+        float out;
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+            : "=&v"(out) : "v"(lo), "v"(hi));
+        return out;
+    } else if constexpr (LEVEL == 3) { // row_ror:n = lane i reads lane (i - n) mod 16 of its row
+        float out;
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xa"
+            : "=&v"(out) : "v"(lo), "v"(hi));
+        return out;
+    } else if constexpr (LEVEL == 4) {
+        return bit_select(bm.m1, hi + dpp_mov<0x4E>(hi), lo + dpp_mov<0x4E>(lo)); // quad_perm [2,3,0,1]
+    } else {
+        return bit_select(bm.m0, hi + dpp_mov<0xB1>(hi), lo + dpp_mov<0xB1>(lo)); // quad_perm [1,0,3,2]
+    }
 }
 
 template <int N, int LEVEL>
-__device__ __forceinline__ void tfold(const float (&in)[N], float (&out)[(N + 1) / 2], int lane)
+__device__ __forceinline__ void tfold(const float (&in)[N], float (&out)[(N + 1) / 2], const ButterflyMasks &bm)
 {
-    const bool role = lane_role(lane, LEVEL) != 0;
 #pragma unroll
-    for (int j = 0; j < (N + 1) / 2; ++j) {
-        const float lo = in[2 * j];
-        const float hi = (2 * j + 1 < N) ? in[2 * j + 1] : 0.0f;
-        const float send = role ? lo : hi;
-        const float keep = role ? hi : lo;
-        out[j] = keep + lane_xchg<LEVEL>(send);
-    }
+    for (int j = 0; j < (N + 1) / 2; ++j) out[j] = tfold_pair<LEVEL>(in[2 * j], (2 * j + 1 < N) ? in[2 * j + 1] : 0.0f, bm);
 }
 
 // in[N] per lane -> out[ceil(N/64)] per lane, out[m] = total of column 64*m + lane_column(lane)
@@ -402,13 +427,14 @@ __device__ __forceinline__ void wave_transpose_sum(const float (&in)[N], float (
 {
     constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2, N6 = (N5 + 1) / 2;
     static_assert(N6 == (N + 63) / 64, "ceil-halving six times equals ceil(N/64)");
+    const ButterflyMasks bm(lane);
     float a1[N1], a2[N2], a3[N3], a4[N4], a5[N5];
-    tfold<N, 0>(in, a1, lane);
-    tfold<N1, 1>(a1, a2, lane);
-    tfold<N2, 2>(a2, a3, lane);
-    tfold<N3, 3>(a3, a4, lane);
-    tfold<N4, 4>(a4, a5, lane);
-    tfold<N5, 5>(a5, out, lane);
+    tfold<N, 0>(in, a1, bm);
+    tfold<N1, 1>(a1, a2, bm);
+    tfold<N2, 2>(a2, a3, bm);
+    tfold<N3, 3>(a3, a4, bm);
+    tfold<N4, 4>(a4, a5, bm);
+    tfold<N5, 5>(a5, out, bm);
 }
 
 } // namespace mppi

@@ -331,12 +331,15 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
 #pragma unroll
                         for (int j = 0; j < A; ++j) zz[j] = z[tl * A + j];
                         scale_noise<A, DIAG>(PC, zz, e);
+                        // steps past the horizon (ragged last group) must not enter the weighted sum: a wave-uniform factor
+                        // 1.0 / 0.0 in an SGPR (exact), NOT `t < H ? e : 0`, which hipcc turns into a v_cndmask_b32 on VCC:
+                        // 19 cycles per instruction on this part against 2.3 for the multiply (tools/micro/valu_issue.hip).
+                        // (Copying e into eps_r through an operation also keeps hipcc at 94 live VGPRs instead of 114.)
+                        const float keep = t < H ? 1.0f : 0.0f;
 #pragma unroll
                         for (int j = 0; j < A; ++j) {
                             u[j] = ug[tl][j];
-                            // (the select costs 1 instruction but saves 20 VGPRs: hipcc keeps 94 instead of 114 live, which
-                            //  is the 5th resident workgroup per CU for grids of several rounds)
-                            eps_r[(i * 4 + tl) * A + j] = t < H ? e[j] : 0.0f;
+                            eps_r[(i * 4 + tl) * A + j] = e[j] * keep;
                             cb[(tl * (A + 1) + j) * 64 + lane] = u[j] + e[j]; // to_apply, :258
                         }
                         cb[(tl * (A + 1) + A) * 64 + lane] = action_cost<A, DIAG>(PC, u, e);
@@ -1302,359 +1305,6 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
 
     mlp_tile_record<A, DIAG>(C, c, valid, w, lane, kk, H, NG, SRC, eps_hbm, seed, gk, base,
                              partials + (size_t)blockIdx.x * rsb, rsc); // element (b, col) at partials[b*rsb + col*rsc]
-}
-
-// ----------------------------------------------------------------------------------------
-// k_rollout_mlp_bx3p: k_rollout_mlp_bx3 with TWO sets of 64 rollouts per workgroup, software-pipelined so that the
-// per-step scalar chain of one set (partial-sum exchange -> state update -> cost -> noise -> normalise -> split) runs
-// inside the layer-2 MFMA stream of the other. In k_rollout_mlp_bx3 that chain is replicated in all 8 waves and serial
-// with the MFMAs (of 13.8 k cycles per horizon step 6.1 k are the MFMA stream, tools/timeline_mlp.py); here
-//   * ONE wave per set (wave q for set q) owns the set's state, running cost and chain, cut into pieces that are
-//     issued between the k-blocks of its layer-2 MFMAs of the OTHER set; it publishes the layer-1 B fragments of its set
-//     in LDS (8 KB), so the other waves need neither the state nor the exchange through lanes;
-//   * half-iteration h (q = h&1, step t = h>>1):  [frag(q) -> layer 1 -> relu/split -> image] barrier
-//     [layer 2(q) MFMAs || chain(1-q): finish step (h-1)>>1, prepare the next] [layer 3(q) -> partial y(q)] barrier;
-//     one 64 KB image serves both sets (it is rewritten only after the barrier that ends its readers' phase).
-// LDS: 64 KB image + 8 KB fragments + 24 KB partial y + 6 KB W3 + 12 KB noise + 1.5 KB b2/costs = 116 KB.
-constexpr int kMlpR2 = 128;
-__host__ __device__ inline size_t mlp_bx3p_lds_floats(int S, int A)
-{
-    return (size_t)kHid * 64 + 2048 + 2 * 8 * S * 64 + kHid * S + 2 * 2 * 4 * A * 64 + kHid + 2 * 64 + 64;
-}
-
-template <int A, bool DIAG>
-__global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3p(
-    const DevConsts *__restrict__ C, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
-    const float *__restrict__ U_dev, const float *__restrict__ eps_hbm,
-    const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
-    const int SRC, const int MODE, const int rsb, const int rsc)
-{
-    constexpr bool QFULL = false;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int S = 2 * A, NIN = S + A;
-    static_assert(NIN + 1 <= 16, "inputs + bias must fit one k-block");
-    const int H = C->H, HA = H * A, K = C->K_local;
-    const int NG = (H + 3) / 4;
-    bf16x8 *img = reinterpret_cast<bf16x8 *>(smem);              // [2 parts][16 k-blocks][2 halves][64] x 16 B
-    bf16x8 *frag = reinterpret_cast<bf16x8 *>(smem + kHid * 64); // [2 sets][2 parts][2 halves][64] x 16 B
-    float *y_s = smem + kHid * 64 + 2048;                        // [2 sets][8][S][64]
-    float *w3_s = y_s + 2 * 8 * S * 64;                          // [kHid][S]
-    float *z_s = w3_s + kHid * S;                                // [2 sets][2][4*A][64]
-    float *b2_s = z_s + 2 * 2 * 4 * A * 64;                      // [kHid]
-    float *c_s = b2_s + kHid;                                    // [2 sets][64]
-
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, j = lane & 31, hh = lane >> 5;
-    const int k0 = blockIdx.x * kMlpR2;
-
-    // ---- stationary weights -> registers (hi/lo bf16 fragments), as k_rollout_mlp_bx3
-    const int unit = 32 * w + j;
-    bf16x8 a2h[16], a2l[16], a1h, a1l;
-#pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 16 * s2 + 8 * (e >> 2) + 4 * hh + (e & 3);
-            __bf16 hi, lo;
-            split_bf16(M->W2[(size_t)k * kHid + unit], hi, lo);
-            a2h[s2][e] = hi; a2l[s2][e] = lo;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = 8 * hh + e;
-        const float wv = k < NIN ? M->W1[(size_t)k * kHid + unit] : (k == NIN ? M->b1[unit] : 0.0f);
-        __bf16 hi, lo;
-        split_bf16(wv, hi, lo);
-        a1h[e] = hi; a1l[e] = lo;
-    }
-    for (int i = tid; i < kHid * S; i += kMlpThreads) w3_s[i] = M->W3[i];
-    for (int i = tid; i < kHid; i += kMlpThreads) b2_s[i] = M->b2[i];
-
-    // ---- the chain wave of set cq (waves 0 and 1): state, cost and constants of ITS set only
-    const bool chain = w < 2;
-    const int cq = w & 1;
-    const bool valid = (k0 + 64 * cq + lane) < K; // meaningful on chain waves
-    const int kk = valid ? k0 + 64 * cq + lane : K - 1;
-    float x[S];
-#pragma unroll
-    for (int i = 0; i < S; ++i) x[i] = x_dev[i];
-    float c = 0.0f, ac_pend = 0.0f;
-    float xm[NIN], xr[NIN], b3v[S], ysd[S], ymn[S];
-#pragma unroll
-    for (int i = 0; i < NIN; ++i) { xm[i] = M->xmean[i]; xr[i] = 1.0f / M->xstd[i]; }
-#pragma unroll
-    for (int i = 0; i < S; ++i) { b3v[i] = M->b3[i]; ysd[i] = M->ystd[i]; ymn[i] = M->ymean[i]; }
-    PcProducerConsts<A> pcst;
-    pcst.template load<DIAG>(C);
-    const PcProducerConsts<A> *PC = &pcst;
-    PcConsumerConsts<S> ccst;
-    ccst.load(C);
-    const PcConsumerConsts<S> *CC = &ccst;
-    const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
-    const unsigned long long seed = C->seed;
-    const unsigned long long koff = (unsigned long long)C->k_offset;
-    // global sample index of (set q, this lane), clamped: lanes past K recompute the last sample and are masked later
-    auto gk_of = [&](int q) { return koff + (unsigned long long)min(k0 + 64 * q + lane, K - 1); };
-
-    // inputs of step t of this wave's set -> B fragments in LDS, and the step's action cost (chain waves only)
-    auto prepare = [&](int t) {
-        float u[A], e[A], v[A];
-        if (SRC == SRC_PHILOX) {
-            const float *zb = z_s + ((cq * 2 + ((t >> 2) & 1)) * 4 * A + (t & 3) * A) * 64 + lane;
-            float zz[A];
-#pragma unroll
-            for (int i = 0; i < A; ++i) zz[i] = zb[i * 64];
-            scale_noise<A, DIAG>(PC, zz, e);
-        } else {
-#pragma unroll
-            for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
-        }
-#pragma unroll
-        for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
-        ac_pend = action_cost<A, DIAG>(PC, u, e);
-        bf16x8 f0h, f0l, f1h, f1l;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float val = 0.0f;
-            if (i < S) val = (x[i] - xm[i]) * xr[i];
-            else if (i < NIN) val = (v[i - S] - xm[i]) * xr[i];
-            else if (i == NIN) val = 1.0f;
-            __bf16 hi, lo;
-            split_bf16(val, hi, lo);
-            if (i < 8) { f0h[i] = hi; f0l[i] = lo; } else { f1h[i - 8] = hi; f1l[i - 8] = lo; }
-        }
-        bf16x8 *fq = frag + cq * 256; // [part][half][64]
-        fq[(0 * 2 + 0) * 64 + lane] = f0h; fq[(0 * 2 + 1) * 64 + lane] = f1h;
-        fq[(1 * 2 + 0) * 64 + lane] = f0l; fq[(1 * 2 + 1) * 64 + lane] = f1l;
-    };
-    // y = Σ_waves partial + b3 (fixed order) -> state update -> cost of the finished step (chain waves only)
-    float ysum[S];
-    auto finish_step = [&]() {
-#pragma unroll
-        for (int n = 0; n < S; ++n) {
-            const float y = ysum[n] + b3v[n];
-            x[n] = x[n] + (y * ysd[n] + ymn[n]);
-        }
-        const float sc = state_cost<S, QFULL>(CC, x); // cost on the POST-step state
-        const float tmp = sc + ac_pend;
-        c = c + tmp;
-    };
-
-    if (SRC == SRC_PHILOX && w < 2) { // horizon group 0 of set w
-        float z[4 * A];
-        normals_group<A>(seed, gk_of(w), base, z);
-#pragma unroll
-        for (int m = 0; m < 4 * A; ++m) z_s[((w * 2 + 0) * 4 * A + m) * 64 + lane] = z[m];
-    }
-    __syncthreads();
-    if (chain) prepare(0);
-    __syncthreads();
-
-#if defined(MPPI_MLP_TIMELINE)
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = pc_stamp();
-#endif
-    for (int h2 = 0; h2 < 2 * H; ++h2) {
-        const int q = h2 & 1, t = h2 >> 1;
-#if defined(BX3P_DBG) && (BX3P_DBG & 2)
-        __syncthreads();
-#endif
-        // ---- layer 1 of set q from its published fragments
-        const bf16x8 *fq = frag + q * 256;
-        const bf16x8 b0h = fq[(0 * 2 + hh) * 64 + j], b1h = fq[(0 * 2 + hh) * 64 + 32 + j];
-        const bf16x8 b0l = fq[(1 * 2 + hh) * 64 + j], b1l = fq[(1 * 2 + hh) * 64 + 32 + j];
-        f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        f32x16 acc1 = acc0;
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc1, 0, 0, 0);
-#pragma unroll
-        for (int s1 = 0; s1 < 2; ++s1) {
-            bf16x8 h0h, h0l, h1h, h1l;
-#pragma unroll
-            for (int e2 = 0; e2 < 8; ++e2) {
-                __bf16 hi, lo;
-                split_bf16(fmaxf(acc0[8 * s1 + e2], 0.0f), hi, lo);
-                h0h[e2] = hi; h0l[e2] = lo;
-                split_bf16(fmaxf(acc1[8 * s1 + e2], 0.0f), hi, lo);
-                h1h[e2] = hi; h1l[e2] = lo;
-            }
-            const int kb = 2 * w + s1;
-            img[((0 * 16 + kb) * 2 + hh) * 64 + j] = h0h;
-            img[((1 * 16 + kb) * 2 + hh) * 64 + j] = h0l;
-            img[((0 * 16 + kb) * 2 + hh) * 64 + 32 + j] = h1h;
-            img[((1 * 16 + kb) * 2 + hh) * 64 + 32 + j] = h1l;
-        }
-        MLP_PH(0); // fragments -> layer 1 -> relu/split -> image
-        __syncthreads();
-        MLP_PH(1); // barrier A
-
-        // the next horizon group's normals of set q, once per workgroup (waves 2..7 in turn), other buffer half
-        if (SRC == SRC_PHILOX && (t & 3) == 0) {
-            const int gn = (t >> 2) + 1;
-            if (gn < NG && 2 + (gn % 6) == w) {
-                float z[4 * A];
-                normals_group<A>(seed, gk_of(q), base + (unsigned long long)gn, z);
-                float *zd = z_s + ((q * 2 + (gn & 1)) * 4 * A) * 64 + lane;
-#pragma unroll
-                for (int m = 0; m < 4 * A; ++m) zd[m * 64] = z[m];
-            }
-        }
-
-        // ---- layer 2 of set q; on the chain wave of set 1-q its chain runs between the k-blocks
-        const bool my_chain = chain && cq == 1 - q && h2 >= 1; // wave-uniform
-        const int tc = (h2 - 1) >> 1;                           // the step of set 1-q whose layer 3 has just finished
-        {
-            const float *bp = b2_s + 32 * w + 4 * hh;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float bv = bp[(r & 3) + 8 * (r >> 2)]; acc0[r] = bv; acc1[r] = bv; }
-        }
-        const bf16x8 *ih = img + hh * 64 + j, *il = img + (16 * 2 + hh) * 64 + j;
-        const float *yq = y_s + (size_t)cq * 8 * S * 64 + lane;
-        float yld[2][8];
-        static_for<0, 16>([&](auto ikb) {
-            constexpr int kb = decltype(ikb)::value;
-            const bf16x8 q0h = ih[kb * 128], q0l = il[kb * 128], q1h = ih[kb * 128 + 32], q1l = il[kb * 128 + 32];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2l[kb], q0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2l[kb], q1h, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2h[kb], q0l, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2h[kb], q1l, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2h[kb], q0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2h[kb], q1h, acc1, 0, 0, 0);
-            if constexpr (kb <= S / 2 + 1) {
-                if (my_chain) {
-                    // The fragment registers of the MFMAs just issued are dead for the compiler, so the first vector
-                    // instruction of this piece may overwrite them while the matrix core is still reading them (seen:
-                    // v_pk_add_f32 into the B operand two slots after its v_mfma, across the branch; 16-lane groups of
-                    // rollouts came out wrong, at random). hipcc pads no wait states here; a full MFMA duration does.
-                    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (kb >= 1 && kb <= S / 2) { // sums of the pair loaded one piece earlier (fixed wave order)
-#pragma unroll
-                        for (int p = 0; p < 2; ++p) {
-                            float y = yld[p][0];
-#pragma unroll
-                            for (int ww = 1; ww < 8; ++ww) y = y + yld[p][ww];
-                            ysum[2 * (kb - 1) + p] = y;
-                        }
-                    }
-                    if constexpr (kb < S / 2) { // loads of output pair kb, summed in the next piece
-#pragma unroll
-                        for (int ww = 0; ww < 8; ++ww) {
-                            yld[0][ww] = yq[(ww * S + 2 * kb) * 64];
-                            yld[1][ww] = yq[(ww * S + 2 * kb + 1) * 64];
-                        }
-                    }
-                    if constexpr (kb == S / 2) finish_step();
-                    if constexpr (kb == S / 2 + 1) { if (tc + 1 < H) prepare(tc + 1); }
-                }
-            }
-        });
-
-#if defined(BX3P_DBG) && (BX3P_DBG & 1)
-        __syncthreads();
-#endif
-        MLP_PH(2); // layer-2 MFMAs issued (+ the other set's chain on its wave)
-        // ---- layer 3 partial over this wave's 32 units, both column blocks of set q, fp32 VALU
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 py[S];
-#pragma unroll
-        for (int n = 0; n < S; ++n) py[n] = (f32x2){0.0f, 0.0f};
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const f32x2 hv = {fmaxf(acc0[r], 0.0f), fmaxf(acc1[r], 0.0f)};
-            const float *w3 = w3_s + (32 * w + row) * S;
-#pragma unroll
-            for (int n = 0; n < S; ++n) {
-                const float wv = w3[n];
-                py[n] = __builtin_elementwise_fma(hv, (f32x2){wv, wv}, py[n]);
-            }
-        }
-        float *yw = y_s + ((size_t)(q * 8 + w) * S) * 64 + lane;
-#pragma unroll
-        for (int n = 0; n < S; ++n) { // halves hold different rows: lane half hh keeps column block hh
-            const float keep = hh ? py[n][1] : py[n][0];
-            const float send = hh ? py[n][0] : py[n][1];
-            yw[n * 64] = keep + __shfl_xor(send, 32, 64);
-        }
-        MLP_PH(3); // layer 3 (waits for the MFMA results) + partial writes
-        __syncthreads();
-        MLP_PH(4); // barrier B
-    }
-#if defined(MPPI_MLP_TIMELINE)
-    {
-        float v_ = 0.f;
-#pragma unroll
-        for (int q2 = 0; q2 < 8; ++q2) v_ = lane == q2 ? (float)tph[q2] : v_;
-        if (lane < 8 && k0 + 8 * w + lane < K) cost[k0 + 8 * w + lane] = v_; // wave w's phase totals at cost[k0 + 8w ..]
-        return;
-    }
-#endif
-    // set 1's last step is still to be finished (set 0's was, inside the last half-iteration)
-    if (chain && cq == 1) {
-#pragma unroll
-        for (int n = 0; n < S; ++n) {
-            const float *yq = y_s + (size_t)8 * S * 64 + lane;
-            float y = yq[(0 * S + n) * 64];
-#pragma unroll
-            for (int ww = 1; ww < 8; ++ww) y = y + yq[(ww * S + n) * 64];
-            ysum[n] = y;
-        }
-        finish_step();
-    }
-    if (chain) {
-        c = c + state_cost<S, QFULL>(CC, x); // terminal cost, controller_base.cpp:271-272
-        if (valid) cost[k0 + 64 * cq + lane] = c;
-        c_s[cq * 64 + lane] = c;
-    }
-    if (MODE == MODE_COST_ONLY) return;
-    __syncthreads();
-
-    // ---- tile record over the 128 rollouts (set 0 then set 1 in every sum: fixed order)
-    const bool v0 = (k0 + lane) < K, v1 = (k0 + 64 + lane) < K;
-    const float c0 = c_s[lane], c1 = c_s[64 + lane];
-    const float beta = fminf(wave_min(v0 ? c0 : INFINITY), wave_min(v1 ? c1 : INFINITY));
-    const float e0 = v0 ? expf(C->neg_inv_lambda * (c0 - beta)) : 0.0f;
-    const float e1 = v1 ? expf(C->neg_inv_lambda * (c1 - beta)) : 0.0f;
-    const float eta = wave_sum(e0) + wave_sum(e1);
-    float *rec = partials + (size_t)blockIdx.x * rsb; // element (b, col) at partials[b*rsb + col*rsc]
-    if (w == 0 && lane == 0) { rec[0] = beta; rec[(size_t)rsc] = eta; }
-    const int kk0 = min(k0 + lane, K - 1), kk1 = min(k0 + 64 + lane, K - 1);
-    for (int g = w; g < NG; g += 8) {
-        float za[4 * A], zb[4 * A];
-        if (SRC == SRC_PHILOX) {
-            normals_group<A>(seed, gk_of(0), base + (unsigned long long)g, za);
-            normals_group<A>(seed, gk_of(1), base + (unsigned long long)g, zb);
-        }
-#pragma unroll
-        for (int tl = 0; tl < 4; ++tl) {
-            const int t = 4 * g + tl;
-            if (t < H) {
-                float z1[A], ea[A], eb[A];
-                if (SRC == SRC_PHILOX) {
-#pragma unroll
-                    for (int i = 0; i < A; ++i) z1[i] = za[tl * A + i];
-                    scale_noise<A, DIAG>(C, z1, ea);
-#pragma unroll
-                    for (int i = 0; i < A; ++i) z1[i] = zb[tl * A + i];
-                    scale_noise<A, DIAG>(C, z1, eb);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < A; ++i) { ea[i] = eps_hbm[(size_t)kk0 * HA + t * A + i]; eb[i] = eps_hbm[(size_t)kk1 * HA + t * A + i]; }
-                }
-#pragma unroll
-                for (int i = 0; i < A; ++i) {
-                    const float tot = wave_sum_dpp(e0 * ea[i]) + wave_sum_dpp(e1 * eb[i]);
-                    if (lane == 0) rec[(size_t)(2 + t * A + i) * rsc] = tot;
-                }
-            }
-        }
-    }
 }
 
 // min / max of the costs (Py normalizeCost, controller_base.py:468-474): out[0]=min, out[1]=max-min

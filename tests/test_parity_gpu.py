@@ -491,9 +491,9 @@ def test_mlp_rollout_costs_within_fp32_of_truth(m, K, H, a, bx3):
     assert err_gpu.max() < (8 if bx3 else 4) * max(err_cpu.max(), 1e-6), (err_gpu.max(), err_cpu.max())
 
 
-# The three MLP rollout kernels: k_rollout_mlp (exact-fp32 MFMA, the default), k_rollout_mlp_bx3 (MPPI_FLAG_MLP_BF16X3)
-# and k_rollout_mlp_bx3p (MPPI_FLAG_MLP_BF16X3_PIPELINED). Bars on the control update U' (absolute, against the fp64
-# oracle on identical noise): north_star's 1e-5 for the exact-fp32 kernel; 2e-5 for the split-bf16 kernels (their
+# The two MLP rollout kernels: k_rollout_mlp (exact-fp32 MFMA, the default) and k_rollout_mlp_bx3
+# (MPPI_FLAG_MLP_BF16X3). Bars on the control update U' (absolute, against the fp64
+# oracle on identical noise): north_star's 1e-5 for the exact-fp32 kernel; 2e-5 for the split-bf16 kernel (its
 # operands carry 16 mantissa bits: measured 2-5x the fp32 kernel's error). Both are ALWAYS held to a small multiple of
 # the error the fp32 CPU oracle itself makes against fp64 (the reference computes in fp32 too): no worse than 4x / 8x.
 # The absolute bar applies where the problem is conditioned for it, i.e. where the fp32 CPU evaluation itself lands
@@ -501,8 +501,7 @@ def test_mlp_rollout_costs_within_fp32_of_truth(m, K, H, a, bx3):
 # with few samples, a long horizon (large costs) and lambda = 1 ANY two fp32 evaluations of the reference's graph
 # differ by more than 1e-5 (the K=512, H=128 case below: fp32 CPU 1.3e-5, this kernel 1.3e-5) — "within 1e-5 of the
 # reference" is then not defined by the reference either.
-MLP_VARIANTS = [("fp32mfma", {}, 1e-5, 4.0), ("bf16x3", dict(mlp_bf16x3=True), 2e-5, 8.0),
-                ("bf16x3p", dict(mlp_bf16x3_pipelined=True), 2e-5, 8.0)]
+MLP_VARIANTS = [("fp32mfma", {}, 1e-5, 4.0), ("bf16x3", dict(mlp_bf16x3=True), 2e-5, 8.0)]
 MLP_IDS = [v[0] for v in MLP_VARIANTS]
 _oracle_cache = {}
 
@@ -580,7 +579,7 @@ def test_mlp_next_matches_oracle(m, name, kw, u_bar, factor):
                          ids=["K65536_H8", "K8192_H128", "K512_H128_illconditioned", "K1000_H130_lam8"])
 def test_mlp_baseline_shapes_against_oracle(m, K, H, lam, cond, name, kw, u_bar, factor):
     """The BASELINE shapes' two long axes, each against the CPU oracle: K = 65536 (configs[3]: 1024 workgroups = 4
-    rounds per CU, a 1024-record finish; 512 for the 128-rollout pipelined kernel) at a horizon the oracle finishes in
+    rounds per CU, a 1024-record finish) at a horizon the oracle finishes in
     seconds, and H = 128 (configs[4]) / a ragged 130. The absolute 1e-5 bar holds wherever fp32 itself can hold it; the
     K=512, H=128, lambda=1 case documents where it cannot (see MLP_VARIANTS) and is held to the fp32 CPU's own error."""
     check_mlp_step(m, K, H, 3, 100 + H, kw, u_bar, factor, lam=lam, well_conditioned=cond)
@@ -990,32 +989,6 @@ def test_sequence_filter_matches_scipy_savgol(m, window, order):
     for bad in [(10, 9), (H + 1, 2), (5, 5)]:
         with pytest.raises(m.MppiError):
             h.set_sequence_filter(*bad)
-
-
-def test_mlp_bf16x3_pipelined_variant_is_bit_identical(m):
-    """k_rollout_mlp_bx3p (MPPI_FLAG_MLP_BF16X3_PIPELINED: two 64-rollout sets per workgroup, the scalar chain of one inside the
-    MFMA stream of the other) must give the SAME bits as k_rollout_mlp_bx3, run after run. This is the regression test
-    of a hardware hazard found while building it: a vector instruction that overwrites an MFMA's source registers right
-    after the MFMA issues (across a branch, where hipcc pads nothing) corrupts 16-lane groups of rollouts at random."""
-    a, s = 3, 6
-    for K, H in [(2048, 32), (300, 64), (4096, 17)]:
-        mlp = make_mlp(s, a, seed=K)
-        cfg = dict(k=K, tau=H, s_dim=s, a_dim=a, lam=1.0, sigma=0.25 * np.eye(a), goal=GOAL3, mlp=mlp, mlp_bf16x3=True, seed=3)
-        h0 = m.Handle(**cfg)
-        h1 = m.Handle(mlp_bf16x3_pipelined=True, **cfg)
-        rng = np.random.default_rng(5)
-        x0 = (0.2 * rng.standard_normal(s)).astype(F32)
-        U = (0.1 * rng.standard_normal((H, a))).astype(F32)
-        eps = (0.25 * rng.standard_normal((K, H, a))).astype(F32)
-        c0 = h0.rollout_cost(x0, U, eps)
-        for _ in range(3):
-            np.testing.assert_array_equal(h1.rollout_cost(x0, U, eps), c0)
-        # a whole step on the fused Philox path: same sample costs; the controls differ only by the grouping of the
-        # soft-min sums (128- instead of 64-rollout tile records)
-        u1, u0 = h1.next(x0), h0.next(x0)
-        np.testing.assert_array_equal(h1.debug_get(m.DBG_COSTS), h0.debug_get(m.DBG_COSTS))
-        np.testing.assert_allclose(u1, u0, rtol=0, atol=1e-6)
-        np.testing.assert_allclose(h1.get_action_sequence(), h0.get_action_sequence(), rtol=0, atol=1e-6)
 
 
 @pytest.mark.parametrize("fault", ["", "export", "probe"])

@@ -34,6 +34,12 @@
 #define I_ADD(n) "v_add_f32_e32 v" #n ", v2, v" #n "\n\t"
 #define I_MOV(n) "v_mov_b32_e32 v" #n ", v1\n\t"
 #define I_CND(n) "v_cndmask_b32_e32 v" #n ", v1, v" #n ", vcc\n\t"
+#define I_CND_NODEP(n) "v_cndmask_b32_e32 v" #n ", v1, v2, vcc\n\t"
+#define I_CND_E64(n) "v_cndmask_b32_e64 v" #n ", v1, v" #n ", s[44:45]\n\t"
+#define I_CND_ONES(n) "v_cndmask_b32_e64 v" #n ", v1, v" #n ", s[46:47]\n\t"
+#define I_MAXF(n) "v_max_f32_e32 v" #n ", v1, v" #n "\n\t"
+#define I_PERM(n) "ds_bpermute_b32 v" #n ", v8, v" #n "\n\t"
+#define I_READLANE(n) "v_readlane_b32 s43, v" #n ", 3\n\t"
 #define I_XOR(n) "v_xor_b32_e32 v" #n ", v3, v" #n "\n\t"
 #define I_BITOP3(n) "v_bitop3_b32 v" #n ", v" #n ", v3, v1 bitop3:0x96\n\t"
 #define I_CVT(n) "v_cvt_f32_u32_e32 v" #n ", v" #n "\n\t"
@@ -56,6 +62,8 @@
 #define I_DSW(n) "ds_write_b32 v8, v" #n " offset:" #n "*256\n\t"
 #define I_DSR(n) "ds_read_b32 v" #n ", v8 offset:" #n "*256\n\t"
 #define I_SNOP(n) "s_nop 0\n\t"
+#define I_SNOP7(n) "s_nop 7\n\t"
+#define I_SNOP15(n) "s_nop 15\n\t"
 // the Philox4x32-10 round as the rollout kernel issues it: 2 x v_mad_u64_u32 + 2 x v_bitop3_b32, each round dependent on
 // the previous one (8 independent blocks in flight per wave here; the kernel has A = 3 per horizon group)
 #define I_PHILOX(a, b) "v_mad_u64_u32 v[" #a ":" #b "], s[40:41], v" #a ", v3, 0\n\t" \
@@ -65,7 +73,7 @@
     "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", \
         "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", \
         "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", \
-        "v61", "v62", "v63", "s40", "s41", "s42", "scc", "vcc", "memory"
+        "v61", "v62", "v63", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "scc", "vcc", "memory"
 
 // init: positive finite floats (log/sqrt stay finite: values collapse to fixed points, the issue rate does not depend
 // on the data), LDS address v8 = lane*4 (conflict-free ds_read/write_b32), vcc = alternating lanes
@@ -74,6 +82,7 @@
     "v_mov_b32 v4, 0x3f800347\n\tv_mov_b32 v5, 0x3f7fff58\n\tv_mov_b32 v6, 0x3a83126f\n\tv_mov_b32 v7, 0x3a83126f\n\t"  \
     "v_mbcnt_lo_u32_b32 v8, -1, 0\n\tv_mbcnt_hi_u32_b32 v8, -1, v8\n\tv_lshlrev_b32 v8, 2, v8\n\t"                      \
     "s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\t"                                                 \
+    "s_mov_b32 s44, 0x55555555\n\ts_mov_b32 s45, 0x55555555\n\ts_mov_b64 s[46:47], -1\n\t"                            \
     "v_mov_b32 v16, 2.0\n\tv_mov_b32 v17, 2.0\n\tv_mov_b32 v18, 2.0\n\tv_mov_b32 v19, 2.0\n\t"                          \
     "v_mov_b32 v20, 2.0\n\tv_mov_b32 v21, 2.0\n\tv_mov_b32 v22, 2.0\n\tv_mov_b32 v23, 2.0\n\t"                          \
     "v_mov_b32 v24, 2.0\n\tv_mov_b32 v25, 2.0\n\tv_mov_b32 v26, 2.0\n\tv_mov_b32 v27, 2.0\n\t"                          \
@@ -118,6 +127,12 @@ DEFINE_KERNEL(k_mul, R16(I_MUL))
 DEFINE_KERNEL(k_add, R16(I_ADD))
 DEFINE_KERNEL(k_mov, R16(I_MOV))
 DEFINE_KERNEL(k_cndmask, R16(I_CND))
+DEFINE_KERNEL(k_cndmask_nodep, R16(I_CND_NODEP))
+DEFINE_KERNEL(k_cndmask_e64, R16(I_CND_E64))
+DEFINE_KERNEL(k_cndmask_ones, R16(I_CND_ONES))
+DEFINE_KERNEL(k_max, R16(I_MAXF))
+DEFINE_KERNEL(k_bpermute, R16(I_PERM))
+DEFINE_KERNEL(k_readlane, R16(I_READLANE))
 DEFINE_KERNEL(k_xor, R16(I_XOR))
 DEFINE_KERNEL(k_bitop3, R16(I_BITOP3))
 DEFINE_KERNEL(k_cvt_f32_u32, R16(I_CVT))
@@ -140,6 +155,8 @@ DEFINE_KERNEL(k_add_f64, P16(I_ADDF64))
 DEFINE_KERNEL(k_ds_write_b32, R16(I_DSW))
 DEFINE_KERNEL(k_ds_read_b32, R16(I_DSR))
 DEFINE_KERNEL(k_s_nop, R16(I_SNOP))
+DEFINE_KERNEL(k_s_nop7, R16(I_SNOP7))
+DEFINE_KERNEL(k_s_nop15, R16(I_SNOP15))
 // 16 x (mad64 + bitop3) = 32 instructions per sweep: counted as 64 per BODY pair below (insts_per_body = 32)
 DEFINE_KERNEL(k_philox_round, "v_mad_u64_u32 v[32:33], s[40:41], v32, v3, 0\n\tv_mad_u64_u32 v[34:35], s[40:41], v34, v3, 0\n\t"
                               "v_mad_u64_u32 v[36:37], s[40:41], v36, v3, 0\n\tv_mad_u64_u32 v[38:39], s[40:41], v38, v3, 0\n\t"
@@ -156,6 +173,9 @@ int main(int argc, char **argv)
     const Op ops[] = {
         {"v_fma_f32", k_fma, 16, "fp32"}, {"v_mul_f32", k_mul, 16, "fp32"}, {"v_add_f32", k_add, 16, "fp32"},
         {"v_fmamk_f32", k_fmamk, 16, "fp32"}, {"v_mov_b32", k_mov, 16, "move"}, {"v_cndmask_b32", k_cndmask, 16, "move"},
+        {"v_cndmask_b32 (sources not the destination)", k_cndmask_nodep, 16, "move"},
+        {"v_cndmask_b32_e64 (mask in s[44:45])", k_cndmask_e64, 16, "move"}, {"v_cndmask_b32_e64 (mask all ones)", k_cndmask_ones, 16, "move"},
+        {"v_max_f32", k_max, 16, "fp32"}, {"ds_bpermute_b32", k_bpermute, 16, "lds"}, {"v_readlane_b32", k_readlane, 16, "move"},
         {"v_xor_b32", k_xor, 16, "int"}, {"v_bitop3_b32", k_bitop3, 16, "int"}, {"v_cvt_f32_u32", k_cvt_f32_u32, 16, "cvt"},
         {"v_log_f32", k_log, 16, "trans"}, {"v_sqrt_f32", k_sqrt, 16, "trans"}, {"v_sin_f32", k_sin, 16, "trans"},
         {"v_exp_f32", k_exp, 16, "trans"}, {"v_rcp_f32", k_rcp, 16, "trans"},
@@ -165,7 +185,7 @@ int main(int argc, char **argv)
         {"v_pk_mul_f32", k_pk_mul, 16, "pk-fp32"}, {"v_pk_add_f32", k_pk_add, 16, "pk-fp32"}, {"v_pk_fma_f32", k_pk_fma, 16, "pk-fp32"},
         {"v_add_f64", k_add_f64, 16, "fp64"},
         {"ds_write_b32", k_ds_write_b32, 16, "lds"}, {"ds_read_b32", k_ds_read_b32, 16, "lds"},
-        {"s_nop 0", k_s_nop, 16, "scalar"},
+        {"s_nop 0", k_s_nop, 16, "scalar"}, {"s_nop 7", k_s_nop7, 16, "scalar"}, {"s_nop 15", k_s_nop15, 16, "scalar"},
         {"philox-like: 6 chains of (v_mad_u64_u32 -> v_bitop3_b32 -> v_mov), dependent", k_philox_round, 16, "mix"},
     };
     const int ITERS = 1024;

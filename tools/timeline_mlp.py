@@ -24,7 +24,7 @@ u = torch.zeros(a, device="cuda")
 for _ in range(2):
     h.next_device(x.data_ptr(), u.data_ptr())
 h.synchronize()
-pipe = os.environ.get("MPPI_MLP_BX3_PIPE") == "1"
+pipe = False
 c = h.debug_get(m.DBG_COSTS)
 if pipe:  # 128 rollouts per workgroup: the first 64 cost slots of every block hold [wave][phase]; units = half-iterations
     c = c.reshape(-1, 128)[:, :64]
