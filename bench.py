@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — rollouts/s of the MPPI control step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload pm3d|pm2d|pm1d|mlp] [--horizon H] [--samples K_PER_GPU]
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is ONE control step of the hot path: K rollouts x H model steps + costs + soft-min update
-+ shift, with the state x and the nominal sequence U already resident in HBM and the noise drawn on
-the device (Philox). Workload at N=1: BASELINE configs[2], point_mass3d analytic, K=65536, H=64 —
-the configuration the metric is quoted on. N>1 is WEAK scaling: every rank keeps K=65536 samples of
-a K·N-sample controller, with one all-gather of the (beta, eta, V) record per step (RCCL).
-Rank 0 prints ONE JSON line (value = whole-job rollouts/s, max-over-ranks time).
+A "step" is ONE control step of the hot path: K rollouts x H model steps + costs + soft-min update + shift, with the
+state x and the nominal sequence U already resident in HBM and the noise drawn on the device (Philox).
+Headline workload at N=1: BASELINE configs[2], point_mass3d analytic, K=65536, H=64 — the configuration the metric is
+quoted on. Every BASELINE config is launchable:
+    configs[1]  --workload pm2d --samples 4096                 (also a sub-record of the default run)
+    configs[2]  (default)
+    configs[3]  --workload mlp                                 (also a sub-record of the default run, with the split-bf16 variant)
+    configs[4]  --workload mlp --horizon 128 --gpus 8          (K = 65536 per rank = 524288 in all)
+N>1 is WEAK scaling: every rank keeps --samples rollouts of a (samples x N)-sample controller, one exchange of the
+(beta, eta, V) record per step. Rank 0 prints ONE JSON line (value = whole-job rollouts/s, max-over-ranks time).
+
+Timing: W warm-up steps, then batches of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and
+reduced with MAX over ranks; batches repeat until --min-time seconds have been timed (a 200-step batch of the analytic
+workload is 4 ms: one batch is a noisy sample), `value` is the MEDIAN batch; all batch times are in the line.
 """
 import argparse
 import json
@@ -24,24 +32,26 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-K_PER_GPU, H, A = 65536, 64, 3            # BASELINE.json configs[2]
-S = 2 * A
-GOAL = [1.0, 0.0, 0.5, 0.0, 0.75, 0.0]    # MuJoCo target site, zero velocity
-SIGMA = (0.25 * np.eye(A)).astype(np.float32)  # config/envs/point_mass.default.yaml:17-26
-CFG = dict(tau=H, s_dim=S, a_dim=A, dt=0.1, mass=1.0, lam=1.0, sigma=SIGMA, goal=GOAL, seed=1)
-# SURVEY §8d / BASELINE.md §3: algorithmic work per state-step (one (k,t) pair)
-BYTES_PER_STATE_STEP = 12 * A             # noise written once, read twice, fp32
-FLOP_PER_STATE_STEP = 6 * S + 5 * A + 3
-HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HID = 256                                 # BASELINE configs[3]: learned 2x256 MLP model_base
-MLP_FLOP_PER_STATE_STEP = 2 * ((S + A) * HID + HID * HID + HID * S)   # 138752, SURVEY §8d
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+GOALS = {1: [1.0, 0.0], 2: [1.0, 0.0, 0.0, 0.0], 3: [1.0, 0.0, 0.5, 0.0, 0.75, 0.0]}  # MuJoCo target sites
+WORKLOADS = {"pm1d": (1, False), "pm2d": (2, False), "pm3d": (3, False), "mlp": (3, True)}
+CONFIG_NAME = {("pm1d", 128, 32, 1): "BASELINE configs[0]", ("pm2d", 4096, 64, 1): "BASELINE configs[1]",
+               ("pm3d", 65536, 64, 1): "BASELINE configs[2]", ("mlp", 65536, 64, 1): "BASELINE configs[3]",
+               ("mlp", 65536, 128, 8): "BASELINE configs[4] (K = 524288 over 8 GPUs)"}
 
 
-def synthetic_mlp(seed=0):
-    """9->256->256->6 ReLU, U(-1/sqrt(fan_in), 1/sqrt(fan_in)), last layer x0.1, identity normalisation."""
+def cfg_of(a, H):
+    return dict(tau=H, s_dim=2 * a, a_dim=a, dt=0.1, mass=1.0, lam=1.0, sigma=(0.25 * np.eye(a)).astype(np.float32),
+                goal=GOALS[a], seed=1)
+
+
+def synthetic_mlp(a=3, seed=0):
+    """(s+a)->256->256->s ReLU, U(-1/sqrt(fan_in), 1/sqrt(fan_in)), last layer x0.1, identity normalisation."""
     rng = np.random.default_rng(seed)
-    dims = [S + A, HID, HID, S]
+    dims = [3 * a, HID, HID, 2 * a]
     W = [(rng.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
     b = [(rng.uniform(-1, 1, dims[i + 1]) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
     W[2] *= 0.1
@@ -49,38 +59,48 @@ def synthetic_mlp(seed=0):
     return dict(W=W, b=b)
 
 
-def cpu_baseline(budget_s=12.0, mlp=None):
-    """The CPU restatement (oracle/, OpenMP over samples) timed on this box's host cores on a bounded
-    sample of the SAME workload: whole control steps (noise + rollouts + update) at H=64 —
-    K=65536 for the analytic model, K=4096 for the MLP (stated in `sample`)."""
+def work_per_state_step(a, mlp):
+    """algorithmic work of one (k, t) pair: (bytes, flop)"""
+    s = 2 * a
+    flop = 6 * s + 5 * a + 3
+    if mlp:
+        flop += 2 * ((s + a) * HID + HID * HID + HID * s)
+    return 12 * a, flop  # bytes: the noise written once and read twice, fp32
+
+
+def cpu_baseline(a, H, K, mlp, budget_s=12.0):
+    """The CPU restatement (oracle/, OpenMP over samples) timed on this box's host cores on a bounded sample of the SAME
+    workload: whole control steps (noise + rollouts + update) at the same H — the same K for the analytic model, K=4096
+    for the MLP (stated in `sample`)."""
     from oracle import oracle as orc
-    K_PER_GPU = 65536 if mlp is None else 4096
-    p = orc.Problem(tau=H, s=S, a=A, dt=0.1, mass=1.0, lam=1.0, sigma=SIGMA, goal=GOAL, threads=0, mlp=mlp)
-    x, U = np.zeros(S, np.float32), np.zeros((H, A), np.float32)
-    eps = orc.noise(1, 0, 0, K_PER_GPU, H, A, SIGMA)
+    Kc = K if mlp is None else min(K, 4096)
+    c = cfg_of(a, H)
+    p = orc.Problem(tau=H, s=2 * a, a=a, dt=0.1, mass=1.0, lam=1.0, sigma=c["sigma"], goal=c["goal"], threads=0, mlp=mlp)
+    x, U = np.zeros(2 * a, np.float32), np.zeros((H, a), np.float32)
+    eps = orc.noise(1, 0, 0, Kc, H, a, c["sigma"])
     p.next_with_noise(x, U, eps)  # warm-up (page in, spin up the OpenMP team)
     n, t0 = 0, time.perf_counter()
     while True:
-        eps = orc.noise(1, n + 1, 0, K_PER_GPU, H, A, SIGMA)
+        eps = orc.noise(1, n + 1, 0, Kc, H, a, c["sigma"])
         _, U, _ = p.next_with_noise(x, U, eps)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 200:
             break
-    return {"value": K_PER_GPU * n / el, "unit": "rollouts/s", "cores": orc.num_threads(), "kind": "port",
+    return {"value": Kc * n / el, "unit": "rollouts/s", "cores": orc.num_threads(), "kind": "port",
             "ms_per_step": 1e3 * el / n,
-            "sample": "%d whole control steps of point_mass3d%s K=%d H=%d (Philox noise + rollouts + update), "
+            "sample": "%d whole control steps of point_mass%dd%s K=%d H=%d (Philox noise + rollouts + update), "
                       "OpenMP over samples; the reference itself (TensorFlow) is not runnable here"
-                      % (n, "" if mlp is None else " + 2x256 MLP model", K_PER_GPU, H)}
+                      % (n, a, "" if mlp is None else " + 2x256 MLP model", Kc, H)}
 
 
-def sync_latency(m, steps=200, warmup=20, mlp=None):
-    """Host-synchronous closed loop: mppi_next(x)->u with the plant stepped on the host (the shape of
-    the reference's loop, main.cpp:37-43). Median / p95 ms per control step."""
-    h = m.Handle(k=K_PER_GPU, mlp=mlp, **CFG)
+def sync_latency(m, a, H, K, mlp, steps=200, warmup=20):
+    """Host-synchronous closed loop: mppi_next(x)->u with the plant stepped on the host (the shape of the reference's
+    loop, main.cpp:37-43). Median / p95 ms per control step."""
+    h = m.Handle(k=K, mlp=mlp, **cfg_of(a, H))
     if mlp is not None:
         steps, warmup = 20, 3
-    x = np.zeros(S, np.float32)
+    x = np.zeros(2 * a, np.float32)
     dt, ts = 0.1, []
     for i in range(warmup + steps):
         t0 = time.perf_counter()
@@ -88,7 +108,7 @@ def sync_latency(m, steps=200, warmup=20, mlp=None):
         t1 = time.perf_counter()
         if i >= warmup:
             ts.append(t1 - t0)
-        for j in range(A):  # point-mass plant, fp32, same model
+        for j in range(a):  # point-mass plant, fp32, same model
             x[2 * j] = x[2 * j] + dt * x[2 * j + 1] + (dt * dt / 2) * u[j]
             x[2 * j + 1] = x[2 * j + 1] + dt * u[j]
     ts = np.sort(np.asarray(ts)) * 1e3
@@ -96,24 +116,145 @@ def sync_latency(m, steps=200, warmup=20, mlp=None):
     return float(np.median(ts)), float(ts[int(0.95 * (len(ts) - 1))])
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
-    (profiles/, collected in separate passes per the guide); None when absent."""
-    f = os.path.join(ROOT, "profiles", "traffic_latest.json")
+def measured(name):
+    """profiles/<name>_latest.json (written by tools/summarize_profiles.py from rocprofv3 --pmc passes), or None when it
+    is absent or was taken on other kernel sources than the ones this run executes."""
+    import mppi_tf_amd as m
     try:
-        return json.load(open(f)).get("hbm_bytes_per_launch")
+        d = json.load(open(os.path.join(ROOT, "profiles", name + "_latest.json")))
     except Exception:
-        return None
+        return None, "no profiles/%s_latest.json" % name
+    sha = m.build.source_sha()
+    if d.get("code_sha") != sha:
+        return None, "profiles/%s_latest.json was measured on kernel sources %s, this run executes %s" % (name, d.get("code_sha"), sha)
+    return d, None
+
+
+def valu_roofline(kernel, kernel_ms):
+    """The limiter of the analytic rollout kernel is vector-instruction issue, not HBM: instructions per launch by class
+    (rocprofv3 SQ_INSTS_VALU_* counters) x issue cycles per instruction of that class (tools/micro/valu_issue.hip, an
+    ISA-verified micro-benchmark, several waves per SIMD) / (1024 SIMDs x the clock) = the time the launch's vector
+    instructions need at full issue rate."""
+    d, why = measured("valu")
+    if d is None or d.get("kernel") != kernel:
+        return {"note": why or "profiles/valu_latest.json describes %s, this run launched %s" % (d.get("kernel"), kernel)}
+    cyc = sum(d["insts_per_launch"][c] * d["cycles_per_inst"][c] for c in d["insts_per_launch"])
+    floor_us = cyc / (d["simds"] * d["clock_mhz"])
+    out = dict(d)
+    out.update({"floor_us": floor_us, "kernel_us": 1e3 * kernel_ms, "frac": floor_us / (1e3 * kernel_ms) if kernel_ms > 0 else None})
+    return out
+
+
+class Runner:
+    def __init__(self, args, dev, world, rank, local_rank):
+        self.args, self.dev, self.world, self.rank, self.local_rank = args, dev, world, rank, local_rank
+
+    def barrier(self):
+        torch.cuda.synchronize(self.dev)
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, v):
+        t = torch.tensor([v], dtype=torch.float64, device=self.dev)
+        if dist.is_initialized():
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def run(self, workload, K, H, steps, warmup, min_time, **handle_kw):
+        """-> dict of measurements of one workload (K rollouts per rank)"""
+        from mppi_tf_amd.distributed import ExchangeTimeout, ShardedController
+        a, is_mlp = WORKLOADS[workload]
+        mlp = synthetic_mlp(a) if is_mlp else None
+        x = torch.zeros(2 * a, dtype=torch.float32, device=self.dev)
+        ctl = ShardedController(device_index=self.local_rank, k=K * self.world, mlp=mlp, exchange=os.environ.get("MPPI_EXCHANGE", "auto"),
+                                p2p_timeout_ms=1000, **cfg_of(a, H), **handle_kw)
+        assert ctl.backend.h.k_local == K
+
+        def steps_timed(n):
+            """n steps between two barriers; a missed direct-exchange deadline sends every rank to the all-gather path"""
+            nonlocal ctl
+            for attempt in range(2):
+                self.barrier()
+                t0 = time.perf_counter()
+                try:
+                    for _ in range(n):
+                        ctl.next(x)
+                    self.barrier()
+                    ctl.check()
+                    bad = 0
+                except ExchangeTimeout:
+                    bad = 1
+                el = time.perf_counter() - t0
+                if self.max_over_ranks(bad) == 0:
+                    return self.max_over_ranks(el)
+                ctl.resync()
+            raise RuntimeError("the all-gather path cannot time out")
+
+        steps_timed(warmup)
+        batches = [steps_timed(steps)]
+        n_more = int(min(200, max(0, np.ceil((min_time - batches[0]) / max(batches[0], 1e-9)))))
+        n_more = int(self.max_over_ranks(n_more))
+        for _ in range(n_more):
+            batches.append(steps_timed(steps))
+        el = float(np.median(batches))
+        # kernel durations: the same K steps with HIP events bound to each launch (the dispatches' own begin/end)
+        h = ctl.backend.h
+        n_prof = min(steps, 200)
+        h.profile_begin(n_prof)
+        for _ in range(n_prof):
+            ctl.next(x)
+        torch.cuda.synchronize(self.dev)
+        roll_ms, fin_ms, n_prof = h.profile_end()
+        assert np.isfinite(ctl.u.cpu().numpy()).all()
+        bytes_ss, flop_ss = work_per_state_step(a, is_mlp)
+        state_steps = K * H
+        res = {"workload": workload, "K_per_gpu": K, "H": H, "a_dim": a, "steps": steps, "batches_s": batches,
+               "rollouts_per_s": K * self.world * steps / el, "ms_per_step": 1e3 * el / steps,
+               "kernel": h.rollout_kernel_name(), "kernel_ms_avg": roll_ms, "finish_kernel_ms_avg": fin_ms, "launches_timed": n_prof,
+               "algorithmic_bytes_per_launch": bytes_ss * state_steps + 8 * K, "algorithmic_flop_per_launch": flop_ss * state_steps,
+               "exchange": ctl.exchange, "p2p_note": ctl.p2p_note, "record_size": h.record_size, "mlp": mlp}
+        del ctl
+        return res
+
+
+def roofline_of(r):
+    if r["workload"] == "mlp":
+        tf = r["algorithmic_flop_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e12 if r["kernel_ms_avg"] > 0 else 0.0
+        return {"bound": "mfma", "kernel": r["kernel"], "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "algorithmic_flop_per_launch": r["algorithmic_flop_per_launch"],
+                "kernel_ms_avg": r["kernel_ms_avg"], "finish_kernel_ms_avg": r["finish_kernel_ms_avg"], "launches_timed": r["launches_timed"],
+                "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-5-class parity target rules out plain bf16; "
+                        "weights stationary in registers, activations in LDS"}
+    ach = r["algorithmic_bytes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e9 if r["kernel_ms_avg"] > 0 else 0.0
+    tr, why = measured("traffic")
+    traffic = tr.get("hbm_bytes_per_launch") if tr and tr.get("kernel") == r["kernel"] else None
+    return {"bound": "hbm", "kernel": r["kernel"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_note": None if traffic is not None else (why or "profiles/traffic_latest.json describes another kernel instance"),
+            "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "algorithmic_flop_per_launch": r["algorithmic_flop_per_launch"],
+            "kernel_ms_avg": r["kernel_ms_avg"], "finish_kernel_ms_avg": r["finish_kernel_ms_avg"], "launches_timed": r["launches_timed"],
+            "timing": "HIP events bound to each launch of the kernel on its stream (hipExtLaunchKernel start/stop events = the "
+                      "dispatch's own begin/end, the quantity rocprofv3 reports in profiles/)",
+            "valu": valu_roofline(r["kernel"], r["kernel_ms_avg"]),
+            "note": "achieved = ALGORITHMIC bytes (SURVEY 8d: noise written once + read twice, 12*a B per state-step) per launch / "
+                    "kernel time; the noise is generated and consumed on-chip, so the physical HBM traffic (`traffic`, PMC) is "
+                    "~20x lower and the algorithmic rate can exceed the HBM peak: frac says how the kernel compares with ANY "
+                    "kernel that materialises the noise, not how close it is to its own limit. Its limiter is vector-instruction "
+                    "issue (Philox4x32-10 + Box-Muller): `valu` prices the launch's instructions at the measured issue rates."}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None, help="K steps per timed batch (default 200; 20 for the MLP workload, ~5 ms per step)")
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
+                    help="default: pm3d (BASELINE configs[2], the metric's config) plus sub-records of configs[1] and [3]")
+    ap.add_argument("--horizon", type=int, default=None, help="H (default 64; 32 for pm1d)")
+    ap.add_argument("--samples", type=int, default=None, help="rollouts PER GPU (default 65536; 4096 for pm2d, 128 for pm1d)")
+    ap.add_argument("--min-time", type=float, default=0.2, help="repeat the K-step batch until this many seconds are timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["pm3d", "mlp"], default="pm3d",
-                    help="pm3d = BASELINE configs[2] (analytic, the metric's config); mlp = configs[3] (learned 2x256 MLP)")
+    ap.add_argument("--no-subrecords", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,133 +274,66 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import mppi_tf_amd as m
-    from mppi_tf_amd.distributed import ShardedController
 
-    k_global = K_PER_GPU * world
-    mlp = synthetic_mlp() if args.workload == "mlp" else None
-    x = torch.zeros(S, dtype=torch.float32, device=dev)
+    headline = args.workload or "pm3d"
+    a, is_mlp = WORKLOADS[headline]
+    H = args.horizon or (32 if headline == "pm1d" else 64)
+    K = args.samples or {"pm1d": 128, "pm2d": 4096}.get(headline, 65536)
+    steps = args.steps if args.steps is not None else (20 if is_mlp else 200)
+    rn = Runner(args, dev, world, rank, local_rank)
+    r = rn.run(headline, K, H, steps, args.warmup if not is_mlp else min(args.warmup, 3), args.min_time)
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    def exchange_failed(ctl):
-        """True on every rank if the direct exchange missed a deadline on any rank (its results are invalid then)"""
-        bad = torch.tensor([1 if (ctl.p2p and ctl.backend.p2p_timed_out()) else 0], dtype=torch.int32, device=dev)
-        if dist.is_initialized():
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        return bool(bad.item())
-
-    # The record exchange of a sharded step: the direct (in-kernel, peer-store) exchange if its self-test passes on
-    # every rank, else one RCCL all-gather per step. A deadline missed later also sends the whole run to RCCL.
-    for exchange in (os.environ.get("MPPI_EXCHANGE", "auto"), "rccl"):
-        ctl = ShardedController(device_index=local_rank, k=k_global, mlp=mlp, exchange=exchange, p2p_timeout_ms=1000, **CFG)
-        assert ctl.backend.h.k_local == K_PER_GPU
-        for _ in range(args.warmup):
-            ctl.next(x)
-        barrier()
-        if exchange_failed(ctl):
-            continue
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ctl.next(x)
-        barrier()
-        el = time.perf_counter() - t0
-        if not exchange_failed(ctl):
-            break
-    t = torch.tensor([el], dtype=torch.float64, device=dev)
-    if dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
-
-    # second pass, same K steps, with HIP events around the dominant kernel on its launch stream
-    h = ctl.backend.h
-    h.profile_begin(args.steps)
-    for _ in range(args.steps):
-        ctl.next(x)
-    torch.cuda.synchronize(dev)
-    roll_ms, fin_ms, n_prof = h.profile_end()
-    u_last = ctl.u.cpu().numpy()
-    assert np.isfinite(u_last).all()
+    subs = []
+    if args.workload is None and world == 1 and not args.no_subrecords:
+        # the other single-GPU BASELINE configs, so that one driver run measures them all
+        subs.append(rn.run("pm2d", 4096, 64, steps, args.warmup, args.min_time))
+        subs.append(rn.run("mlp", 65536, 64, 20, 3, 0.0))
+        subs.append(rn.run("mlp", 65536, 64, 20, 3, 0.0, mlp_bf16x3=True))
 
     if rank == 0:
-        state_steps = K_PER_GPU * H
-        alg_bytes = BYTES_PER_STATE_STEP * state_steps + 8 * K_PER_GPU
-        ach = alg_bytes / (roll_ms * 1e-3) / 1e9 if roll_ms > 0 else 0.0
-        if mlp is not None:
-            flop = MLP_FLOP_PER_STATE_STEP * state_steps
-            tf = flop / (roll_ms * 1e-3) / 1e12 if roll_ms > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "mppi::k_rollout_mlp<3, false, true, 0, 0>", "achieved": tf,
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                    "algorithmic_flop_per_launch": flop, "kernel_ms_avg": roll_ms, "record_tree_kernels_ms_avg": fin_ms,
-                    "launches_timed": n_prof,
-                    "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-5-class parity target rules out bf16; "
-                            "weights stationary in registers, activations in LDS"}
+        cfg = cfg_of(a, H)
+        name = CONFIG_NAME.get((headline, K, H, world), CONFIG_NAME.get((headline, K, H, 1), "not a BASELINE configuration"))
         out = {
             "metric": "rollouts/s (one control step = K rollouts x H steps), point_mass3d H=64",
-            "value": k_global * args.steps / el, "unit": "rollouts/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": r["rollouts_per_s"], "unit": "rollouts/s",
+            "n_gpus": world, "steps": r["steps"], "warmup": args.warmup,
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "state_steps_per_s": k_global * H * args.steps / el,
-            "config": {"workload": ("point_mass3d analytic model, K=%d H=%d per GPU (BASELINE configs[2]), "
-                                    "on-device Philox noise, device-resident x/U" % (K_PER_GPU, H)) if mlp is None else
-                                   ("point_mass3d learned 2x256 MLP model_base, K=%d H=%d per GPU (BASELINE configs[3]), "
-                                    "on-device Philox noise, device-resident x/U" % (K_PER_GPU, H)),
-                       "K_global": k_global, "K_per_gpu": K_PER_GPU, "H": H, "s_dim": S, "a_dim": A,
+            "state_steps_per_s": r["rollouts_per_s"] * H,
+            "batches": {"n": len(r["batches_s"]), "steps_each": r["steps"], "seconds": r["batches_s"],
+                        "what": "value = K*N*steps / median batch; every batch is bracketed by barrier + synchronize, max over ranks"},
+            "config": {"workload": "point_mass%dd %s, K=%d H=%d per GPU (%s), on-device Philox noise, device-resident x/U"
+                                   % (a, "learned 2x256 MLP model_base" if is_mlp else "analytic model", K, H, name),
+                       "K_global": K * world, "K_per_gpu": K, "H": H, "s_dim": 2 * a, "a_dim": a,
                        "lambda": 1.0, "sigma": "0.25*I", "dt": 0.1, "mass": 1.0,
                        "parallelism": "K-shard x%d, %s" % (world, {
                            "none": "single shard, no exchange",
                            "p2p": "records (%d floats) exchanged as peer stores over xGMI inside the finish kernel (%s)"
-                                  % (h.record_size, ctl.p2p_note),
+                                  % (r["record_size"], r["p2p_note"]),
                            "rccl": "one RCCL all-gather of %d floats per step (direct exchange: %s)"
-                                   % (h.record_size, ctl.p2p_note)}[ctl.exchange]),
-                       "exchange": ctl.exchange},
-            "roofline": {"bound": "hbm", "kernel": "mppi::k_rollout_pc<3, 3, 6, true>",
-                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(),
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "algorithmic_flop_per_launch": FLOP_PER_STATE_STEP * state_steps,
-                         "kernel_ms_avg": roll_ms, "record_tree_kernels_ms_avg": fin_ms, "launches_timed": n_prof,
-                         "timing": "HIP events bound to each launch of the kernel on its stream (hipExtLaunchKernel start/stop "
-                                   "events = the dispatch's own begin/end, the quantity rocprofv3 reports in profiles/)",
-                         "note": "achieved = ALGORITHMIC bytes (SURVEY 8d: noise written once + read twice, 36 B per state-step) "
-                                 "per launch / kernel time; the noise is generated and consumed on-chip, so the physical HBM "
-                                 "traffic (`traffic`, PMC) is ~20x lower and the algorithmic rate can exceed the HBM peak "
-                                 "(frac > 1 means faster than ANY kernel that materialises the noise could be); the true "
-                                 "limiter is VALU issue (Philox4x32-10 + Box-Muller), see DESIGN.md 4."},
+                                   % (r["record_size"], r["p2p_note"])}[r["exchange"]]),
+                       "exchange": r["exchange"]},
+            "roofline": roofline_of(r),
         }
-        if mlp is not None:
-            out["roofline"] = roof
-            if world == 1:
-                # the opt-in split-bf16 variant of the same workload (MPPI_FLAG_MLP_BF16X3): reported beside the
-                # exact-fp32 headline, never as `value`
-                hb = m.Handle(k=K_PER_GPU, mlp=mlp, mlp_bf16x3=True, **CFG)
-                ub = torch.zeros(A, dtype=torch.float32, device=dev)
-                nb3 = max(5, min(args.steps, 50))
-                for _ in range(3):
-                    hb.next_device(x.data_ptr(), ub.data_ptr())
-                hb.synchronize()
-                tb = time.perf_counter()
-                for _ in range(nb3):
-                    hb.next_device(x.data_ptr(), ub.data_ptr())
-                hb.synchronize()
-                tb = (time.perf_counter() - tb) / nb3
-                out["mlp_bf16x3"] = {"ms_per_step": 1e3 * tb, "rollouts_per_s": K_PER_GPU / tb, "steps": nb3,
-                                     "algorithmic_TFLOP_per_s": flop / tb / 1e12,
-                                     "executed_bf16_TFLOP_per_s": 3 * flop / tb / 1e12, "bf16_mfma_peak_TFLOP_per_s": 2500.0,
-                                     "frac_of_bf16_peak": 3 * flop / tb / 1e12 / 2500.0,
-                                     "what": "same workload, 256-wide layers as 3 split-bf16 MFMA products per term, fp32 "
-                                             "accumulate; sample costs within 1e-6 relative of fp64 (tests hold 2e-5)"}
-                del hb
+        if subs:
+            def sub(s):
+                d = {"config": CONFIG_NAME.get((s["workload"], s["K_per_gpu"], s["H"], 1), "") + (" + MPPI_FLAG_MLP_BF16X3" if "bx3" in s["kernel"] else ""),
+                     "workload": s["workload"], "K": s["K_per_gpu"], "H": s["H"], "value": s["rollouts_per_s"], "unit": "rollouts/s",
+                     "ms_per_step": s["ms_per_step"], "steps": s["steps"], "batches": len(s["batches_s"]), "roofline": roofline_of(s)}
+                if "bx3" in s["kernel"]:  # the matrix cores execute 3 bf16 products per fp32 term
+                    ex = 3 * s["algorithmic_flop_per_launch"] / (s["kernel_ms_avg"] * 1e-3) / 1e12
+                    d["roofline"].update({"peak": MFMA_BF16_PEAK_TFLOPS, "achieved": ex, "frac": ex / MFMA_BF16_PEAK_TFLOPS,
+                                          "algorithmic_TFLOP_per_s": ex / 3,
+                                          "note": "split-bf16: 3 v_mfma_f32_32x32x16_bf16 products per fp32 term (achieved = executed bf16 "
+                                                  "FLOP/s against the bf16 dense peak); sample costs within 1e-6 relative of fp64"})
+                return d
+            out["sub_records"] = [sub(s) for s in subs]
         if world == 1:
-            med, p95 = sync_latency(m, mlp=mlp)
+            med, p95 = sync_latency(m, a, H, K, r["mlp"])
             out["ms_per_control_step_sync"] = {"median": med, "p95": p95,
-                                               "what": "host-synchronous mppi_next(x)->u incl. H2D x, D2H u, 200 closed-loop steps"}
+                                               "what": "host-synchronous mppi_next(x)->u incl. H2D x, D2H u, closed-loop steps"}
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(mlp=mlp)
+                out["cpu_baseline"] = cpu_baseline(a, H, K, r["mlp"])
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

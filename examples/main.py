@@ -49,13 +49,17 @@ def write_log_dir(log_path, conf, task):  # observer_base.py:39-54
     return logdir
 
 
-def get_cost(task_file, lam, gamma, upsilon, sigma):  # scripts/src/cost.py:51-64, "static" branch
+def get_cost(task_file, lam, gamma, upsilon, sigma):  # scripts/src/cost.py:51-64
     task = parse_config(task_file)
-    if task["type"] != "static":
-        raise NotImplementedError("only the static cost is on the accelerated path (SURVEY §2 row 12)")
-    goal = np.asarray(task["goal"], np.float32).reshape(-1, 1)
-    return m.StaticCost(lam, gamma, upsilon, np.asarray(sigma, np.float32), goal, np.asarray(task["Q"], np.float32),
-                        diag=bool(task.get("diag", False)))
+    sigma = np.asarray(sigma, np.float32)
+    if task["type"] == "static":  # cost.py:7-11
+        goal = np.asarray(task["goal"], np.float32).reshape(-1, 1)
+        return m.StaticCost(lam, gamma, upsilon, sigma, goal, np.asarray(task["Q"], np.float32), diag=bool(task.get("diag", False)))
+    if task["type"] == "elipse":  # cost.py:21-30 — which hands task['center_y'] to center_x and vice versa; reproduced
+        center_y, center_x = task["center_x"], task["center_y"]
+        return m.ElipseCost(lam, gamma, upsilon, sigma, task["a"], task["b"], center_x, center_y, task["speed"],
+                            task["m_state"], task["m_vel"])
+    raise NotImplementedError("cost types on the accelerated path: static, elipse (SURVEY §8f row 4: elipse3d / waypoints are not)")
 
 
 def main():
@@ -99,10 +103,14 @@ def main():
         ts.append(time.perf_counter() - t0)
         x_next = sim.step(u)
         cont.save(x, u, x_next)
-    goal = cost.getGoal().ravel()
     steady = np.sort(ts[min(5, len(ts) - 1):])  # the first calls load the code objects
-    print("%d control steps, controller median %.3f ms/step (first call %.1f ms), |x - goal| = %.4f" % (
-        args.steps, 1e3 * float(np.median(steady)), 1e3 * ts[0], float(np.linalg.norm(sim.getState().ravel() - goal))))
+    if hasattr(cost, "getGoal"):
+        tail = "|x - goal| = %.4f" % float(np.linalg.norm(sim.getState().ravel() - cost.getGoal().ravel()))
+    else:
+        d = cost.dist(sim.getState())
+        tail = "elipse x_dist = %.4f v_dist = %.4f" % (float(d["x_dist"]), float(d["v_dist"]))
+    print("%d control steps, controller median %.3f ms/step (first call %.1f ms), %s" % (
+        args.steps, 1e3 * float(np.median(steady)), 1e3 * ts[0], tail))
     if args.csv:
         cont._h.to_csv(args.csv)
         print("wrote", args.csv)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 1
+#define MPPI_ABI_VERSION 2 /* 2: mppi_config gained state_cost_kind / ellipse; transition log, tuning, kernel-name entry points */
 #define MPPI_MAX_S 32  /* largest state dimension  */
 #define MPPI_MAX_A 16  /* largest action dimension */
 
@@ -54,6 +54,10 @@ enum { MPPI_MODEL_POINT_MASS = 0, /* x' = A x + (B/m) v, src/model_base.cpp:53-8
 
 enum { MPPI_ACTION_COST_CPP = 0,  /* λ uᵀΣ⁻¹ε                          src/cost_base.cpp:63-68   */
        MPPI_ACTION_COST_PY = 1 }; /* ½[γ(uᵀΣ⁻¹u+2uᵀΣ⁻¹ε)+λ(1-1/υ)εᵀΣ⁻¹ε]  costs/cost_base.py:114-170 */
+
+enum { MPPI_STATE_COST_QUADRATIC = 0, /* (x-g)ᵀQ(x-g)   src/cost_base.cpp:56-61, costs/static_cost.py:40-63          */
+       MPPI_STATE_COST_ELLIPSE = 1 }; /* 2D elliptic track, state (x, vx, y, vy, ..): m_state·|((x-cx)/a)²+((y-cy)/b)²-1|
+                                         + m_vel·(sqrt(vx²+vy²)-speed)²                 costs/elipse_cost.py:9-85       */
 
 /* mppi_config.flags */
 enum { MPPI_FLAG_UPSILON_SCALES_NOISE = 1, /* Py build_noise: eps = (υΣ)·z while the cost keeps Σ⁻¹ of the
@@ -104,6 +108,9 @@ typedef struct {
     int32_t shard_rank;       /* this handle owns samples [rank*k/count, (rank+1)*k/count) */
     int32_t shard_count;      /* 1 = unsharded                                            */
     int32_t flags;            /* MPPI_FLAG_* bits, 0 = the C++ reference's behaviour      */
+    int32_t state_cost_kind;  /* MPPI_STATE_COST_*; 0 = the quadratic cost (goal, Q)       */
+    const float *ellipse;     /* MPPI_STATE_COST_ELLIPSE: [7] a, b, cx, cy, speed, m_state, m_vel (ElipseCost's
+                                 constructor arguments, elipse_cost.py:10-46); needs s_dim >= 4 */
 } mppi_config;
 
 /* ---- library ------------------------------------------------------------------------- */
@@ -271,8 +278,11 @@ mppi_status mppi_set_tuning(mppi_handle *h, int what, int value);
  * events ON THE STREAM THEY ARE LAUNCHED ON. */
 mppi_status mppi_profile_begin(mppi_handle *h, int max_steps);
 /* Synchronise, stop recording, return average kernel durations in milliseconds over the
- * n_steps recorded steps (any output may be NULL). */
+ * n_steps recorded steps (any output may be NULL). Both are the dispatches' own begin/end (what rocprofv3 reports). */
 mppi_status mppi_profile_end(mppi_handle *h, float *rollout_ms_avg, float *finish_ms_avg, int *n_steps);
+/* Name of the rollout kernel instance a fused step of this handle launches, as rocprofv3 prints it
+ * (e.g. "mppi::k_rollout_pc<3, 3, 6, true>"): what a roofline figure of this handle refers to. */
+mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf, size_t n);
 
 #ifdef __cplusplus
 }

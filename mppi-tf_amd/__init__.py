@@ -12,8 +12,8 @@ hand-written HIP for gfx950 in csrc/, reached through the C-ABI of include/mppi_
 from . import build as _build  # noqa: F401
 from ._lib import (ACTION_COST_CPP, ACTION_COST_PY, CSV_REFERENCE, CSV_ROUNDTRIP, DBG_BETA, DBG_COSTS, DBG_ETA, DBG_NOISE,
                    DBG_U_UPDATED, DBG_WEIGHTS, Handle, MppiError, load)
-from .controller import ControllerBase, ControllerBaseCpp, CostBase, PointMassModel, StaticCost
+from .controller import ControllerBase, ControllerBaseCpp, CostBase, ElipseCost, PointMassModel, StaticCost
 
 __all__ = ["Handle", "MppiError", "load", "ControllerBase", "ControllerBaseCpp", "CostBase", "PointMassModel",
-           "StaticCost", "ACTION_COST_CPP", "ACTION_COST_PY", "DBG_COSTS", "DBG_BETA", "DBG_ETA", "DBG_WEIGHTS",
+           "StaticCost", "ElipseCost", "ACTION_COST_CPP", "ACTION_COST_PY", "DBG_COSTS", "DBG_BETA", "DBG_ETA", "DBG_WEIGHTS",
            "DBG_NOISE", "DBG_U_UPDATED", "CSV_REFERENCE", "CSV_ROUNDTRIP"]

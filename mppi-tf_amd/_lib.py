@@ -46,7 +46,7 @@ class Config(C.Structure):
                 ("sigma", FP), ("goal", FP), ("Q", FP), ("q_is_full", C.c_int32),
                 ("seed", C.c_uint64), ("model_kind", C.c_int32), ("mlp", C.POINTER(MlpDesc)),
                 ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
-                ("flags", C.c_int32)]
+                ("flags", C.c_int32), ("state_cost_kind", C.c_int32), ("ellipse", FP)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol include/mppi_c.h declares
@@ -99,6 +99,7 @@ SIGNATURES = {
     "mppi_shard_p2p_status": (C.c_int, [_H, C.POINTER(C.c_int)]),
     "mppi_profile_begin": (C.c_int, [_H, C.c_int]),
     "mppi_profile_end": (C.c_int, [_H, FP, FP, C.POINTER(C.c_int)]),
+    "mppi_rollout_kernel_name": (C.c_int, [_H, C.c_char_p, C.c_size_t]),
 }
 
 _lib = None
@@ -117,7 +118,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.mppi_abi_version() != 1:
+    if lib.mppi_abi_version() != 2:
         raise OSError("libmppi_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -138,7 +139,7 @@ class Handle:
     def __init__(self, k, tau, s_dim, a_dim, dt=0.1, mass=1.0, lam=1.0, gamma=1.0, upsilon=1.0,
                  sigma=None, goal=None, Q=None, q_is_full=None, action_cost=ACTION_COST_CPP,
                  normalize_cost=False, seed=1, device=0, shard_rank=0, shard_count=1, mlp=None,
-                 upsilon_scales_noise=False, mlp_bf16x3=False, tuning=None, log_rows=0):
+                 upsilon_scales_noise=False, mlp_bf16x3=False, tuning=None, log_rows=0, ellipse=None):
         """mlp: dict(W=[W1,W2,W3], b=[b1,b2,b3], xmean=, xstd=, ymean=, ystd=) selects the learned
         model_base (Dense(256,relu) x2 + Dense(s_dim); Keras [in x out] kernels).
         tuning: dict of diagnostic switches (keys of TUNING) applied with mppi_set_tuning right after creation.
@@ -151,6 +152,10 @@ class Handle:
         cfg.seed, cfg.device, cfg.shard_rank, cfg.shard_count = seed, device, shard_rank, shard_count
         cfg.flags = (1 if upsilon_scales_noise else 0) | (2 if mlp_bf16x3 else 0)  # MPPI_FLAG_UPSILON_SCALES_NOISE | MPPI_FLAG_MLP_BF16X3
         keep = []
+        if ellipse is not None:  # ElipseCost (elipse_cost.py:9-85): dict or the 7 numbers a, b, cx, cy, speed, m_state, m_vel
+            e = [ellipse[k] for k in ("a", "b", "cx", "cy", "speed", "m_state", "m_vel")] if isinstance(ellipse, dict) else ellipse
+            keep.append(f32(e, (7,)))
+            cfg.state_cost_kind, cfg.ellipse = 1, fp(keep[-1])
         if sigma is not None:
             keep.append(f32(sigma, (a_dim, a_dim)))
             cfg.sigma = fp(keep[-1])
@@ -388,6 +393,11 @@ class Handle:
 
     def synchronize(self):
         self._check(self.lib.mppi_synchronize(self.h))
+
+    def rollout_kernel_name(self):
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.mppi_rollout_kernel_name(self.h, buf, 128))
+        return buf.value.decode()
 
     def profile_begin(self, max_steps):
         self._check(self.lib.mppi_profile_begin(self.h, max_steps))

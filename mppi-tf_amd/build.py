@@ -28,6 +28,15 @@ def command(out=SO, extra=()):
             *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
 
 
+def source_sha():
+    """sha256 over the kernel sources: tags a measurement (profiles/*_latest.json) with the code it was taken on."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        hsh.update(open(os.path.join(CSRC, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(SO):
         return True

@@ -169,6 +169,45 @@ class StaticCost(CostBase):
         return np.asarray(state, np.float32) - self.goal
 
 
+class ElipseCost(CostBase):
+    """2D elliptic track cost (costs/elipse_cost.py:9-104), state (x, vx, y, vy):
+    m_state·|((x-cx)/a)² + ((y-cy)/b)² - 1| + m_vel·(sqrt(vx²+vy²) - speed)² + action cost. The reference's spelling
+    and constructor argument order are kept."""
+
+    def __init__(self, lam, gamma, upsilon, sigma, a, b, center_x, center_y, speed, m_state, m_vel, device=0):
+        CostBase.__init__(self, lam, gamma, upsilon, sigma, device)
+        self.a, self.b, self.cx, self.cy, self.gv = float(a), float(b), float(center_x), float(center_y), float(speed)
+        self.mx, self.mv = float(m_state), float(m_vel)
+        self._sDim = 4
+        self._h = None
+
+    @property
+    def ellipse(self):
+        return dict(a=self.a, b=self.b, cx=self.cx, cy=self.cy, speed=self.gv, m_state=self.mx, m_vel=self.mv)
+
+    def _handle(self):
+        if self._h is None:
+            self._h = Handle(k=1, tau=1, s_dim=self._sDim, a_dim=self._aDim, lam=self.lam, gamma=self.gamma,
+                             upsilon=self.upsilon, sigma=self.sigma, action_cost=self._action_cost_kind,
+                             ellipse=self.ellipse, device=self._device)
+        return self._h
+
+    def state_cost(self, scope, state):
+        st = np.asarray(state)
+        if st.ndim != 3 or st.shape[1:] != (4, 1):  # elipse_cost.py:66-67
+            raise AssertionError("State tensor doesn't have the expected shape.\n Expected [k/1, 4, 1], got {}".format(st.shape))
+        return self._handle().state_cost(_flat(state, 4)).reshape(-1, 1, 1)
+
+    def draw_goal(self):  # elipse_cost.py:87-91
+        alpha = np.linspace(0, 2 * np.pi, 1000)
+        return self.a * np.cos(alpha), self.b * np.sin(alpha)
+
+    def dist(self, state):  # elipse_cost.py:93-104
+        x, vx, y, vy = (np.asarray(state).reshape(-1)[i] for i in range(4))
+        v = np.sqrt(vx ** 2 + vy ** 2)
+        return {"x_dist": (((x - self.cx) / self.a) ** 2 + ((y - self.cy) / self.b) ** 2) - 1, "v_dist": np.abs(v - self.gv)}
+
+
 class ControllerBase:
     """MPPI controller (controller_base.py:17-597). `next(state)` is one control step on the GPU.
 
@@ -192,7 +231,7 @@ class ControllerBase:
         self._h = Handle(k=self._k, tau=self._tau, s_dim=self._sDim, a_dim=self._aDim,
                          dt=model._dt, mass=model._mass, lam=self._lam,
                          gamma=getattr(cost, "gamma", 1.0), upsilon=getattr(cost, "upsilon", 1.0),
-                         sigma=sigma, goal=cost.goal.ravel(), Q=cost.Q, q_is_full=True,
+                         sigma=sigma, **self._state_cost_args(cost),
                          action_cost=cost._action_cost_kind, normalize_cost=self._normalizeCost,
                          seed=seed, device=device,
                          # build_noise: noises = (υΣ)·z (controller_base.py:362-368); the cost keeps Σ⁻¹ of Σ
@@ -217,6 +256,13 @@ class ControllerBase:
             self._h.set_action_limits(np.asarray(lo, np.float32).reshape(-1), np.asarray(hi, np.float32).reshape(-1))
         self._timingDict = {"total": 0., "calls": 0}
         self._steps = 0
+
+    @staticmethod
+    def _state_cost_args(cost):
+        """what selects the device state cost: (goal, Q) of a StaticCost or the ellipse of an ElipseCost"""
+        if isinstance(cost, ElipseCost):
+            return dict(ellipse=cost.ellipse)
+        return dict(goal=cost.goal.ravel(), Q=cost.Q, q_is_full=True)
 
     # ---- the step ---------------------------------------------------------------------
     def next(self, state):

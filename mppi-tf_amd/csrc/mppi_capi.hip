@@ -225,6 +225,14 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     if (cfg->model_kind == MPPI_MODEL_POINT_MASS && !(cfg->mass != 0.0f)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "mass must be non-zero");
     if (cfg->model_kind != MPPI_MODEL_POINT_MASS && cfg->model_kind != MPPI_MODEL_MLP)
         return fail(nullptr, MPPI_ERR_INVALID_ARG, "unknown model kind");
+    if (cfg->state_cost_kind != MPPI_STATE_COST_QUADRATIC && cfg->state_cost_kind != MPPI_STATE_COST_ELLIPSE)
+        return fail(nullptr, MPPI_ERR_INVALID_ARG, "unknown state cost kind");
+    if (cfg->state_cost_kind == MPPI_STATE_COST_ELLIPSE) {
+        if (!cfg->ellipse) return fail(nullptr, MPPI_ERR_INVALID_ARG, "the elliptic cost needs cfg.ellipse[7]");
+        if (s < 4) return fail(nullptr, MPPI_ERR_INVALID_ARG, "the elliptic cost reads (x, vx, y, vy): s_dim >= 4");
+        if (!(cfg->ellipse[0] != 0.0f) || !(cfg->ellipse[1] != 0.0f)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "ellipse axes a, b must be non-zero");
+        if (cfg->model_kind == MPPI_MODEL_MLP) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "MLP rollouts are instantiated for the quadratic state cost");
+    }
     if (cfg->model_kind == MPPI_MODEL_MLP) {
         const mppi_mlp_desc *d = cfg->mlp;
         if (!d || !d->widths || !d->W || !d->b) return fail(nullptr, MPPI_ERR_INVALID_ARG, "MLP model needs cfg.mlp with widths, W, b");
@@ -258,6 +266,8 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     c.K_local = h->K_local; c.k_offset = h->k_offset; c.H = h->H; c.s = s; c.a = a;
     c.q_full = cfg->q_is_full ? 1 : 0;
     c.action_cost_kind = cfg->action_cost_kind; c.model_kind = cfg->model_kind;
+    c.state_cost_kind = cfg->state_cost_kind;
+    if (cfg->state_cost_kind == MPPI_STATE_COST_ELLIPSE) for (int i = 0; i < 7; ++i) c.ell[i] = cfg->ellipse[i];
     c.lambda = cfg->lambda; c.neg_inv_lambda = -1.0f / cfg->lambda;
     c.gamma = cfg->gamma; c.upsilon = cfg->upsilon;
     c.py_ncoef = cfg->lambda * (1.0f - 1.0f / cfg->upsilon);
@@ -448,7 +458,8 @@ static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_
 // diagonal-Q handles only (a dense Q runs the tile kernel); horizon groups per producer must fit the registers
 static bool pc_eligible(const mppi_handle *h)
 {
-    return h->no_rollout.empty() && h->R == 64 && !h->hc.q_full && !h->force_tile && h->H <= (h->pc_np == 3 ? 132 : 160);
+    return h->no_rollout.empty() && h->R == 64 && !h->hc.q_full && !h->force_tile && h->H <= (h->pc_np == 3 ? 132 : 160) &&
+           h->hc.state_cost_kind == MPPI_STATE_COST_QUADRATIC; // other costs run the general tile kernel
 }
 
 static hipError_t launch_pc(mppi_handle *h, hipStream_t st, const float *x_dev)
@@ -515,7 +526,6 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
 {
     // a profiled step = the rollout kernel + the finish that applies the update
     const bool prof = apply && h->prof_n < h->prof_cap;
-    if (prof) { hipError_t e = hipEventRecord(h->ev[4 * h->prof_n + 2], st); if (e != hipSuccess) return e; }
     float *out = h->d_part2;
     while (nb > 1024) {
         const int ng = (nb + kGroup - 1) / kGroup;
@@ -525,15 +535,17 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
         recs = out; sb = 2 + h->HA; sc = 1; nb = ng;
         out = h->d_part3;
     }
+    // profiled: the finish kernel's own dispatch begin/end (hipExtLaunchKernel events), like the rollout kernel's
+    hipEvent_t f0 = prof ? h->ev[4 * h->prof_n + 2] : nullptr, f1 = prof ? h->ev[4 * h->prof_n + 3] : nullptr;
     if (xchg)
-        hipLaunchKernelGGL(k_finish_cols_xchg, dim3(h->HA), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
-                           U_in, U_out, u_out, h->d_step, h->d_dbg, h->xchg_peers, h->shard_count, h->shard_rank, ++h->xchg_seq,
-                           h->xchg_timeout_ticks, h->d_xchg_status, h->d_xchg_dead, h->d_clip);
+        hipExtLaunchKernelGGL(k_finish_cols_xchg, dim3(h->HA), dim3(kThreads), 0, st, f0, f1, 0, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
+                              U_in, U_out, u_out, h->d_step, h->d_dbg, h->xchg_peers, h->shard_count, h->shard_rank, ++h->xchg_seq,
+                              h->xchg_timeout_ticks, h->d_xchg_status, h->d_xchg_dead, (const float *)h->d_clip);
     else
-        hipLaunchKernelGGL(k_finish_cols, dim3(h->HA), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
-                           U_in, U_out, u_out, record_out, apply, h->d_step, h->d_dbg, h->d_clip);
+        hipExtLaunchKernelGGL(k_finish_cols, dim3(h->HA), dim3(kThreads), 0, st, f0, f1, 0, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
+                              U_in, U_out, u_out, record_out, apply, h->d_step, h->d_dbg, (const float *)h->d_clip);
     hipError_t e = hipGetLastError();
-    if (prof && e == hipSuccess) { e = hipEventRecord(h->ev[4 * h->prof_n + 3], st); h->prof_stream = st; h->prof_n++; }
+    if (prof && e == hipSuccess) { h->prof_stream = st; h->prof_n++; }
     return e;
 }
 
@@ -698,6 +710,22 @@ extern "C" mppi_status mppi_synchronize(mppi_handle *h)
     if (!h) return MPPI_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
+// The rollout kernel instance a fused (Philox) step of this handle launches — the same decisions as enqueue_partials /
+// launch_pc / launch_tile / launch_mlp_a, spelled the way rocprofv3 prints the instance.
+extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf, size_t n)
+{
+    if (!h || !buf || n == 0) return MPPI_ERR_INVALID_ARG;
+    const int NG = (h->H + 3) / 4;
+    if (h->hc.model_kind == MPPI_MODEL_MLP)
+        std::snprintf(buf, n, "mppi::%s<%d, %s>", h->mlp_bx3 ? "k_rollout_mlp_bx3" : "k_rollout_mlp", h->a, h->sigma_diag ? "true" : "false");
+    else if (!h->normalize && pc_eligible(h))
+        std::snprintf(buf, n, "mppi::k_rollout_pc<%d, %d, %d, %s>", h->a, h->pc_np,
+                      h->pc_np == 3 ? (NG <= 18 ? 6 : 11) : (NG <= 20 ? 4 : 8), h->sigma_diag ? "true" : "false");
+    else
+        std::snprintf(buf, n, "mppi::k_rollout_tile<%d, %d, %s, 0, %d>", h->a, h->R, h->hc.q_full ? "true" : "false", h->normalize ? 2 : 0);
     return MPPI_OK;
 }
 

@@ -39,6 +39,8 @@ struct DevConsts {
     int q_full;       // 1: Q is a dense [s,s] matrix (Py StaticCost), 0: diagonal (C++ Diag(in_Q))
     int action_cost_kind;
     int model_kind;
+    int state_cost_kind;  // MPPI_STATE_COST_*
+    float ell[7];         // ElipseCost: a, b, cx, cy, speed, m_state, m_vel (elipse_cost.py:10-46)
     float lambda;
     float neg_inv_lambda; // {{-1.f/m_lambda}}  controller_base.cpp:171
     float gamma, upsilon;
@@ -244,6 +246,37 @@ __device__ __forceinline__ float state_cost(const CT *__restrict__ C, const floa
 #pragma unroll
     for (int i = 1; i < S; ++i) acc = acc + diff[i] * left[i];
     return acc;
+}
+
+// costs/elipse_cost.py:48-85 ElipseCost.state_cost, state = (x, vx, y, vy, ...): in the reference's operation order, every
+// operation rounded on its own (correctly rounded divide and square root: hipcc's default for fp32):
+//   v = sqrt(vx² + vy²) ; dx = (x-cx)/a ; dy = (y-cy)/b ; m_state·|dx² + dy² - 1| + m_vel·(v - speed)²
+template <int S>
+__device__ __forceinline__ float state_cost_ellipse(const DevConsts *__restrict__ C, const float (&x)[S])
+{
+    static_assert(S >= 4, "the elliptic cost reads (x, vx, y, vy)");
+    const float vx2 = x[1] * x[1], vy2 = x[3] * x[3];
+    const float v = sqrtf(vx2 + vy2); // correctly rounded (not __fsqrt_rn: that is the native ~1 ulp v_sqrt_f32 in this toolchain)
+    const float dx = (x[0] - C->ell[2]) / C->ell[0];
+    const float dy = (x[2] - C->ell[3]) / C->ell[1];
+    const float dx2 = dx * dx, dy2 = dy * dy;
+    float d = (dx2 + dy2) - 1.0f;
+    d = fabsf(d);
+    d = C->ell[5] * d;
+    const float dvv = v - C->ell[4];
+    float dv = dvv * dvv;
+    dv = C->ell[6] * dv;
+    return d + dv;
+}
+
+// the cost_base slot of the tile kernel and the helpers: the state cost the controller was built with (wave-uniform branch)
+template <int S, bool QFULL>
+__device__ __forceinline__ float state_cost_of(const DevConsts *__restrict__ C, const float (&x)[S])
+{
+    if constexpr (S >= 4) {
+        if (C->state_cost_kind == MPPI_STATE_COST_ELLIPSE) return state_cost_ellipse<S>(C, x);
+    }
+    return state_cost<S, QFULL>(C, x);
 }
 
 // cost_base.cpp:63-68 (C++: λ·uᵀ(Σ⁻¹ε), u = NOMINAL action) or cost_base.py:114-170 (γ/υ form).

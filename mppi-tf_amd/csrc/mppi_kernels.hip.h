@@ -120,12 +120,12 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
                     v[j] = u[j] + e[j];                  // to_apply        controller_base.cpp:258
                 }
                 pm_step<A>(C, x, v);
-                const float sc = state_cost<S, QFULL>(C, x);  // cost on the POST-step state
+                const float sc = state_cost_of<S, QFULL>(C, x); // cost on the POST-step state (quadratic or elliptic)
                 const float ac = action_cost<A>(C, u, e);
                 const float tmp = sc + ac;                    // Step_cost_result cost_base.cpp:49
                 c = c + tmp;                                  // path_cost        controller_base.cpp:268
             }
-            c = c + state_cost<S, QFULL>(C, x); // terminal: x_H counted a second time, :271-272
+            c = c + state_cost_of<S, QFULL>(C, x); // terminal: x_H counted a second time, :271-272
             if (valid) cost[k0 + tid] = c;
         } else {
             c = valid ? cost[k0 + tid] : 0.0f;
@@ -1384,7 +1384,7 @@ __global__ void k_costs(const DevConsts *__restrict__ C, const float *__restrict
         float xs[S];
 #pragma unroll
         for (int j = 0; j < S; ++j) xs[j] = j < s ? x[(size_t)i * s + j] : 0.0f;
-        sc = state_cost<S, QFULL>(C, xs);
+        sc = state_cost_of<S, QFULL>(C, xs);
     }
     if (u != nullptr) {
         float us[A], es[A];

@@ -43,6 +43,8 @@ extern "C" {
 
 #define ORC_ACTION_COST_CPP 0 /* λ uᵀΣ⁻¹ε                      cost_base.cpp:63-68 */
 #define ORC_ACTION_COST_PY 1  /* ½[γ(uᵀΣ⁻¹u+2uᵀΣ⁻¹ε)+λ(1-1/υ)εᵀΣ⁻¹ε]  cost_base.py:114-170 */
+#define ORC_STATE_COST_QUADRATIC 0 /* (x-g)ᵀQ(x-g)                  cost_base.cpp:56-61, static_cost.py:40-63 */
+#define ORC_STATE_COST_ELLIPSE 1   /* 2D elliptic track               costs/elipse_cost.py:48-85 */
 #define ORC_MODEL_POINT_MASS 0
 #define ORC_MODEL_MLP 1
 

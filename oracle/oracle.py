@@ -39,7 +39,8 @@ def _structs(real):
     class Cost(C.Structure):
         _fields_ = [("s", C.c_int), ("a", C.c_int), ("action_cost_kind", C.c_int),
                     ("lam", real), ("gamma", real), ("upsilon", real),
-                    ("goal", P), ("Q", P), ("sigma_inv", P)]
+                    ("goal", P), ("Q", P), ("sigma_inv", P),
+                    ("state_cost_kind", C.c_int), ("ellipse", real * 7)]
 
     class Mlp(C.Structure):
         _fields_ = [("s", C.c_int), ("a", C.c_int), ("n_layers", C.c_int),
@@ -208,7 +209,9 @@ class Problem:
 
     def __init__(self, tau, s, a, dt=0.1, mass=1.0, lam=1.0, sigma=None, goal=None, Q=None,
                  gamma=1.0, upsilon=1.0, action_cost=ACTION_COST_CPP, mlp=None, threads=1,
-                 dtype=np.float32):
+                 dtype=np.float32, ellipse=None):
+        """ellipse: dict(a, b, cx, cy, speed, m_state, m_vel) selects ElipseCost's state cost (elipse_cost.py:9-85)
+        instead of the quadratic one."""
         I = self.I = _get(dtype)
         self.tau, self.s, self.a = tau, s, a
         self.sigma = I.arr(np.eye(a) if sigma is None else sigma, (a, a))
@@ -222,6 +225,10 @@ class Problem:
         p.cost.s, p.cost.a, p.cost.action_cost_kind = s, a, action_cost
         p.cost.lam, p.cost.gamma, p.cost.upsilon = lam, gamma, upsilon
         p.cost.goal, p.cost.Q, p.cost.sigma_inv = I.ptr(self.goal), I.ptr(self.Q), I.ptr(self.sigma_inv)
+        if ellipse is not None:
+            p.cost.state_cost_kind = 1  # ORC_STATE_COST_ELLIPSE
+            for i, key in enumerate(("a", "b", "cx", "cy", "speed", "m_state", "m_vel")):
+                p.cost.ellipse[i] = ellipse[key]
         p.tau, p.threads = tau, threads
         self._keep = []
         if mlp is None:

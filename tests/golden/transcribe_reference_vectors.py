@@ -4,7 +4,7 @@
 Every number below was transcribed by hand from the literals in the reference's unit tests
 (read as text; the reference cannot be compiled or imported here — SURVEY.md §8c):
   C++  test/test_controller.cpp, test/test_cost.cpp, test/test_model.cpp, test/test_utile.cpp
-  Py   scripts/test.py (TestPointMassModel, TestCost, TestStaticCost, TestController)
+  Py   scripts/test.py (TestPointMassModel, TestCost, TestStaticCost, TestElipseCost, TestController)
 Where the reference test spells an expectation as an arithmetic expression of literals
 (e.g. `(dt*dt)/(2.f*m)`), the same expression is evaluated here in the same precision
 (np.float32 for the C++ tests, python float = fp64 for scripts/test.py) and the RESULT is stored.
@@ -207,6 +207,20 @@ def blockdiag():
 
 
 # ------------------------------------------------------------------ cost, Py γ/υ form (A5-A7)
+def cost_elipse():
+    # scripts/test.py:1098-1161 TestElipseCost: a = b = 1, centre (0, 0), speed 1, m_state = m_vel = 1;
+    # states are [k, 4, 1] = (x, vx, y, vy); expectations are the test's literals / literal sums.
+    par = dict(a=1., b=1., cx=0., cy=0., speed=1., m_state=1., m_vel=1.)
+    dump("cost_elipse", dict(
+        source="scripts/test.py:1098-1161 (TestElipseCost)", tol="assertAllClose rtol=atol=1e-6", ellipse=par,
+        scenarios=[
+            dict(name="testStepElipseCost_s4_l1_k1", state=[[0., 0.5, 1., 0.]], exp_state_cost=[0.25]),
+            dict(name="testStepElipseCost_s4_l1_k5",
+                 state=[[0., 0.5, 1., 0.], [0., 2., 0., 0.], [10., 2., 2., 3.], [1., 1., 1., 2.], [3., 4., 5., 6.]],
+                 exp_state_cost=[0.25, 2., 103 + 6.788897449072021, 1 + 1.5278640450004208, 33 + 38.57779489814404]),
+        ]))
+
+
 def cost_py():
     S4 = [[0., 0.5, 2., 0.], [0., 2., 0., 0.], [10., 2., 2., 3.], [1., 1., 1., 2.], [3., 4., 5., 6.]]
     E3 = [[0.5, 1., 2.], [0.5, 2., 0.25], [-2., -0.2, -1.], [0., 0., 0.], [1., 0.5, 3.]]
@@ -266,4 +280,5 @@ if __name__ == "__main__":
     model_py()
     blockdiag()
     cost_py()
+    cost_elipse()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".json")))

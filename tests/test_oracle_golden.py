@@ -105,6 +105,17 @@ def test_static_cost_py(idx, dtype):
     np.testing.assert_allclose(p.step_cost(sc["state"], sc["action"], sc["noise"]), sc["exp_step"], rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("idx", range(2))
+@pytest.mark.parametrize("dtype", [F32, F64])
+def test_elipse_cost_py(idx, dtype):
+    """ElipseCost.state_cost (costs/elipse_cost.py:48-85) against TestElipseCost's literals (scripts/test.py:1098-1161)."""
+    g = load_golden("cost_elipse")
+    sc = g["scenarios"][idx]
+    p = orc.Problem(tau=1, s=4, a=2, ellipse=g["ellipse"], dtype=dtype)
+    tol = 1e-6 if dtype is F64 else 2e-6
+    np.testing.assert_allclose(p.state_cost(sc["state"]), sc["exp_state_cost"], rtol=tol, atol=tol)
+
+
 # ---------------------------------------------------------------- A3 data prep
 def test_dataprep_slicing_is_the_khta_layout():
     """mPrepareAction/mPrepareNoise (controller_base.cpp:205-213) are U[t] and eps[:,t]; the oracle

@@ -432,6 +432,73 @@ def test_cpp_facade_reference_vectors_and_host_loop(m):
     assert "Execution time" in r.stdout
 
 
+# =============================================================== §8f row 4 (first slice): the elliptic cost in the cost_base slot
+def test_golden_elipse_cost_on_device(m):
+    """ElipseCost.state_cost (costs/elipse_cost.py:48-85) through the device cost slot: TestElipseCost's literals
+    (scripts/test.py:1098-1161) at the reference's tolerance, and bit-identical to the fp32 oracle."""
+    g = load_golden("cost_elipse")
+    e = g["ellipse"]
+    cost = m.ElipseCost(1.0, 1.0, 1.0, np.eye(2), e["a"], e["b"], e["cx"], e["cy"], e["speed"], e["m_state"], e["m_vel"])
+    p = orc.Problem(tau=1, s=4, a=2, ellipse=e)
+    for sc in g["scenarios"]:
+        st = np.asarray(sc["state"], F32)[..., None]
+        got = cost.state_cost("", st)
+        assert got.shape == (len(sc["state"]), 1, 1)
+        np.testing.assert_allclose(got.ravel(), sc["exp_state_cost"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(got.ravel(), p.state_cost(sc["state"]))
+    rng = np.random.default_rng(0)
+    X = (3 * rng.standard_normal((4096, 4))).astype(F32)
+    p2 = orc.Problem(tau=1, s=4, a=2, ellipse=dict(a=4., b=2., cx=0.3, cy=-0.2, speed=5., m_state=1., m_vel=0.1))
+    c2 = m.ElipseCost(1.0, 1.0, 1.0, np.eye(2), 4., 2., 0.3, -0.2, 5., 1., 0.1)
+    np.testing.assert_array_equal(c2.state_cost("", X[..., None]).ravel(), p2.state_cost(X))  # correctly rounded / and sqrt
+    with pytest.raises(AssertionError):
+        cost.state_cost("", np.zeros((3, 6, 1)))
+    with pytest.raises(m.MppiError):
+        m.Handle(k=8, tau=2, s_dim=2, a_dim=1, ellipse=e)  # the cost reads (x, vx, y, vy)
+
+
+@pytest.mark.parametrize("K,H", [(4096, 32), (1000, 17)])
+def test_control_step_with_the_elipse_cost_matches_oracle(m, K, H):
+    """The whole control step of a point_mass2d controller with the elliptic cost (general tile kernel): sample costs
+    bit-identical to the oracle, update within 1e-5, injected and Philox noise; then the reference-shaped entry point
+    (examples/main.py --task elipse_task.yaml) drives the plant onto the ellipse at the target speed."""
+    ell = dict(a=2., b=1., cx=0., cy=0., speed=1., m_state=1., m_vel=0.1)
+    cfg = dict(tau=H, dt=0.1, mass=1.0, lam=1.0, sigma=np.eye(2))
+    h = m.Handle(k=K, s_dim=4, a_dim=2, ellipse=ell, seed=2, **cfg)
+    p = orc.Problem(s=4, a=2, ellipse=ell, threads=0, **cfg)
+    x = np.array([1.5, 0.0, 0.2, 0.4], F32)
+    rng = np.random.default_rng(1)
+    for step in range(2):
+        U_in = h.get_action_sequence()  # the oracle starts every step from the handle's own sequence
+        eps = rng.standard_normal((K, H, 2)).astype(F32)
+        u = h.next_with_noise(x, eps)
+        u_ref, U_ref, c_ref = p.next_with_noise(x, U_in, eps)
+        np.testing.assert_array_equal(h.debug_get(m.DBG_COSTS), c_ref)
+        np.testing.assert_allclose(u, u_ref, rtol=0, atol=U_TOL)
+        np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=U_TOL)
+    U_in = h.get_action_sequence()
+    u = h.next(x)
+    eps = h.debug_get(m.DBG_NOISE)
+    u_ref, U2, c_ref = p.next_with_noise(x, U_in, eps)
+    np.testing.assert_array_equal(h.debug_get(m.DBG_COSTS), c_ref)
+    np.testing.assert_allclose(u, u_ref, rtol=0, atol=U_TOL)
+
+
+def test_entry_point_follows_the_elipse(m):
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "main.py"), "--new",
+                        "--config", os.path.join(ROOT, "examples", "config", "point_mass2d.yaml"),
+                        "--task", os.path.join(ROOT, "examples", "config", "elipse_task.yaml"), "-s", "150"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    xd = float(r.stdout.split("x_dist =")[1].split()[0])
+    vd = float(r.stdout.split("v_dist =")[1].split()[0])
+    assert abs(xd) < 0.3 and vd < 0.7, r.stdout  # on the ellipse (x_dist ~ 0) and moving along it (speed within 0.7 of the target 1)
+
+
 # =============================================================== M2: learned 2x256 MLP model_base (parity unpinned by the reference)
 def make_mlp(s, a, seed=0, hid=256):
     """SURVEY §8d synthetic weights: U(-1/sqrt(fan_in), 1/sqrt(fan_in)), last layer x0.1."""

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 cd /tmp
 WORKLOAD=${2:-pm3d}
 STEPS=200; [ "$WORKLOAD" = "mlp" ] && STEPS=10
-BENCH="python3 $R/bench.py --workload $WORKLOAD --steps $STEPS --warmup 3 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --workload $WORKLOAD --steps $STEPS --warmup 3 --no-cpu-baseline --no-subrecords --min-time 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1
 # VALU instructions by class (for the issue-rate floor, roofline.valu) and the busy cycles of the issue ports: own passes
