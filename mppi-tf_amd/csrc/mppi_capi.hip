@@ -28,6 +28,8 @@ struct mppi_handle {
     int R = 64, nb = 0;   // tile size / record count of the point-mass tile kernels
     int nb_mlp = 0;       // record count of the MLP rollout kernel (64 rollouts per workgroup)
     int mlp_bx3 = 0;      // MPPI_FLAG_MLP_BF16X3: split-bf16 matrix-core variant of the MLP rollout
+    int n_cu = 256;       // compute units of the device (k_rollout_mlp2 runs one tile-walking workgroup per CU)
+    int mlp_v2 = 0;       // exact-fp32 MLP rollouts run k_rollout_mlp2 (one wave per SIMD, two pipelined sets; a_dim <= 3)
     MlpDev hm{};          // learned model: device pointers + normalisation (host copy)
     MlpDev *dM = nullptr;
     float *d_mlp_w = nullptr; // one allocation holding W1,b1,W2,b2,W3,b3
@@ -316,12 +318,14 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     else if (a > 4) h->no_rollout = "rollout kernels are instantiated for a_dim <= 4";
     else if (tile_lds_floats(h->HA, R) * 4 > lds_cap) h->no_rollout = "tau*a_dim too large: the 16-rollout LDS tile exceeds 160 KiB";
     h->R = R; h->nb = (h->K_local + R - 1) / R; h->tile_lds = tile_lds_floats(h->HA, R) * 4;
-    h->nb_mlp = cfg->model_kind == MPPI_MODEL_MLP ? (h->K_local + kMlpR - 1) / kMlpR : 0;
     h->mlp_bx3 = (cfg->model_kind == MPPI_MODEL_MLP && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) ? 1 : 0;
+    h->mlp_v2 = (cfg->model_kind == MPPI_MODEL_MLP && !h->mlp_bx3 && a <= 3) ? 1 : 0; // a_dim = 4: two h1 images + the rest exceed 160 KiB of LDS
+    h->nb_mlp = cfg->model_kind == MPPI_MODEL_MLP ? (h->mlp_v2 ? (h->K_local + kMlp2R - 1) / kMlp2R : (h->K_local + kMlpR - 1) / kMlpR) : 0;
 
     mppi_status st = MPPI_OK;
     auto body = [&]() -> mppi_status {
         HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
         HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_TRY(h, hipMalloc((void **)&h->dC, sizeof(DevConsts)));
         HIP_TRY(h, hipMalloc((void **)&h->d_x, sizeof(float) * kMaxS));
@@ -484,8 +488,8 @@ template <int A>
 static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
                                const float *eps, float *cost)
 {
-    const size_t lds = mlp_lds_floats(2 * A, A) * 4;
-    const dim3 g(h->nb_mlp), b(kMlpThreads);
+    const size_t lds = (h->mlp_v2 ? mlp2_lds_floats(2 * A, A, h->H) : mlp_lds_floats(2 * A, A)) * 4;
+    const dim3 g(h->mlp_v2 ? std::min(h->nb_mlp, h->n_cu) : h->nb_mlp), b(h->mlp_v2 ? kMlp2Threads : kMlpThreads);
     if (mode != MODE_ROLLOUT && mode != MODE_COST_ONLY) return hipErrorInvalidValue;
 #define MPPI_MLP_L(KERN, BIT)                                                                                           \
     do {                                                                                                                \
@@ -501,6 +505,28 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
     if (h->mlp_bx3) {
         if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp_bx3<A, true>), 8);
         else MPPI_MLP_L((k_rollout_mlp_bx3<A, false>), 16);
+    } else if (h->mlp_v2) {
+        if constexpr (A <= 3) {
+#define MPPI_MLP2_L(KERN, BIT)                                                                                          \
+    do {                                                                                                                \
+        auto kern = KERN;                                                                                               \
+        if (!(h->attr_done & BIT)) {                                                                                    \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e_ != hipSuccess) return e_;                                                                            \
+            h->attr_done |= BIT;                                                                                        \
+        }                                                                                                               \
+        hipExtLaunchKernelGGL(kern, g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, x_dev, U_dev, eps, \
+                              (const unsigned long long *)h->d_step, cost, h->d_part, mode, 1, h->nb_mlp);                     \
+    } while (0)
+            if (src == SRC_PHILOX) {
+                if (h->sigma_diag) MPPI_MLP2_L((k_rollout_mlp2<A, true, SRC_PHILOX>), 32);
+                else MPPI_MLP2_L((k_rollout_mlp2<A, false, SRC_PHILOX>), 64);
+            } else if (src == SRC_HBM) {
+                if (h->sigma_diag) MPPI_MLP2_L((k_rollout_mlp2<A, true, SRC_HBM>), 128);
+                else MPPI_MLP2_L((k_rollout_mlp2<A, false, SRC_HBM>), 256);
+            } else return hipErrorInvalidValue;
+#undef MPPI_MLP2_L
+        } else return hipErrorInvalidValue;
     } else if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp<A, true>), 2);
     else MPPI_MLP_L((k_rollout_mlp<A, false>), 4);
 #undef MPPI_MLP_L
@@ -720,7 +746,8 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
     if (!h || !buf || n == 0) return MPPI_ERR_INVALID_ARG;
     const int NG = (h->H + 3) / 4;
     if (h->hc.model_kind == MPPI_MODEL_MLP)
-        std::snprintf(buf, n, "mppi::%s<%d, %s>", h->mlp_bx3 ? "k_rollout_mlp_bx3" : "k_rollout_mlp", h->a, h->sigma_diag ? "true" : "false");
+        if (h->mlp_v2 && !h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp2<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
+        else std::snprintf(buf, n, "mppi::%s<%d, %s>", h->mlp_bx3 ? "k_rollout_mlp_bx3" : "k_rollout_mlp", h->a, h->sigma_diag ? "true" : "false");
     else if (!h->normalize && pc_eligible(h))
         std::snprintf(buf, n, "mppi::k_rollout_pc<%d, %d, %d, %s>", h->a, h->pc_np,
                       h->pc_np == 3 ? (NG <= 18 ? 6 : 11) : (NG <= 20 ? 4 : 8), h->sigma_diag ? "true" : "false");
@@ -1065,6 +1092,11 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
         if (value < 0 || value > 64 * 1024) return fail(h, MPPI_ERR_INVALID_ARG, "LDS bytes out of range (0..65536)");
         h->pc_lds_min = value; break;
     case MPPI_TUNE_SYNC_SPIN: h->sync_spin = value != 0; break;
+    case MPPI_TUNE_MLP_V1: // the first exact-fp32 MLP kernel (8 waves, 64 rollouts per workgroup), for A/B timing
+        if (h->hc.model_kind != MPPI_MODEL_MLP || h->mlp_bx3) return fail(h, MPPI_ERR_INVALID_ARG, "not an exact-fp32 MLP handle");
+        h->mlp_v2 = (value == 0 && h->a <= 3) ? 1 : 0;
+        h->nb_mlp = h->mlp_v2 ? (h->K_local + kMlp2R - 1) / kMlp2R : (h->K_local + kMlpR - 1) / kMlpR; // d_part is sized for the larger count
+        break;
     case MPPI_TUNE_P2P_FAULT:
         if (value < 0 || value > 2) return fail(h, MPPI_ERR_INVALID_ARG, "fault: 0 none, 1 export, 2 probe");
         h->p2p_fault = value; break;

@@ -753,7 +753,7 @@ __global__ void k_mlp_step_ref(const DevConsts *__restrict__ C, const MlpDev *__
 // Tile record of the MLP rollout kernels: every wave holds the same 64 costs; beta, eta by wave 0, and
 // V_b[t,i] = Σ_k e_k·eps[k,t,i] with wave w regenerating the noise of horizon groups g = w, w+8, ... from the Philox
 // counters (cheap next to H steps of MFMA).
-template <int A, bool DIAG>
+template <int A, bool DIAG, int NWAVES = 8>
 __device__ __forceinline__ void mlp_tile_record(const DevConsts *__restrict__ C, float c, bool valid, int w, int lane, int kk,
                                                 int H, int NG, int SRC, const float *__restrict__ eps_hbm,
                                                 unsigned long long seed, unsigned long long gk, unsigned long long base,
@@ -764,7 +764,7 @@ __device__ __forceinline__ void mlp_tile_record(const DevConsts *__restrict__ C,
     const float ek = valid ? expf(C->neg_inv_lambda * (c - beta)) : 0.0f;
     const float eta = wave_sum(ek);
     if (w == 0 && lane == 0) { rec[0] = beta; rec[(size_t)rsc] = eta; }
-    for (int g = w; g < NG; g += 8) {
+    for (int g = w; g < NG; g += NWAVES) {
         float zz[4 * A];
         if (SRC == SRC_PHILOX) normals_group<A>(seed, gk, base + (unsigned long long)g, zz);
 #pragma unroll
@@ -1306,6 +1306,10 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
     mlp_tile_record<A, DIAG>(C, c, valid, w, lane, kk, H, NG, SRC, eps_hbm, seed, gk, base,
                              partials + (size_t)blockIdx.x * rsb, rsc); // element (b, col) at partials[b*rsb + col*rsc]
 }
+
+} // namespace mppi
+#include "mppi_mlp2.hip.h"
+namespace mppi {
 
 // min / max of the costs (Py normalizeCost, controller_base.py:468-474): out[0]=min, out[1]=max-min
 __global__ __launch_bounds__(kFinishThreads) void k_cost_minmax(const float *__restrict__ cost, int K, float *__restrict__ out)

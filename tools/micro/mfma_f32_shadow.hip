@@ -33,21 +33,29 @@
 #define F_FMADEP3(n) "v_fma_f32 v16, v1, v2, v16\n\tv_fma_f32 v17, v1, v2, v17\n\tv_fma_f32 v18, v1, v2, v18\n\t"
 // the layer-3 row of k_rollout_mlp2: relu of an accumulator register, then 3 packed fmas that broadcast it
 #define F_L3ROW(n) "v_max_f32 v16, 0, v96\n\ts_nop 0\n\tv_pk_fma_f32 v[32:33], v[16:17], v[4:5], v[32:33] op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 v[34:35], v[16:17], v[6:7], v[34:35] op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 v[36:37], v[16:17], v[4:5], v[36:37] op_sel_hi:[0,1,1]\n\t"
+// in-place relu of registers that no MFMA in flight touches (k_rollout_mlp2's relu lump), 16 distinct registers
+#define F_RELU(n) "v_max_f32 v" #n ", 0, v" #n "\n\t"
 #define N0(F)
 #define N1(F) F(16)
 #define N2(F) F(16) F(17)
 #define N4(F) F(16) F(17) F(18) F(19)
 #define N8(F) F(16) F(17) F(18) F(19) F(20) F(21) F(22) F(23)
 #define N12(F) N8(F) F(24) F(25) F(26) F(27)
+#define N16(F) N12(F) F(28) F(29) F(30) F(31)
+#define N32(F) N16(F) N16(F)
 // 8 MFMAs per asm body, fillers after each
 #define BODY(NF, F) MF0 NF(F) MF1 NF(F) MF0 NF(F) MF1 NF(F) MF0 NF(F) MF1 NF(F) MF0 NF(F) MF1 NF(F)
-#define CLOB "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
+// the rollout kernel's shape: both MFMAs of a k pair (each behind its s_nop 1), then the lump
+#define BODY2(NF, F) "s_nop 1\n\t" MF0 "s_nop 1\n\t" MF1 NF(F) "s_nop 1\n\t" MF0 "s_nop 1\n\t" MF1 NF(F) "s_nop 1\n\t" MF0 "s_nop 1\n\t" MF1 NF(F) "s_nop 1\n\t" MF0 "s_nop 1\n\t" MF1 NF(F)
+#define CLOB "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", \
     "v32", "v33", "v34", "v35", "v36", "v37", "v96", "v40", "v41", "v42", "v43", "s40", "scc", "memory", \
     "v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79", \
     "v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95", "a0", "a1"
 
 constexpr int ITERS = 256;
-#define KERNEL(NAME, NF, F)                                                                                            \
+#define KERNEL(NAME, NF, F) KERNELB(NAME, BODY(NF, F))
+#define KERNEL2(NAME, NF, F) KERNELB(NAME, BODY2(NF, F))
+#define KERNELB(NAME, THEBODY)                                                                                            \
     __global__ __launch_bounds__(512) void NAME(unsigned long long *out, float seed)                                    \
     {                                                                                                                  \
         extern __shared__ float lds[];                                                                                 \
@@ -68,7 +76,7 @@ constexpr int ITERS = 256;
                      "v_mov_b32 v94, 0\n\tv_mov_b32 v95, 0\n\t" ::: CLOB);                                               \
         __syncthreads();                                                                                               \
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                    \
-        for (int it = 0; it < ITERS; ++it) asm volatile(BODY(NF, F) "s_waitcnt lgkmcnt(0)\n\t" ::: CLOB);               \
+        for (int it = 0; it < ITERS; ++it) asm volatile(THEBODY "s_waitcnt lgkmcnt(0)\n\t" ::: CLOB);               \
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                                             \
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                    \
         float r;                                                                                                       \
@@ -88,6 +96,8 @@ KERNEL(k_snop4, N4, F_SNOP) KERNEL(k_snop8, N8, F_SNOP) KERNEL(k_salu4, N4, F_SA
 KERNEL(k_pkd1_4, N4, F_PKDEP1) KERNEL(k_pkd1_8, N8, F_PKDEP1) KERNEL(k_pkd3_1, N1, F_PKDEP3) KERNEL(k_pkd3_4, N4, F_PKDEP3)
 KERNEL(k_fd1_4, N4, F_FMADEP1) KERNEL(k_fd1_8, N8, F_FMADEP1) KERNEL(k_fd3_4, N4, F_FMADEP3)
 KERNEL(k_l3_1, N1, F_L3ROW) KERNEL(k_l3_2, N2, F_L3ROW) KERNEL(k_l3_4, N4, F_L3ROW)
+KERNEL(k_relu16, N16, F_RELU) KERNEL(k_relu32, N32, F_RELU) KERNEL(k_fma16, N16, F_FMA) KERNEL(k_fma32, N32, F_FMA)
+KERNEL2(k2_none, N0, F_FMA) KERNEL2(k2_l3x2, N2, F_L3ROW) KERNEL2(k2_l3x4, N4, F_L3ROW) KERNEL2(k2_relu32, N32, F_RELU) KERNEL2(k2_fma8, N8, F_FMA) KERNEL2(k2_fma1, N1, F_FMA)
 KERNEL(k_cvt4, N4, F_CVT) KERNEL(k_exp2, N2, F_EXP) KERNEL(k_exp4, N4, F_EXP) KERNEL(k_mullo4, N4, F_MULLO)
 
 struct Case { const char *name; void (*k)(unsigned long long *, float); int nf; };
@@ -102,6 +112,8 @@ int main()
                     {"v_pk_fma_f32 dependent x4", k_pkd1_4, 4}, {"v_pk_fma_f32 dependent x8", k_pkd1_8, 8}, {"v_pk_fma_f32 3 chains x3", k_pkd3_1, 3}, {"v_pk_fma_f32 3 chains x12", k_pkd3_4, 12},
                     {"v_fma_f32 dependent x4", k_fd1_4, 4}, {"v_fma_f32 dependent x8", k_fd1_8, 8}, {"v_fma_f32 3 chains x12", k_fd3_4, 12},
                     {"layer-3 row (v_max + 3 v_pk_fma) x1", k_l3_1, 4}, {"layer-3 row x2", k_l3_2, 8}, {"layer-3 row x4", k_l3_4, 16},
+                    {"v_max_f32 in place x16", k_relu16, 16}, {"v_max_f32 in place x32", k_relu32, 32}, {"v_fma_f32 x16", k_fma16, 16}, {"v_fma_f32 x32", k_fma32, 32},
+                    {"[2 MFMAs, lump] none", k2_none, 0}, {"[2 MFMAs, lump] layer-3 row x2", k2_l3x2, 8}, {"[2 MFMAs, lump] layer-3 row x4", k2_l3x4, 16}, {"[2 MFMAs, lump] v_max in place x32", k2_relu32, 32}, {"[2 MFMAs, lump] v_fma_f32 x8", k2_fma8, 8}, {"[2 MFMAs, lump] v_fma_f32 x1", k2_fma1, 1},
                     {"v_cvt_f32_u32 x4", k_cvt4, 4}, {"v_exp_f32 x2", k_exp2, 2}, {"v_exp_f32 x4", k_exp4, 4}, {"v_mul_lo_u32 x4", k_mullo4, 4}};
     unsigned long long *d;
     CK(hipMalloc((void **)&d, 8 * 8192));
