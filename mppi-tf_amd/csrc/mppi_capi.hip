@@ -28,6 +28,8 @@ struct mppi_handle {
     int R = 64, nb = 0;   // tile size / record count of the point-mass tile kernels
     int nb_mlp = 0;       // record count of the MLP rollout kernel (64 rollouts per workgroup)
     int mlp_bx3 = 0;      // MPPI_FLAG_MLP_BF16X3: split-bf16 matrix-core variant of the MLP rollout
+    int mlp_small = 0;    // hidden width (16 or 32) of a small learned model served by k_rollout_mlp_small, else 0
+    MlpSmallArgs small_args{};
     int n_cu = 256;       // compute units of the device (k_rollout_mlp2 runs one tile-walking workgroup per CU)
     int mlp_v2 = 0;       // exact-fp32 MLP rollouts run k_rollout_mlp2 (one wave per SIMD, two pipelined sets; a_dim <= 3)
     MlpDev hm{};          // learned model: device pointers + normalisation (host copy)
@@ -238,9 +240,16 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     if (cfg->model_kind == MPPI_MODEL_MLP) {
         const mppi_mlp_desc *d = cfg->mlp;
         if (!d || !d->widths || !d->W || !d->b) return fail(nullptr, MPPI_ERR_INVALID_ARG, "MLP model needs cfg.mlp with widths, W, b");
-        if (d->n_layers != 3 || d->widths[0] != kHid || d->widths[1] != kHid || d->widths[2] != s)
-            return fail(nullptr, MPPI_ERR_UNSUPPORTED, "the MLP kernels implement Dense(256,relu) x2 + Dense(s_dim): widths must be {256,256,s_dim}");
-        for (int l = 0; l < 3; ++l) if (!d->W[l] || !d->b[l]) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NULL MLP weight pointer");
+        if (d->n_layers < 2 || d->n_layers > kMlpSmallMaxLayers) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "MLP: 2 to 4 Dense layers (1 to 3 hidden + the output layer)");
+        for (int l = 0; l < d->n_layers; ++l) if (!d->W[l] || !d->b[l]) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NULL MLP weight pointer");
+        if (d->widths[d->n_layers - 1] != s) return fail(nullptr, MPPI_ERR_INVALID_ARG, "MLP: the last layer's width must be s_dim");
+        const int hid = d->widths[0];
+        bool same = true;
+        for (int l = 0; l + 1 < d->n_layers; ++l) same = same && d->widths[l] == hid;
+        const bool big = d->n_layers == 3 && same && hid == kHid, small = same && (hid == 16 || hid == 32);
+        if (!big && !small)
+            return fail(nullptr, MPPI_ERR_UNSUPPORTED, "MLP kernels exist for hidden widths {256,256} (matrix cores) and 1-3 equal hidden layers of 16 or 32 (nn_model.py:54-60)");
+        if (small && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "MPPI_FLAG_MLP_BF16X3 applies to the 256-wide network only");
         if (s != 2 * a || a > 4) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "MLP rollouts are instantiated for s_dim == 2*a_dim, a_dim <= 4");
         if (cfg->q_is_full) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "MLP rollouts are instantiated for a diagonal Q");
     }
@@ -319,7 +328,8 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     else if (tile_lds_floats(h->HA, R) * 4 > lds_cap) h->no_rollout = "tau*a_dim too large: the 16-rollout LDS tile exceeds 160 KiB";
     h->R = R; h->nb = (h->K_local + R - 1) / R; h->tile_lds = tile_lds_floats(h->HA, R) * 4;
     h->mlp_bx3 = (cfg->model_kind == MPPI_MODEL_MLP && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) ? 1 : 0;
-    h->mlp_v2 = (cfg->model_kind == MPPI_MODEL_MLP && !h->mlp_bx3 && a <= 3) ? 1 : 0; // a_dim = 4: two h1 images + the rest exceed 160 KiB of LDS
+    h->mlp_small = (cfg->model_kind == MPPI_MODEL_MLP && cfg->mlp->widths[0] != kHid) ? cfg->mlp->widths[0] : 0;
+    h->mlp_v2 = (cfg->model_kind == MPPI_MODEL_MLP && !h->mlp_small && !h->mlp_bx3 && a <= 3) ? 1 : 0; // a_dim = 4: two h1 images + the rest exceed 160 KiB of LDS
     h->nb_mlp = cfg->model_kind == MPPI_MODEL_MLP ? (h->mlp_v2 ? (h->K_local + kMlp2R - 1) / kMlp2R : (h->K_local + kMlpR - 1) / kMlpR) : 0;
 
     mppi_status st = MPPI_OK;
@@ -344,18 +354,25 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         if (cfg->model_kind == MPPI_MODEL_MLP) {
             const mppi_mlp_desc *d = cfg->mlp;
             const int nin = s + a;
-            const size_t n1 = (size_t)nin * kHid, n2 = (size_t)kHid * kHid, n3 = (size_t)kHid * s;
-            const size_t total = n1 + kHid + n2 + kHid + n3 + s;
+            size_t total = 0;
+            for (int l = 0, w_in = nin; l < d->n_layers; w_in = d->widths[l], ++l) total += (size_t)(w_in + 1) * d->widths[l];
             HIP_TRY(h, hipMalloc((void **)&h->d_mlp_w, sizeof(float) * total));
             HIP_TRY(h, hipMalloc((void **)&h->dM, sizeof(MlpDev)));
             float *p = h->d_mlp_w;
-            const float *src[6] = {d->W[0], d->b[0], d->W[1], d->b[1], d->W[2], d->b[2]};
-            const size_t len[6] = {n1, (size_t)kHid, n2, (size_t)kHid, n3, (size_t)s};
-            const float **dst[6] = {&h->hm.W1, &h->hm.b1, &h->hm.W2, &h->hm.b2, &h->hm.W3, &h->hm.b3};
-            for (int i = 0; i < 6; ++i) {
-                HIP_TRY(h, hipMemcpyAsync(p, src[i], sizeof(float) * len[i], hipMemcpyHostToDevice, h->stream));
-                *dst[i] = p;
-                p += len[i];
+            h->hm.n_layers = d->n_layers;
+            h->small_args.n_layers = d->n_layers;
+            for (int l = 0, w_in = nin; l < d->n_layers; w_in = d->widths[l], ++l) {
+                const size_t nw = (size_t)w_in * d->widths[l], nbias = (size_t)d->widths[l];
+                HIP_TRY(h, hipMemcpyAsync(p, d->W[l], sizeof(float) * nw, hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(h, hipMemcpyAsync(p + nw, d->b[l], sizeof(float) * nbias, hipMemcpyHostToDevice, h->stream));
+                h->hm.widths[l] = d->widths[l];
+                h->hm.Wl[l] = h->small_args.W[l] = p;
+                h->hm.bl[l] = h->small_args.b[l] = p + nw;
+                p += nw + nbias;
+            }
+            if (!h->mlp_small) {
+                h->hm.W1 = h->hm.Wl[0]; h->hm.b1 = h->hm.bl[0]; h->hm.W2 = h->hm.Wl[1]; h->hm.b2 = h->hm.bl[1];
+                h->hm.W3 = h->hm.Wl[2]; h->hm.b3 = h->hm.bl[2];
             }
             for (int i = 0; i < nin; ++i) { h->hm.xmean[i] = d->xmean ? d->xmean[i] : 0.f; h->hm.xstd[i] = d->xstd ? d->xstd[i] : 1.f; }
             for (int i = 0; i < s; ++i) { h->hm.ymean[i] = d->ymean ? d->ymean[i] : 0.f; h->hm.ystd[i] = d->ystd ? d->ystd[i] : 1.f; }
@@ -491,6 +508,16 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
     const size_t lds = (h->mlp_v2 ? mlp2_lds_floats(2 * A, A, h->H) : mlp_lds_floats(2 * A, A)) * 4;
     const dim3 g(h->mlp_v2 ? std::min(h->nb_mlp, h->n_cu) : h->nb_mlp), b(h->mlp_v2 ? kMlp2Threads : kMlpThreads);
     if (mode != MODE_ROLLOUT && mode != MODE_COST_ONLY) return hipErrorInvalidValue;
+    if (h->mlp_small) { // one wave = one 64-rollout tile, weights through the scalar cache
+        const dim3 gs(h->nb_mlp), bs(64);
+        if (h->mlp_small == 16)
+            hipExtLaunchKernelGGL((k_rollout_mlp_small<A, 16>), gs, bs, 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, h->small_args,
+                                  x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp);
+        else
+            hipExtLaunchKernelGGL((k_rollout_mlp_small<A, 32>), gs, bs, 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, h->small_args,
+                                  x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp);
+        return hipGetLastError();
+    }
 #define MPPI_MLP_L(KERN, BIT)                                                                                           \
     do {                                                                                                                \
         auto kern = KERN;                                                                                               \
@@ -746,7 +773,8 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
     if (!h || !buf || n == 0) return MPPI_ERR_INVALID_ARG;
     const int NG = (h->H + 3) / 4;
     if (h->hc.model_kind == MPPI_MODEL_MLP)
-        if (h->mlp_v2 && !h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp2<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
+        if (h->mlp_small) std::snprintf(buf, n, "mppi::k_rollout_mlp_small<%d, %d>", h->a, h->mlp_small);
+        else if (h->mlp_v2 && !h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp2<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
         else std::snprintf(buf, n, "mppi::%s<%d, %s>", h->mlp_bx3 ? "k_rollout_mlp_bx3" : "k_rollout_mlp", h->a, h->sigma_diag ? "true" : "false");
     else if (!h->normalize && pc_eligible(h))
         std::snprintf(buf, n, "mppi::k_rollout_pc<%d, %d, %d, %s>", h->a, h->pc_np,
@@ -1093,7 +1121,7 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
         h->pc_lds_min = value; break;
     case MPPI_TUNE_SYNC_SPIN: h->sync_spin = value != 0; break;
     case MPPI_TUNE_MLP_V1: // the first exact-fp32 MLP kernel (8 waves, 64 rollouts per workgroup), for A/B timing
-        if (h->hc.model_kind != MPPI_MODEL_MLP || h->mlp_bx3) return fail(h, MPPI_ERR_INVALID_ARG, "not an exact-fp32 MLP handle");
+        if (h->hc.model_kind != MPPI_MODEL_MLP || h->mlp_bx3 || h->mlp_small) return fail(h, MPPI_ERR_INVALID_ARG, "not an exact-fp32 2x256 MLP handle");
         h->mlp_v2 = (value == 0 && h->a <= 3) ? 1 : 0;
         h->nb_mlp = h->mlp_v2 ? (h->K_local + kMlp2R - 1) / kMlp2R : (h->K_local + kMlpR - 1) / kMlpR; // d_part is sized for the larger count
         break;

@@ -710,8 +710,10 @@ __global__ void k_xchg_probe(XchgPeers peers, size_t probe_off, int G, int rank,
 // Device-side weights, Keras layout [in x out] row-major.
 constexpr int kHid = 256;
 struct MlpDev {
-    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    const float *W1, *b1, *W2, *b2, *W3, *b3; // the {256, 256, s} network of k_rollout_mlp / _mlp2 / _bx3 (NULL otherwise)
     float xmean[kMaxS + kMaxA], xstd[kMaxS + kMaxA], ymean[kMaxS], ystd[kMaxS];
+    int n_layers, widths[4];                  // every network: Dense layers l = 0 .. n_layers-1, [in x out] row-major
+    const float *Wl[4], *bl[4];
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -725,29 +727,24 @@ __global__ void k_mlp_step_ref(const DevConsts *__restrict__ C, const MlpDev *__
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
     const int s = C->s, a = C->a, nin = s + a;
-    float *h0 = scratch + (size_t)i * 2 * kHid, *h1 = h0 + kHid;
+    float *cur = scratch + (size_t)i * 2 * kHid, *nxt = cur + kHid;
     const float *xi = x + (size_t)(kx == 1 ? 0 : i) * s;
-    float in[kMaxS + kMaxA];
-    for (int j = 0; j < s; ++j) in[j] = (xi[j] - M->xmean[j]) / M->xstd[j];
-    for (int j = 0; j < a; ++j) in[s + j] = (v[(size_t)i * a + j] - M->xmean[s + j]) / M->xstd[s + j];
-    for (int o = 0; o < kHid; ++o) {
-        float acc = 0.0f;
-        for (int j = 0; j < nin; ++j) acc = acc + in[j] * M->W1[j * kHid + o];
-        acc = acc + M->b1[o];
-        h0[o] = acc < 0.0f ? 0.0f : acc;
+    for (int j = 0; j < s; ++j) cur[j] = (xi[j] - M->xmean[j]) / M->xstd[j];
+    for (int j = 0; j < a; ++j) cur[s + j] = (v[(size_t)i * a + j] - M->xmean[s + j]) / M->xstd[s + j];
+    int width = nin;
+    for (int l = 0; l < M->n_layers; ++l) {
+        const int out_w = M->widths[l];
+        const float *W = M->Wl[l], *b = M->bl[l];
+        for (int o = 0; o < out_w; ++o) {
+            float acc = 0.0f;
+            for (int j = 0; j < width; ++j) acc = acc + cur[j] * W[j * out_w + o];
+            acc = acc + b[o];
+            nxt[o] = (l + 1 < M->n_layers && acc < 0.0f) ? 0.0f : acc; // relu on hidden layers
+        }
+        float *t = cur; cur = nxt; nxt = t;
+        width = out_w;
     }
-    for (int o = 0; o < kHid; ++o) {
-        float acc = 0.0f;
-        for (int j = 0; j < kHid; ++j) acc = acc + h0[j] * M->W2[j * kHid + o];
-        acc = acc + M->b2[o];
-        h1[o] = acc < 0.0f ? 0.0f : acc;
-    }
-    for (int o = 0; o < s; ++o) {
-        float acc = 0.0f;
-        for (int j = 0; j < kHid; ++j) acc = acc + h1[j] * M->W3[j * s + o];
-        acc = acc + M->b3[o];
-        out_next[(size_t)i * s + o] = xi[o] + (acc * M->ystd[o] + M->ymean[o]);
-    }
+    for (int o = 0; o < s; ++o) out_next[(size_t)i * s + o] = xi[o] + (cur[o] * M->ystd[o] + M->ymean[o]);
 }
 
 // Tile record of the MLP rollout kernels: every wave holds the same 64 costs; beta, eta by wave 0, and
@@ -1309,6 +1306,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
 
 } // namespace mppi
 #include "mppi_mlp2.hip.h"
+#include "mppi_mlp_small.hip.h"
 namespace mppi {
 
 // min / max of the costs (Py normalizeCost, controller_base.py:468-474): out[0]=min, out[1]=max-min

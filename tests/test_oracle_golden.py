@@ -238,3 +238,25 @@ def test_noise_is_shard_invariant_and_standard_normal():
     sig = np.array([[0.5, 0.1, 0], [0, 0.25, 0], [0.2, 0, 1.0]], F32)
     e = orc.noise(1, 3, 0, 4096, 16, 3, sig)
     np.testing.assert_allclose(e, z_all @ sig.T, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("hid,n_hidden", [(32, 3), (16, 3), (256, 2)], ids=["32x3", "16x3", "256x2"])
+def test_mlp_step_restatement_against_numpy(hid, n_hidden):
+    """orc_mlp_step (the learned-step convention of nn_model.py:215-239,289-304 with the reference's layer shapes,
+    nn_model.py:54-60: Dense(32, relu) x3 + Dense(s)) against a plain numpy fp64 evaluation of the same formulas."""
+    s, a = 6, 3
+    rng = np.random.default_rng(hid + n_hidden)
+    dims = [s + a] + [hid] * n_hidden + [s]
+    W = [rng.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i]) for i in range(n_hidden + 1)]
+    b = [rng.uniform(-1, 1, dims[i + 1]) for i in range(n_hidden + 1)]
+    mlp = dict(W=W, b=b, xmean=rng.uniform(-.1, .1, s + a), xstd=rng.uniform(.8, 1.2, s + a),
+               ymean=rng.uniform(-.01, .01, s), ystd=rng.uniform(.8, 1.2, s))
+    p = orc.Problem(tau=4, s=s, a=a, sigma=np.eye(a), goal=[1, 0, 1, 0, 1, 0], mlp=mlp, dtype=np.float64)
+    for _ in range(20):
+        x, v = rng.standard_normal(s), rng.standard_normal(a)
+        h = (np.concatenate([x, v]) - mlp["xmean"]) / mlp["xstd"]
+        for l in range(n_hidden + 1):
+            h = h @ W[l] + b[l]
+            if l < n_hidden:
+                h = np.maximum(h, 0)
+        np.testing.assert_allclose(p.mlp_step(x, v), x + (h * mlp["ystd"] + mlp["ymean"]), rtol=1e-12, atol=1e-13)

@@ -500,14 +500,15 @@ def test_entry_point_follows_the_elipse(m):
 
 
 # =============================================================== M2: learned 2x256 MLP model_base (parity unpinned by the reference)
-def make_mlp(s, a, seed=0, hid=256):
-    """SURVEY §8d synthetic weights: U(-1/sqrt(fan_in), 1/sqrt(fan_in)), last layer x0.1."""
+def make_mlp(s, a, seed=0, hid=256, n_hidden=2):
+    """SURVEY §8d synthetic weights: U(-1/sqrt(fan_in), 1/sqrt(fan_in)), last layer x0.1. hid=32, n_hidden=3 is the
+    reference's own network shape (nn_model.py:54-60)."""
     rng = np.random.default_rng(seed)
-    dims = [s + a, hid, hid, s]
-    W = [rng.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i]) for i in range(3)]
-    b = [rng.uniform(-1, 1, dims[i + 1]) / np.sqrt(dims[i]) for i in range(3)]
-    W[2] *= 0.1
-    b[2] *= 0.1
+    dims = [s + a] + [hid] * n_hidden + [s]
+    W = [rng.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i]) for i in range(n_hidden + 1)]
+    b = [rng.uniform(-1, 1, dims[i + 1]) / np.sqrt(dims[i]) for i in range(n_hidden + 1)]
+    W[-1] *= 0.1
+    b[-1] *= 0.1
     return dict(W=[w.astype(F32) for w in W], b=[v.astype(F32) for v in b],
                 xmean=rng.uniform(-0.1, 0.1, s + a).astype(F32), xstd=rng.uniform(0.8, 1.2, s + a).astype(F32),
                 ymean=rng.uniform(-0.01, 0.01, s).astype(F32), ystd=rng.uniform(0.8, 1.2, s).astype(F32))
@@ -573,13 +574,13 @@ MLP_IDS = [v[0] for v in MLP_VARIANTS]
 _oracle_cache = {}
 
 
-def mlp_step_case(K, H, a, seed, lam=1.0):
+def mlp_step_case(K, H, a, seed, lam=1.0, hid=256, n_hidden=2):
     """Inputs and the CPU oracles' answers (fp64 = truth, fp32 = what an fp32 CPU evaluation gives) of ONE control
     step with injected noise; cached so the three kernel variants share one oracle evaluation."""
-    key = (K, H, a, seed, lam)
+    key = (K, H, a, seed, lam, hid, n_hidden)
     if key not in _oracle_cache:
         s = 2 * a
-        mlp = make_mlp(s, a, seed=seed)
+        mlp = make_mlp(s, a, seed=seed, hid=hid, n_hidden=n_hidden)
         sigma, goal = 0.25 * np.eye(a), (GOAL3 + [0.25, 0])[:s]
         kw = dict(tau=H, s=s, a=a, lam=lam, sigma=sigma, goal=goal, mlp=mlp, threads=0)
         p32, p64 = orc.Problem(**kw), orc.Problem(dtype=np.float64, **kw)
@@ -595,8 +596,8 @@ def mlp_step_case(K, H, a, seed, lam=1.0):
     return _oracle_cache[key]
 
 
-def check_mlp_step(m, K, H, a, seed, kw, u_bar, factor, lam=1.0, well_conditioned=True):
-    cs = mlp_step_case(K, H, a, seed, lam)
+def check_mlp_step(m, K, H, a, seed, kw, u_bar, factor, lam=1.0, well_conditioned=True, hid=256, n_hidden=2):
+    cs = mlp_step_case(K, H, a, seed, lam, hid, n_hidden)
     h = m.Handle(k=K, tau=H, s_dim=2 * a, a_dim=a, lam=lam, sigma=cs["sigma"], goal=cs["goal"], mlp=cs["mlp"], **kw)
     h.set_action_sequence(cs["U"])
     u = h.next_with_noise(cs["x"], cs["eps"])
@@ -650,6 +651,78 @@ def test_mlp_baseline_shapes_against_oracle(m, K, H, lam, cond, name, kw, u_bar,
     seconds, and H = 128 (configs[4]) / a ragged 130. The absolute 1e-5 bar holds wherever fp32 itself can hold it; the
     K=512, H=128, lambda=1 case documents where it cannot (see MLP_VARIANTS) and is held to the fp32 CPU's own error."""
     check_mlp_step(m, K, H, 3, 100 + H, kw, u_bar, factor, lam=lam, well_conditioned=cond)
+
+
+# ---- the reference's own network shapes (nn_model.py:54-60: Dense(32, relu) x3 + Dense(s); VERDICT r01 item 8): served by
+# k_rollout_mlp_small (one rollout per lane, weights through the scalar cache into v_pk_fma_f32)
+SMALL_NETS = [(32, 3), (16, 3), (32, 1), (16, 2)]
+SMALL_IDS = ["32x3", "16x3", "32x1", "16x2"]
+
+
+@pytest.mark.parametrize("hid,n_hidden", SMALL_NETS, ids=SMALL_IDS)
+def test_small_mlp_single_step_reference_order_is_bit_exact(m, hid, n_hidden):
+    """mppi_model_step with the reference's widths: the oracle's order, bit-identical."""
+    a, s = 3, 6
+    mlp = make_mlp(s, a, seed=11, hid=hid, n_hidden=n_hidden)
+    h, p32, _ = make_mlp_pair(m, 64, 4, a, mlp)
+    assert h.rollout_kernel_name() == "mppi::k_rollout_mlp_small<3, %d>" % hid
+    rng = np.random.default_rng(0)
+    X, V = rng.standard_normal((50, s)).astype(F32), rng.standard_normal((50, a)).astype(F32)
+    np.testing.assert_array_equal(h.model_next(X, V), np.stack([p32.mlp_step(X[i], V[i]) for i in range(50)]))
+
+
+@pytest.mark.parametrize("hid,n_hidden", SMALL_NETS, ids=SMALL_IDS)
+@pytest.mark.parametrize("K,H,a", [(4096, 32, 3), (100, 16, 3), (33, 5, 2), (1000, 130, 1), (512, 24, 4)])
+def test_small_mlp_control_step_against_oracle(m, K, H, a, hid, n_hidden):
+    """One control step on injected noise: sample costs as close to the fp64 oracle as an fp32 CPU evaluation is (4x),
+    U' within north_star's 1e-5 wherever the fp32 CPU evaluation itself is (see MLP_VARIANTS: K=1000, H=130, a=1 at
+    lambda=1 is not — fp32 CPU 2.2e-5, this kernel 1.6e-5); ragged K (33, 100, 1000: partial last tile) and a horizon
+    that is no multiple of 4."""
+    check_mlp_step(m, K, H, a, 300 + H, {}, 1e-5, 4.0, hid=hid, n_hidden=n_hidden, well_conditioned=False)
+
+
+def test_small_mlp_fused_philox_step_and_sharding(m):
+    """The reference's {32,32,32,s} network on the fused Philox path: U' against the fp64 oracle on the noise the step
+    exported; the device noise is the oracle's Philox stream; and the 4-way K-sharded step reproduces the unsharded one."""
+    import torch
+    K, H, a = 8192, 20, 3
+    mlp = make_mlp(6, a, seed=5, hid=32, n_hidden=3)
+    sigma = 0.25 * np.eye(a)
+    cfg = dict(k=K, tau=H, s_dim=6, a_dim=a, lam=1.0, sigma=sigma, goal=GOAL3, mlp=mlp, seed=7)
+    h = m.Handle(**cfg)
+    p64 = orc.Problem(tau=H, s=6, a=a, lam=1.0, sigma=sigma, goal=GOAL3, mlp=mlp, threads=0, dtype=np.float64)
+    x = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
+    U_in = h.get_action_sequence()
+    u = h.next(x)
+    eps = h.debug_get(m.DBG_NOISE)
+    np.testing.assert_allclose(eps, orc.noise(7, 0, 0, K, H, a, sigma), rtol=0, atol=5e-6)
+    u64, U64, c64 = p64.next_with_noise(x, U_in, eps)
+    assert np.abs(h.get_action_sequence().astype(np.float64) - np.asarray(U64)).max() <= 1e-5
+    assert np.abs(u.astype(np.float64) - np.asarray(u64)).max() <= 1e-5
+    c = h.debug_get(m.DBG_COSTS).astype(np.float64)
+    assert (np.abs(c - np.asarray(c64)) / np.abs(np.asarray(c64))).max() < 2e-5
+    # 4 shards on one device: partial records -> combine == the unsharded update
+    shards = [m.Handle(shard_rank=r, shard_count=4, **cfg) for r in range(4)]
+    xd = torch.tensor(x, device="cuda")
+    recs = torch.empty((4, 2 + H * a), dtype=torch.float32, device="cuda")
+    for r, sh in enumerate(shards):
+        sh.shard_partial(xd.data_ptr(), recs[r].data_ptr())
+    ud = torch.empty(a, dtype=torch.float32, device="cuda")
+    shards[0].shard_finish(recs.data_ptr(), 4, ud.data_ptr())
+    shards[0].synchronize()
+    assert np.abs(ud.cpu().numpy() - u).max() <= 2e-6
+
+
+def test_mlp_shapes_without_a_kernel_are_refused(m):
+    """Widths that neither kernel family serves answer MPPI_ERR_UNSUPPORTED with the reason; the split-bf16 flag is the
+    256-wide network's."""
+    a, s = 3, 6
+    with pytest.raises(m.MppiError) as e:
+        m.Handle(k=64, tau=4, s_dim=s, a_dim=a, sigma=0.25 * np.eye(a), mlp=make_mlp(s, a, hid=64, n_hidden=2))
+    assert e.value.status == 4 and "16 or 32" in str(e.value)  # MPPI_ERR_UNSUPPORTED
+    with pytest.raises(m.MppiError) as e:
+        m.Handle(k=64, tau=4, s_dim=s, a_dim=a, sigma=0.25 * np.eye(a), mlp=make_mlp(s, a, hid=32, n_hidden=3), mlp_bf16x3=True)
+    assert e.value.status == 1  # MPPI_ERR_INVALID_ARG
 
 
 def mlp_full_size_properties(m, h, p64, x, U_in, n_check=1536):
