@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — rollouts/s of the MPPI control step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload pm3d|pm2d|pm1d|mlp] [--horizon H] [--samples K_PER_GPU]
+    python bench.py --gpus N --steps K --warmup W [--workload pm3d|pm2d|pm1d|mlp|mlp32] [--horizon H] [--samples K_PER_GPU]
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is ONE control step of the hot path: K rollouts x H model steps + costs + soft-min update + shift, with the
@@ -12,6 +12,7 @@ quoted on. Every BASELINE config is launchable:
     configs[2]  (default)
     configs[3]  --workload mlp                                 (also a sub-record of the default run, with the split-bf16 variant)
     configs[4]  --workload mlp --horizon 128 --gpus 8          (K = 65536 per rank = 524288 in all)
+    (--workload mlp32: the reference's own Dense(32) x3 network, not a BASELINE config; a sub-record of the default run)
 N>1 is WEAK scaling: every rank keeps --samples rollouts of a (samples x N)-sample controller, one exchange of the
 (beta, eta, V) record per step. Rank 0 prints ONE JSON line (value = whole-job rollouts/s, max-over-ranks time).
 
@@ -37,7 +38,8 @@ HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 MFMA_F32_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 GOALS = {1: [1.0, 0.0], 2: [1.0, 0.0, 0.0, 0.0], 3: [1.0, 0.0, 0.5, 0.0, 0.75, 0.0]}  # MuJoCo target sites
-WORKLOADS = {"pm1d": (1, False), "pm2d": (2, False), "pm3d": (3, False), "mlp": (3, True)}
+# workload -> (a_dim, learned model: None | (hidden width, hidden layers))
+WORKLOADS = {"pm1d": (1, None), "pm2d": (2, None), "pm3d": (3, None), "mlp": (3, (256, 2)), "mlp32": (3, (32, 3))}
 CONFIG_NAME = {("pm1d", 128, 32, 1): "BASELINE configs[0]", ("pm2d", 4096, 64, 1): "BASELINE configs[1]",
                ("pm3d", 65536, 64, 1): "BASELINE configs[2]", ("mlp", 65536, 64, 1): "BASELINE configs[3]",
                ("mlp", 65536, 128, 8): "BASELINE configs[4] (K = 524288 over 8 GPUs)"}
@@ -48,14 +50,15 @@ def cfg_of(a, H):
                 goal=GOALS[a], seed=1)
 
 
-def synthetic_mlp(a=3, seed=0):
-    """(s+a)->256->256->s ReLU, U(-1/sqrt(fan_in), 1/sqrt(fan_in)), last layer x0.1, identity normalisation."""
+def synthetic_mlp(a=3, seed=0, hid=HID, n_hidden=2):
+    """SURVEY §8d: (s+a)->256->256->s ReLU, U(-1/sqrt(fan_in), 1/sqrt(fan_in)), last layer x0.1, identity normalisation;
+    hid=32, n_hidden=3 is the reference's own network shape (nn_model.py:54-60)."""
     rng = np.random.default_rng(seed)
-    dims = [3 * a, HID, HID, 2 * a]
-    W = [(rng.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
-    b = [(rng.uniform(-1, 1, dims[i + 1]) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
-    W[2] *= 0.1
-    b[2] *= 0.1
+    dims = [3 * a] + [hid] * n_hidden + [2 * a]
+    W = [(rng.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(n_hidden + 1)]
+    b = [(rng.uniform(-1, 1, dims[i + 1]) / np.sqrt(dims[i])).astype(np.float32) for i in range(n_hidden + 1)]
+    W[-1] *= 0.1
+    b[-1] *= 0.1
     return dict(W=W, b=b)
 
 
@@ -64,7 +67,8 @@ def work_per_state_step(a, mlp):
     s = 2 * a
     flop = 6 * s + 5 * a + 3
     if mlp:
-        flop += 2 * ((s + a) * HID + HID * HID + HID * s)
+        hid, n_hidden = mlp
+        flop += 2 * ((s + a) * hid + (n_hidden - 1) * hid * hid + hid * s)
     return 12 * a, flop  # bytes: the noise written once and read twice, fp32
 
 
@@ -91,7 +95,7 @@ def cpu_baseline(a, H, K, mlp, budget_s=12.0):
             "ms_per_step": 1e3 * el / n,
             "sample": "%d whole control steps of point_mass%dd%s K=%d H=%d (Philox noise + rollouts + update), "
                       "OpenMP over samples; the reference itself (TensorFlow) is not runnable here"
-                      % (n, a, "" if mlp is None else " + 2x256 MLP model", Kc, H)}
+                      % (n, a, "" if mlp is None else " + %dx%d MLP model" % (len(mlp["W"]) - 1, mlp["W"][0].shape[1]), Kc, H)}
 
 
 def sync_latency(m, a, H, K, mlp, steps=200, warmup=20):
@@ -164,8 +168,9 @@ class Runner:
     def run(self, workload, K, H, steps, warmup, min_time, **handle_kw):
         """-> dict of measurements of one workload (K rollouts per rank)"""
         from mppi_tf_amd.distributed import ExchangeTimeout, ShardedController
-        a, is_mlp = WORKLOADS[workload]
-        mlp = synthetic_mlp(a) if is_mlp else None
+        a, net = WORKLOADS[workload]
+        is_mlp = net is not None
+        mlp = synthetic_mlp(a, 0, *net) if is_mlp else None
         x = torch.zeros(2 * a, dtype=torch.float32, device=self.dev)
         ctl = ShardedController(device_index=self.local_rank, k=K * self.world, mlp=mlp, exchange=os.environ.get("MPPI_EXCHANGE", "auto"),
                                 p2p_timeout_ms=1000, **cfg_of(a, H), **handle_kw)
@@ -207,7 +212,7 @@ class Runner:
         torch.cuda.synchronize(self.dev)
         roll_ms, fin_ms, n_prof = h.profile_end()
         assert np.isfinite(ctl.u.cpu().numpy()).all()
-        bytes_ss, flop_ss = work_per_state_step(a, is_mlp)
+        bytes_ss, flop_ss = work_per_state_step(a, net)
         state_steps = K * H
         res = {"workload": workload, "K_per_gpu": K, "H": H, "a_dim": a, "steps": steps, "batches_s": batches,
                "rollouts_per_s": K * self.world * steps / el, "ms_per_step": 1e3 * el / steps,
@@ -219,13 +224,21 @@ class Runner:
 
 
 def roofline_of(r):
-    if r["workload"] == "mlp":
+    if r["workload"] in ("mlp", "mlp32"):
         tf = r["algorithmic_flop_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e12 if r["kernel_ms_avg"] > 0 else 0.0
+        note = ("exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-5-class parity target rules out plain bf16; weights stationary in "
+                "registers (a0-a255), activations in LDS. On gfx950 the f32-input MFMA runs at the f32 vector rate and does not "
+                "overlap with the vector ALU (tools/micro/mfma_f32_shadow.hip): the attainable rate is peak x MFMA cycles / "
+                "(MFMA + vector cycles) — the MFMAs alone measure 156 TFLOP/s (tools/micro/mlp2_bench.hip), layer 3, relu, the "
+                "state update and the layer-1 MFMAs are the rest")
+        if r["workload"] == "mlp32":
+            note = ("the reference's own network shape (Dense(32, relu) x3 + Dense(s), nn_model.py:54-60) on k_rollout_mlp_small: "
+                    "one rollout per lane, weights through the scalar cache into v_pk_fma_f32 — packed fp32 vector math has the "
+                    "f32 MFMA's rate on gfx950 (64 FLOP/clk/SIMD), so the same peak prices it")
         return {"bound": "mfma", "kernel": r["kernel"], "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "algorithmic_flop_per_launch": r["algorithmic_flop_per_launch"],
                 "kernel_ms_avg": r["kernel_ms_avg"], "finish_kernel_ms_avg": r["finish_kernel_ms_avg"], "launches_timed": r["launches_timed"],
-                "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-5-class parity target rules out plain bf16; "
-                        "weights stationary in registers, activations in LDS"}
+                "note": note}
     ach = r["algorithmic_bytes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e9 if r["kernel_ms_avg"] > 0 else 0.0
     tr, why = measured("traffic")
     traffic = tr.get("hbm_bytes_per_launch") if tr and tr.get("kernel") == r["kernel"] else None
@@ -276,7 +289,8 @@ def main():
     import mppi_tf_amd as m
 
     headline = args.workload or "pm3d"
-    a, is_mlp = WORKLOADS[headline]
+    a, net = WORKLOADS[headline]
+    is_mlp = net is not None
     H = args.horizon or (32 if headline == "pm1d" else 64)
     K = args.samples or {"pm1d": 128, "pm2d": 4096}.get(headline, 65536)
     steps = args.steps if args.steps is not None else (20 if is_mlp else 200)
@@ -289,6 +303,7 @@ def main():
         subs.append(rn.run("pm2d", 4096, 64, steps, args.warmup, args.min_time))
         subs.append(rn.run("mlp", 65536, 64, 20, 3, 0.0))
         subs.append(rn.run("mlp", 65536, 64, 20, 3, 0.0, mlp_bf16x3=True))
+        subs.append(rn.run("mlp32", 65536, 64, 50, 5, 0.0))
 
     if rank == 0:
         cfg = cfg_of(a, H)
@@ -303,7 +318,7 @@ def main():
             "batches": {"n": len(r["batches_s"]), "steps_each": r["steps"], "seconds": r["batches_s"],
                         "what": "value = K*N*steps / median batch; every batch is bracketed by barrier + synchronize, max over ranks"},
             "config": {"workload": "point_mass%dd %s, K=%d H=%d per GPU (%s), on-device Philox noise, device-resident x/U"
-                                   % (a, "learned 2x256 MLP model_base" if is_mlp else "analytic model", K, H, name),
+                                   % (a, ("learned %dx%d MLP model_base" % (net[1], net[0])) if is_mlp else "analytic model", K, H, name),
                        "K_global": K * world, "K_per_gpu": K, "H": H, "s_dim": 2 * a, "a_dim": a,
                        "lambda": 1.0, "sigma": "0.25*I", "dt": 0.1, "mass": 1.0,
                        "parallelism": "K-shard x%d, %s" % (world, {
@@ -317,7 +332,8 @@ def main():
         }
         if subs:
             def sub(s):
-                d = {"config": CONFIG_NAME.get((s["workload"], s["K_per_gpu"], s["H"], 1), "") + (" + MPPI_FLAG_MLP_BF16X3" if "bx3" in s["kernel"] else ""),
+                d = {"config": CONFIG_NAME.get((s["workload"], s["K_per_gpu"], s["H"], 1), "the reference's Dense(32) x3 network (nn_model.py:54-60), not a BASELINE configuration"
+                                               if s["workload"] == "mlp32" else "") + (" + MPPI_FLAG_MLP_BF16X3" if "bx3" in s["kernel"] else ""),
                      "workload": s["workload"], "K": s["K_per_gpu"], "H": s["H"], "value": s["rollouts_per_s"], "unit": "rollouts/s",
                      "ms_per_step": s["ms_per_step"], "steps": s["steps"], "batches": len(s["batches_s"]), "roofline": roofline_of(s)}
                 if "bx3" in s["kernel"]:  # the matrix cores execute 3 bf16 products per fp32 term
