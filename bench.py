@@ -257,6 +257,11 @@ def roofline_of(r):
 
 
 def main():
+    # Only the JSON line may reach stdout: native libraries print there too (RCCL's version banner when the first
+    # communicator comes up), so fd 1 points at stderr for the whole run and the line is written to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="K steps per timed batch (default 200; 20 for the MLP workload, ~5 ms per step)")
@@ -350,7 +355,8 @@ def main():
                                                "what": "host-synchronous mppi_next(x)->u incl. H2D x, D2H u, closed-loop steps"}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(a, H, K, r["mlp"])
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -27,6 +27,8 @@ struct mppi_handle {
     int H = 0, s = 0, a = 0, HA = 0;
     int R = 64, nb = 0;   // tile size / record count of the point-mass tile kernels
     int nb_mlp = 0;       // record count of the MLP rollout kernel (64 rollouts per workgroup)
+    int nbp = 0;          // record slots in d_part: record_pad(max(nb, nb_mlp)), the column stride of every rollout launch
+    int part_nb = 0;      // tile count whose slots currently hold records (0: all slots neutral)
     int mlp_bx3 = 0;      // MPPI_FLAG_MLP_BF16X3: split-bf16 matrix-core variant of the MLP rollout
     int mlp_small = 0;    // hidden width (16 or 32) of a small learned model served by k_rollout_mlp_small, else 0
     MlpSmallArgs small_args{};
@@ -346,8 +348,11 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         HIP_TRY(h, hipMalloc((void **)&h->d_u, sizeof(float) * kMaxA));
         HIP_TRY(h, hipMalloc((void **)&h->d_cost, sizeof(float) * h->K_local));
         HIP_TRY(h, hipMalloc((void **)&h->d_cost2, sizeof(float) * h->K_local));
-        const int nrec = std::max(h->nb, h->nb_mlp);
+        const int nrec = h->nbp = record_pad(std::max(h->nb, h->nb_mlp));
         HIP_TRY(h, hipMalloc((void **)&h->d_part, sizeof(float) * (size_t)nrec * (2 + h->HA)));
+        hipLaunchKernelGGL(k_fill_records, dim3((nrec * (2 + h->HA) + 255) / 256), dim3(256), 0, h->stream, h->d_part, nrec, 2 + h->HA);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamSynchronize(h->stream)); // steps may be enqueued on the caller's stream
         const int nrec2 = (nrec + kGroup - 1) / kGroup, nrec3 = (nrec2 + kGroup - 1) / kGroup;
         HIP_TRY(h, hipMalloc((void **)&h->d_part2, sizeof(float) * (size_t)nrec2 * (2 + h->HA)));
         HIP_TRY(h, hipMalloc((void **)&h->d_part3, sizeof(float) * (size_t)nrec3 * (2 + h->HA)));
@@ -409,7 +414,7 @@ static hipError_t launch_tile_inst(mppi_handle *h, hipStream_t st, const float *
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tile_lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(h->nb), dim3(kThreads), h->tile_lds, st, h->dC, x_dev, U_dev, eps, h->d_step, cost, part, noise_out, 1, h->nb);
+    hipLaunchKernelGGL(kern, dim3(h->nb), dim3(kThreads), h->tile_lds, st, h->dC, x_dev, U_dev, eps, h->d_step, cost, part, noise_out, 1, h->nbp);
     return hipGetLastError();
 }
 
@@ -471,8 +476,8 @@ static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_
     const DevConsts *dC = h->dC;
     const float *U = h->U_cur();
     const unsigned long long *stp = h->d_step;
-    if (h->sigma_diag) hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, nb, balance);
-    else hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, nb, balance);
+    if (h->sigma_diag) hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
+    else hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
     return hipGetLastError();
 }
 
@@ -512,10 +517,10 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
         const dim3 gs(h->nb_mlp), bs(64);
         if (h->mlp_small == 16)
             hipExtLaunchKernelGGL((k_rollout_mlp_small<A, 16>), gs, bs, 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, h->small_args,
-                                  x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp);
+                                  x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);
         else
             hipExtLaunchKernelGGL((k_rollout_mlp_small<A, 32>), gs, bs, 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, h->small_args,
-                                  x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp);
+                                  x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);
         return hipGetLastError();
     }
 #define MPPI_MLP_L(KERN, BIT)                                                                                           \
@@ -527,7 +532,7 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
             h->attr_done |= BIT;                                                                                        \
         }                                                                                                               \
         hipExtLaunchKernelGGL(kern, g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, x_dev, U_dev, eps, \
-                              (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nb_mlp);                \
+                              (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);                \
     } while (0)
     if (h->mlp_bx3) {
         if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp_bx3<A, true>), 8);
@@ -543,7 +548,7 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
             h->attr_done |= BIT;                                                                                        \
         }                                                                                                               \
         hipExtLaunchKernelGGL(kern, g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, x_dev, U_dev, eps, \
-                              (const unsigned long long *)h->d_step, cost, h->d_part, mode, 1, h->nb_mlp);                     \
+                              (const unsigned long long *)h->d_step, cost, h->d_part, mode, 1, h->nbp);                     \
     } while (0)
             if (src == SRC_PHILOX) {
                 if (h->sigma_diag) MPPI_MLP2_L((k_rollout_mlp2<A, true, SRC_PHILOX>), 32);
@@ -710,11 +715,23 @@ extern "C" mppi_status mppi_set_sequence_filter(mppi_handle *h, int window, int 
     return MPPI_OK;
 }
 
+// The slots of d_part that hold records belong to ONE tile count at a time (the MLP kernels and the tile kernel of the same
+// handle may cut K differently): when the count changes, every slot goes back to the neutral record first.
+static hipError_t ensure_record_layout(mppi_handle *h, hipStream_t st, int n_tiles)
+{
+    if (h->part_nb == n_tiles) return hipSuccess;
+    if (h->part_nb != 0)
+        hipLaunchKernelGGL(k_fill_records, dim3((h->nbp * (2 + h->HA) + 255) / 256), dim3(256), 0, st, h->d_part, h->nbp, 2 + h->HA);
+    h->part_nb = n_tiles;
+    return hipGetLastError();
+}
+
 // rollouts of this shard -> partial records in d_part; *nrec = how many. Handles normalizeCost.
 static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, const float *x_dev, const float *eps, float *noise_out, int *nrec)
 {
     const bool mlp = h->hc.model_kind == MPPI_MODEL_MLP;
-    *nrec = mlp ? h->nb_mlp : h->nb;
+    *nrec = h->nbp; // every slot: those no tile owns hold neutral records
+    HIP_TRY(h, ensure_record_layout(h, st, (mlp && !h->normalize) ? h->nb_mlp : h->nb)); // (normalizeCost: the tile kernel writes the records)
     if (!h->normalize) {
         const bool prof = h->prof_n < h->prof_cap;
         const bool pc = !mlp && src == SRC_PHILOX && noise_out == nullptr && pc_eligible(h);
@@ -743,7 +760,7 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
     hipLaunchKernelGGL(k_cost_normalize, dim3((h->K_local + 255) / 256), dim3(256), 0, st, h->d_cost, h->K_local, h->d_mm, h->d_cost2);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, launch_tile(h, st, src, MODE_COSTS_GIVEN, x_dev, h->U_cur(), eps, h->d_cost2, h->d_part, nullptr));
-    *nrec = h->nb;
+    *nrec = h->nbp;
     return MPPI_OK;
 }
 
@@ -1365,11 +1382,12 @@ extern "C" mppi_status mppi_update(mppi_handle *h, const float *cost, const floa
     HIP_TRY(h, darg.alloc(K)); HIP_TRY(h, dexp.alloc(K)); HIP_TRY(h, dw.alloc(K)); HIP_TRY(h, dUn.alloc(HA)); HIP_TRY(h, du.alloc(kMaxA));
     HIP_TRY(h, dU.up(U, HA, h->stream)); HIP_TRY(h, dc.up(cost, K, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_eps, eps, sizeof(float) * (size_t)K * HA, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, ensure_record_layout(h, h->stream, h->nb));
     HIP_TRY(h, launch_tile(h, h->stream, SRC_HBM, MODE_COSTS_GIVEN, h->d_x, dU.p, h->d_eps, dc.p, h->d_part, nullptr));
     // record = (beta, eta, V); then U' on a scratch copy of U (apply shifts it, so read U_updated)
     unsigned long long step_before = 0;
     HIP_TRY(h, hipMemcpyAsync(&step_before, h->d_step, sizeof(step_before), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, 1, h->nb, h->nb, dU.p, dUn.p, du.p, drec.p, 1));
+    HIP_TRY(h, launch_finish(h, h->stream, h->d_part, 1, h->nbp, h->nbp, dU.p, dUn.p, du.p, drec.p, 1));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_step, &step_before, sizeof(step_before), hipMemcpyHostToDevice, h->stream)); // stateless call
     hipLaunchKernelGGL(k_weights, dim3((K + 255) / 256), dim3(256), 0, h->stream, h->dC, dc.p, K, drec.p, darg.p, dexp.p, dw.p);

@@ -59,6 +59,16 @@ struct DevConsts {
 // of just the fields a wave needs (PcProducerConsts / PcConsumerConsts). A barrier is a memory fence, so constants read
 // through a global pointer are re-fetched (s_load + s_waitcnt) after every __syncthreads; a local copy made before the
 // first barrier lives in SGPRs for the whole kernel. Same field names and indexing, same arithmetic.
+// Where tile b keeps its record. Records are column-major [2 + H*a][nbp] (the finish kernel reads whole columns), so
+// a tile's 2 + H*a values are scattered dwords, one per column. Workgroups go to the 8 XCDs round-robin and every XCD
+// has its own write-back L2: with slot = (b mod 8) * nbp/8 + b / 8 the 16 floats of a 64-byte line belong to 16 tiles
+// of the SAME XCD, whose L2 merges them into one line write (r02: WRITE_SIZE of k_rollout_pc at C3 6.3 MB -> see
+// DESIGN §3.3). nbp = the record count padded to a multiple of 128 (16 per line x 8 XCDs); slots no tile owns hold a
+// neutral record (beta = kPadBeta, eta = 0, V = 0: weight exp(-(kPadBeta - beta)/lambda) = 0) written once at create.
+constexpr float kPadBeta = 3.0e38f; // finite: a group of pads alone combines to (kPadBeta, 0, 0), not to NaN
+__host__ __device__ inline int record_pad(int n) { return (n + 127) & ~127; }
+__host__ __device__ inline int record_slot(int b, int nbp) { return (b & 7) * (nbp >> 3) + (b >> 3); }
+
 template <int A>
 struct PcProducerConsts {
     int action_cost_kind;

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
 
     // ---- phase C: V_b[c] = Σ_k e_k·eps[k,c] in fixed k order (mWeightedNoise, :188-192) -----
     // record element (b, col) lives at partials[b*rsb + col*rsc]: column-major (rsb = 1) for the finish kernel
-    float *rec = partials + (size_t)blockIdx.x * rsb;
+    float *rec = partials + (size_t)record_slot(blockIdx.x, rsc) * rsb;
     if (tid == 0) { rec[0] = red_s[0]; rec[(size_t)rsc] = red_s[1]; }
 #if defined(MPPI_ABLATE_WSUM) // timing-only build: no weighted-noise sum
     for (int c = tid; c < 1; c += kThreads) {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
     const int lane = tid & 63;
     const int k0 = blockIdx.x * 64;
     const bool valid = (k0 + lane) < K;
-    float *rec = partials + (size_t)blockIdx.x * rsb; // element (b, col) at partials[b*rsb + col*rsc]
+    float *rec = partials + (size_t)record_slot(blockIdx.x, rsc) * rsb; // element (b, col) at partials[b*rsb + col*rsc]
 #if defined(MPPI_PC_TIMELINE)
     if (lane == 0) { // where this wave runs: HW_ID[15:0] (wave, simd, pipe, cu, sh, se) and XCC_ID[3:0]; role in slot
         tl_s[48 + wave] = (float)(__builtin_amdgcn_s_getreg((15 << 11) | 4) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16));
@@ -447,6 +447,13 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
 // in fixed b order. A single-workgroup combine of ~1000 tile records is a chain of ~200
 // dependent L2 round trips per thread (measured 76 µs at K=65536); this level runs on
 // ceil(nb/kGroup) CUs with kGroup independent loads in flight per thread instead.
+// neutral records in every slot (see record_slot): launched at create and when a handle changes its record count
+__global__ void k_fill_records(float *__restrict__ recs, int nbp, int ncol)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nbp * ncol) recs[i] = i < nbp ? kPadBeta : 0.0f;
+}
+
 constexpr int kGroup = 16;
 // Scalars arrive as kernel arguments (SGPRs at wave start) rather than through DevConsts: these
 // kernels are a chain of dependent memory round trips, and every hop removed is ~0.5-1 µs.
@@ -1013,7 +1020,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
     if (MODE == MODE_COST_ONLY) return;
 
     mlp_tile_record<A, DIAG>(C, c, valid, w, lane, kk, H, NG, SRC, eps_hbm, seed, gk, base,
-                             partials + (size_t)blockIdx.x * rsb, rsc); // element (b, col) at partials[b*rsb + col*rsc]
+                             partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc); // element (b, col) at partials[b*rsb + col*rsc]
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1301,7 +1308,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
     if (MODE == MODE_COST_ONLY) return;
 
     mlp_tile_record<A, DIAG>(C, c, valid, w, lane, kk, H, NG, SRC, eps_hbm, seed, gk, base,
-                             partials + (size_t)blockIdx.x * rsb, rsc); // element (b, col) at partials[b*rsb + col*rsc]
+                             partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc); // element (b, col) at partials[b*rsb + col*rsc]
 }
 
 } // namespace mppi

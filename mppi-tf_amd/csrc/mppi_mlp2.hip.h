@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
     if (w == 0 && valid) cost[k0 + lane] = c;
     if (MODE == MODE_COST_ONLY) continue;
     mlp_tile_record<A, DIAG, 4>(C, c, valid, w, lane, kk, H, NG, SRC, eps_hbm, seed, koff + (unsigned long long)kk, base,
-                                partials + (size_t)tile * rsb, rsc); // element (b, col) at partials[b*rsb + col*rsc]
+                                partials + (size_t)record_slot(tile, rsc) * rsb, rsc); // element (b, col) at partials[b*rsb + col*rsc]
     } // tiles
 }
 

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void k_rollout_mlp_small(
     if (valid) cost[k0 + lane] = c;
     if (MODE == MODE_COST_ONLY) return;
     mlp_tile_record<A, DIAG, 1>(C, c, valid, 0, lane, kk, H, NG, SRC, eps_hbm, seed, gk, base,
-                                partials + (size_t)blockIdx.x * rsb, rsc);
+                                partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc);
 }
 
 } // namespace mppi
