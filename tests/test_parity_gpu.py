@@ -266,6 +266,8 @@ DENSE_SIGMA3 = np.array([[0.3, 0.05, 0.0], [0.02, 0.2, -0.04], [0.0, 0.03, 0.25]
     (300, 130, 4, None), (64, 3, 2, None),
     (40000, 20, 3, None),          # 513..1024 tiles: 3 producers, SIMD-true roles + progress priorities
     (70000, 16, 3, None),          # > 1024 tiles: several rounds, roles by wave index, no priorities
+    (65600, 8, 3, None),           # 1025 tiles in 1152 record slots: every XCD class ends in a 16:1 fold group of neutral records only
+    (90, 12, 2, None),             # 2 tiles in 128 record slots
     (5000, 24, 3, DENSE_SIGMA3),   # dense Σ: the non-diagonal instances
 ])
 def test_producer_consumer_kernel_equals_tile_kernel(m, K, H, a, sigma):
