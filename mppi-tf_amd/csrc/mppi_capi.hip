@@ -553,9 +553,8 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
             if (src == SRC_PHILOX) {
                 if (h->sigma_diag) MPPI_MLP2_L((k_rollout_mlp2<A, true, SRC_PHILOX>), 32);
                 else MPPI_MLP2_L((k_rollout_mlp2<A, false, SRC_PHILOX>), 64);
-            } else if (src == SRC_HBM) {
-                if (h->sigma_diag) MPPI_MLP2_L((k_rollout_mlp2<A, true, SRC_HBM>), 128);
-                else MPPI_MLP2_L((k_rollout_mlp2<A, false, SRC_HBM>), 256);
+            } else if (src == SRC_HBM) { // injected noise (API helpers, tests): one instance, the dense-Sigma arithmetic
+                MPPI_MLP2_L((k_rollout_mlp2<A, false, SRC_HBM>), 256); // (exact for a diagonal Sigma too: it adds 0 * z terms)
             } else return hipErrorInvalidValue;
 #undef MPPI_MLP2_L
         } else return hipErrorInvalidValue;

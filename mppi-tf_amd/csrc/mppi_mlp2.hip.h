@@ -9,8 +9,9 @@
 // this path is (MFMA cycles + vector cycles), not the MFMA peak alone, and the design minimises vector instructions and
 // excursions instead of trying to hide them:
 //   * ONE wave per SIMD (4 waves, 256 threads, the unified 512-entry register file): wave w owns hidden units
-//     [64w, 64w+64) of both layers = two 32-row M-tiles = 2 x 129 stationary W2 registers, pinned to the accumulator
-//     half (a0-a255) through inline-asm MFMAs — hipcc left alone keeps them in v0-v255 and spills;
+//     [64w, 64w+64) of both layers = two 32-row M-tiles = 2 x 128 stationary W2 registers = exactly the accumulator
+//     half (a0-a255), pinned there through inline-asm MFMAs — hipcc left alone keeps them in v0-v255 and spills; the
+//     layer-2 bias is the accumulators' initial value (8 LDS reads per set and step) instead of a 129th k pair;
 //   * TWO sets of 32 rollouts (one 32-column MFMA tile each: 2 x 16 accumulator registers per set), each with its own
 //     h1 image in LDS (2 x 32 KB), software-pipelined against each other: while the 258 layer-2 MFMAs of one set
 //     stream, the other set's step is finished and its next one prepared in ~13 LUMPS of vector work (8 of layer 3 at
@@ -24,7 +25,7 @@
 // History (r02, K=65536 H=64, fp32 peak 157.3): k_rollout_mlp 122 TFLOP/s (0.77; 8 waves in lock-step phases) -> this
 // design with 64-rollout sets 108 (weight spills) -> 32-rollout sets, work spread one piece per MFMA "to hide it" 120
 // (the opposite of what the hardware wants: 258 excursions) -> lumps 131 -> waits/requests out of the lumps 135 ->
-// one-statement swaps, 4-register lumps 137-138. Measured floor of the MFMAs alone: 156 (tools/micro/mlp2_bench.hip,
+// one-statement swaps, 4-register lumps 137-138 -> bias as accumulator init 141 (harness; 143 in bench.py's timing). Measured floor of the MFMAs alone: 156 (tools/micro/mlp2_bench.hip,
 // ablation 2047).
 // Arithmetic is k_rollout_mlp's up to the reciprocal (multiplication by 1/sigma; v_mfma_f32_32x32x2_f32 = a k-ordered
 // fmaf chain; the cross-wave sum of layer 3 has 4 terms instead of 8): the parity tests hold it to the same bars.
@@ -63,7 +64,7 @@ constexpr int kMlp2R = 64; // rollouts per workgroup: two sets of 32
 __host__ __device__ inline size_t mlp2_lds_floats(int S, int A, int H)
 {
     return (size_t)2 * kHid * 32 + 2 * 4 * S * 32 + kHid * 8 + 2 * 2 * 4 * A * 32 + (size_t)((S + A + 2) / 2 * 2) * kHid +
-           (size_t)(H * A + 3) / 4 * 4 + 64;
+           (size_t)(H * A + 3) / 4 * 4 + kHid + 64;
 }
 
 // lanes 32-63 of a <-> lanes 0-31 of b (v_permlane32_swap; asm: see the transposing butterfly in mppi_device.hip.h)
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 2 * A, NIN = S + A;
     constexpr int K1 = (NIN + 2) / 2 * 2; // inputs + bias, padded to the MFMA's k pairs (10 for s=6, a=3)
-    constexpr int NKP = kHid / 2 + 1;     // k pairs of layer 2, the last one carries the bias against a row of ones
+    constexpr int NKP = kHid / 2;         // k pairs of layer 2 (its bias is the accumulators' initial value, read from LDS)
     constexpr int R = 32;                 // rollouts of a set = columns of one MFMA tile
     const int H = C->H, HA = H * A, K = C->K_local;
     const int NG = (H + 3) / 4;
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
     float *w3_s = y_s + 2 * 4 * S * R;         // [kHid][8]: rows padded to two 16-byte reads
     float *z_s = w3_s + kHid * 8;              // [2 sets][2 buffers][4*A][R] standard normals of a horizon group
     float *w1_s = z_s + 2 * 2 * 4 * A * R;     // [K1][kHid]: W1, the b1 row, zero padding
-    float *u_s = w1_s + K1 * kHid;             // [H*A] the nominal controls (LDS, not s_load: a scalar load's return
+    float *b2_s = w1_s + K1 * kHid;            // [kHid] layer-2 bias
+    float *u_s = b2_s + kHid;                  // [H*A] the nominal controls (LDS, not s_load: a scalar load's return
                                                // is waited for with lgkmcnt(0), which would drain the B-operand reads)
 
     const int tid = threadIdx.x;
@@ -110,7 +112,6 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
         const int unit = 64 * w + 32 * mt + j;
 #pragma unroll
         for (int s2 = 0; s2 < kHid / 2; ++s2) a2[mt][s2] = M->W2[(size_t)(2 * s2 + hh) * kHid + unit];
-        a2[mt][kHid / 2] = hh == 0 ? M->b2[unit] : 0.0f;
     }
     for (int i = tid; i < K1 * kHid; i += kMlp2Threads) {
         const int kin = i / kHid, unit = i % kHid;
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
     static_assert(S <= 8, "W3 rows are staged as 8 floats");
     for (int i = tid; i < kHid * 8; i += kMlp2Threads) w3_s[i] = (i & 7) < S ? M->W3[(i >> 3) * S + (i & 7)] : 0.0f;
     for (int i = tid; i < HA; i += kMlp2Threads) u_s[i] = U_dev[i];
+    for (int i = tid; i < kHid; i += kMlp2Threads) b2_s[i] = M->b2[i];
 
     // wave-uniform constants, read once (a barrier would otherwise force a re-fetch per step)
     float xm[NIN], xr[NIN], b3v[S], ysd[S], ymn[S];
@@ -156,8 +158,9 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
     int y_rd0 = (int)(y_s - smem) + 2 * j;
     int z_rd0 = (int)(z_s - smem) + j;
     int b_rd0 = hh * R + j;
+    int b2_rd0 = (int)(b2_s - smem) + 64 * w + 4 * hh;
     asm volatile("" : "+v"(img_row0[0]), "+v"(img_row0[1]), "+v"(w3_row0), "+v"(w1_row0), "+v"(y_wr0[0]), "+v"(y_wr0[1]),
-                 "+v"(y_rd0), "+v"(z_rd0), "+v"(b_rd0));
+                 "+v"(y_rd0), "+v"(z_rd0), "+v"(b_rd0), "+v"(b2_rd0));
     constexpr auto crow_of = [](int pi) { return 32 * (pi >> 4) + (pi & 3) + 8 * ((pi & 15) >> 2); };
 
     // One v_mfma_f32_32x32x2_f32 with the stationary weight pinned to the accumulator half of the register file ("a"):
@@ -386,6 +389,14 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
 #pragma unroll
         for (int pi = pi0; pi < pi0 + 2; ++pi) smem[img_row0[q] + crow_of(pi) * R] = acc[pi >> 4][pi & 15];
     };
+    // layer 2's bias as the initial value of the set's accumulators (accumulator register r of M-tile mt is row
+    // 32 mt + 8 (r >> 2) + 4 hh + (r & 3) of the wave's 64: four consecutive rows per 16-byte read), piece i of 8
+    auto acc_init = [&](auto qc, auto ic) {
+        constexpr int q = decltype(qc)::value, i = decltype(ic)::value, mt = i >> 2, g4 = i & 3;
+        f32x16 (&acc)[2] = q ? accB : accA;
+        const f32x4 b4 = lds4(b2_rd0 + 32 * mt + 8 * g4);
+        acc[mt][4 * g4 + 0] = b4.x; acc[mt][4 * g4 + 1] = b4.y; acc[mt][4 * g4 + 2] = b4.z; acc[mt][4 * g4 + 3] = b4.w;
+    };
     // The standard normals of horizon group gn for BOTH sets -> buffer gn & 1. One Philox block (4 normals: one action
     // dimension of the group's 4 steps) per lane: unit 2 * wave + hh is block (set, q) = (unit / A, unit % A), so 2 A of
     // the workgroup's 8 half-waves do ~140 vector instructions each instead of one wave doing 4 A blocks in a row.
@@ -414,7 +425,8 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
     constexpr int KP_RELU = KP_L1 + 2;         // relu; the 32 image writes follow, two per k pair
     constexpr int KP_BAR2 = KP_RELU + 19;
     constexpr int KP_NOISE = KP_BAR2 + 1;
-    static_assert(KP_A1 + K1 <= KP_FIN && KP_NOISE < NKP - 8, "the schedule of a half-step");
+    constexpr int KP_ACC = KP_BAR2 + 2;        // 8 requests: layer-2 bias into the set's accumulators for its next half-step
+    static_assert(KP_A1 + K1 <= KP_FIN && KP_ACC + 8 < NKP - 8, "the schedule of a half-step");
     auto half_step = [&](auto Qc, auto finc, auto prepc, int t_prep) {
         constexpr int Q = decltype(Qc)::value, O = 1 - Q;
         constexpr bool do_fin = decltype(finc)::value && !(MPPI_MLP2_ABL & 1), do_prep = decltype(prepc)::value && !(MPPI_MLP2_ABL & 2);
@@ -429,17 +441,15 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
 #endif
         static_for<0, NKP>([&](auto kpc) {
             constexpr int kp = decltype(kpc)::value;
-            float b;
-            if constexpr (kp < kHid / 2) b = bq[kp % 4];
-            else b = hh == 0 ? 1.0f : 0.0f; // the bias pair: a row of ones against b2
+            const float b = bq[kp % 4];
             if constexpr (do_fin && kp >= KP_L3 && kp < KP_L3 + 32 && ((kp - KP_L3) & 3) == 0) l3_arrived(integral_constant<int, kp - KP_L3>{}, g);
             if constexpr (kp == KP_FIN) {
                 if constexpr (do_fin) fin_arrived(g);
                 if constexpr (do_prep) prep_arrived(g);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfma_acc(acc[0], a2[0][kp], b, integral_constant<bool, (kp < kHid / 2)>{}, integral_constant<bool, kp == 0>{});
-            mfma_acc(acc[1], a2[1][kp], b, integral_constant<bool, (kp < kHid / 2)>{}, integral_constant<bool, kp == 0>{});
+            mfma_acc(acc[0], a2[0][kp], b, yes, no); // (k pair 0 accumulates on the bias: acc_init)
+            mfma_acc(acc[1], a2[1][kp], b, yes, no);
             __builtin_amdgcn_sched_barrier(0); // keep what follows in one piece, behind the MFMAs
             // ---- LDS requests: a few per k pair, and in FRONT of the lump — there they issue while the second MFMA
             // runs; behind the lump each would hold the next MFMA back by its issue slot
@@ -450,6 +460,7 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
                 if constexpr (do_prep && kp >= KP_A1 && kp < KP_A1 + K1) a1_request(integral_constant<int, kp - KP_A1>{}, g);
                 if constexpr (do_prep && kp == KP_FIN - 2) prep_request(Oc, t_prep, g);
                 if constexpr (do_prep && kp > KP_RELU && kp <= KP_RELU + 16 && !(MPPI_MLP2_ABL & 2048)) image_store(Oc, integral_constant<int, 2 * (kp - KP_RELU - 1)>{});
+                if constexpr (do_prep && kp >= KP_ACC && kp < KP_ACC + 8) acc_init(Oc, integral_constant<int, kp - KP_ACC>{}); // its image is written: the registers are free
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- vector lumps
@@ -513,6 +524,7 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(accA[0]), "+v"(accA[1])); // MFMA D -> VALU reader: 16 passes + 2
         relu_lump(c0);
         static_for<0, 16>([&](auto ic) { image_store(c0, integral_constant<int, 2 * decltype(ic)::value>{}); });
+        static_for<0, 8>([&](auto ic) { acc_init(c0, ic); });
     }
     __syncthreads();
     {
