@@ -235,8 +235,14 @@ def roofline_of(r):
             note = ("the reference's own network shape (Dense(32, relu) x3 + Dense(s), nn_model.py:54-60) on k_rollout_mlp_small: "
                     "one rollout per lane, weights through the scalar cache into v_pk_fma_f32 — packed fp32 vector math has the "
                     "f32 MFMA's rate on gfx950 (64 FLOP/clk/SIMD), so the same peak prices it")
+        mf, why = measured("mfma")  # PMC passes of tools/collect_profiles.sh <tag> mlp, tagged with the kernel sources' hash
+        ok = mf is not None and mf.get("kernel") == r["kernel"]
         return {"bound": "mfma", "kernel": r["kernel"], "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "algorithmic_flop_per_launch": r["algorithmic_flop_per_launch"],
+                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": mf.get("hbm_bytes_per_launch") if ok else None,
+                "mfma_busy_frac": mf.get("mfma_busy_frac") if ok else None,
+                "other_vector_insts_per_launch": mf.get("other_vector_insts_per_launch") if ok else None,
+                "pmc_note": None if ok else (why or "profiles/mfma_latest.json describes another kernel instance"),
+                "algorithmic_flop_per_launch": r["algorithmic_flop_per_launch"],
                 "kernel_ms_avg": r["kernel_ms_avg"], "finish_kernel_ms_avg": r["finish_kernel_ms_avg"], "launches_timed": r["launches_timed"],
                 "note": note}
     ach = r["algorithmic_bytes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e9 if r["kernel_ms_avg"] > 0 else 0.0

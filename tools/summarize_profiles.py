@@ -80,6 +80,17 @@ if dominant and "k_rollout_pc" in dominant and "SQ_INSTS_VALU_MUL_F32" in summar
                        "they issue at ~4.2 cycles: the floor is a lower bound"}
     out["valu"] = valu
     json.dump(valu, open(os.path.join(dst, "valu_latest.json"), "w"), indent=1)
+if dominant and "k_rollout_mlp" in dominant and "SQ_VALU_MFMA_BUSY_CYCLES" in summary[dominant] and "GRBM_GUI_ACTIVE" in summary[dominant]:
+    k = summary[dominant]  # the MLP path: how busy the matrix pipe was, and what shared the vector pipe with it
+    mfma = {"kernel": kname, "code_sha": code_sha,
+            "mfma_busy_frac": k["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (k["GRBM_GUI_ACTIVE"] / 8.0),
+            "mfma_insts_per_launch": k.get("SQ_INSTS_MFMA"),
+            "other_vector_insts_per_launch": (k["SQ_INSTS_VALU"] - k["SQ_INSTS_MFMA"]) if "SQ_INSTS_VALU" in k and "SQ_INSTS_MFMA" in k else None,
+            "hbm_bytes_per_launch": out.get("traffic", {}).get("hbm_bytes_per_launch"),
+            "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (summed over SIMDs / XCDs), SQ_INSTS_*; FETCH_SIZE / "
+                      "WRITE_SIZE; separate passes, tag " + tag}
+    out["mfma"] = mfma
+    json.dump(mfma, open(os.path.join(dst, "mfma_latest.json"), "w"), indent=1)
 b = os.path.join(src, "bench_under_profiler.json")
 if os.path.exists(b) and os.path.getsize(b):
     out["bench_line_under_profiler"] = json.loads(open(b).read())
