@@ -232,9 +232,10 @@ def roofline_of(r):
                 "(MFMA + vector cycles) — the MFMAs alone measure 156 TFLOP/s (tools/micro/mlp2_bench.hip), layer 3, relu, the "
                 "state update and the layer-1 MFMAs are the rest")
         if r["workload"] == "mlp32":
-            note = ("the reference's own network shape (Dense(32, relu) x3 + Dense(s), nn_model.py:54-60) on k_rollout_mlp_small: "
-                    "one rollout per lane, weights through the scalar cache into v_pk_fma_f32 — packed fp32 vector math has the "
-                    "f32 MFMA's rate on gfx950 (64 FLOP/clk/SIMD), so the same peak prices it")
+            note = ("the reference's own network shape (Dense(32, relu) x3 + Dense(s), nn_model.py:54-60) on k_rollout_mlp32: a 32-wide "
+                    "layer is one v_mfma_f32_32x32x2_f32 tile and the accumulator layout of one layer is the B-operand layout of the "
+                    "next, so the layers chain through registers (weights and biases stationary, no LDS, no barrier); 2 waves x 32 "
+                    "rollouts per tile, the output layer on the vector ALU")
         mf, why = measured("mfma")  # PMC passes of tools/collect_profiles.sh <tag> mlp, tagged with the kernel sources' hash
         ok = mf is not None and mf.get("kernel") == r["kernel"]
         return {"bound": "mfma", "kernel": r["kernel"], "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",

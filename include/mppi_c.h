@@ -271,7 +271,8 @@ enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instea
        MPPI_TUNE_PC_LDS_MIN = 3,        /* pad the rollout kernel's LDS to this many bytes (caps workgroups per CU)     */
        MPPI_TUNE_SYNC_SPIN = 4,         /* 0: mppi_next waits for the stream instead of watching the pinned u slot      */
        MPPI_TUNE_P2P_FAULT = 5,         /* 1: inbox export fails, 2: probe reports failure (exercise the RCCL fallback) */
-       MPPI_TUNE_MLP_V1 = 6 };          /* 1: exact-fp32 MLP rollouts on the first kernel (8 waves per workgroup) instead of k_rollout_mlp2 */
+       MPPI_TUNE_MLP_V1 = 6,            /* 1: exact-fp32 MLP rollouts on the first kernel (8 waves per workgroup) instead of k_rollout_mlp2 */
+       MPPI_TUNE_MLP32_VALU = 7 };      /* 1: a Dense(32) network on k_rollout_mlp_small (vector ALU, scalar-cache weights) instead of k_rollout_mlp32 (matrix cores) */
 mppi_status mppi_set_tuning(mppi_handle *h, int what, int value);
 
 /* ---- measurement (the reference only has a commented-out chrono loop, main.cpp:55-64) ------ */

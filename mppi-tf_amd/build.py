@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libmppi_hip.so")
 SOURCES = ["mppi_capi.hip"]
-HEADERS = ["mppi_device.hip.h", "mppi_kernels.hip.h", "mppi_mlp2.hip.h", "mppi_mlp_small.hip.h"]
+HEADERS = ["mppi_device.hip.h", "mppi_kernels.hip.h", "mppi_mlp2.hip.h", "mppi_mlp_small.hip.h", "mppi_mlp32.hip.h"]
 ARCH = "gfx950"
 
 

@@ -32,6 +32,7 @@ struct mppi_handle {
     int mlp_bx3 = 0;      // MPPI_FLAG_MLP_BF16X3: split-bf16 matrix-core variant of the MLP rollout
     int mlp_small = 0;    // hidden width (16 or 32) of a small learned model served by k_rollout_mlp_small, else 0
     MlpSmallArgs small_args{};
+    int mlp32_valu = 0;   // tuning: a Dense(32) network on k_rollout_mlp_small instead of k_rollout_mlp32
     int n_cu = 256;       // compute units of the device (k_rollout_mlp2 runs one tile-walking workgroup per CU)
     int mlp_v2 = 0;       // exact-fp32 MLP rollouts run k_rollout_mlp2 (one wave per SIMD, two pipelined sets; a_dim <= 3)
     MlpDev hm{};          // learned model: device pointers + normalisation (host copy)
@@ -513,6 +514,11 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
     const size_t lds = (h->mlp_v2 ? mlp2_lds_floats(2 * A, A, h->H) : mlp_lds_floats(2 * A, A)) * 4;
     const dim3 g(h->mlp_v2 ? std::min(h->nb_mlp, h->n_cu) : h->nb_mlp), b(h->mlp_v2 ? kMlp2Threads : kMlpThreads);
     if (mode != MODE_ROLLOUT && mode != MODE_COST_ONLY) return hipErrorInvalidValue;
+    if (h->mlp_small == 32 && !h->mlp32_valu) { // matrix cores, weights stationary in registers: 2 waves x 32 rollouts per tile
+        hipExtLaunchKernelGGL((k_rollout_mlp32<A>), dim3(h->nb_mlp), dim3(kMlp32Threads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC,
+                              (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);
+        return hipGetLastError();
+    }
     if (h->mlp_small) { // one wave = one 64-rollout tile, weights through the scalar cache
         const dim3 gs(h->nb_mlp), bs(64);
         if (h->mlp_small == 16)
@@ -789,7 +795,8 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
     if (!h || !buf || n == 0) return MPPI_ERR_INVALID_ARG;
     const int NG = (h->H + 3) / 4;
     if (h->hc.model_kind == MPPI_MODEL_MLP)
-        if (h->mlp_small) std::snprintf(buf, n, "mppi::k_rollout_mlp_small<%d, %d>", h->a, h->mlp_small);
+        if (h->mlp_small == 32 && !h->mlp32_valu) std::snprintf(buf, n, "mppi::k_rollout_mlp32<%d>", h->a);
+        else if (h->mlp_small) std::snprintf(buf, n, "mppi::k_rollout_mlp_small<%d, %d>", h->a, h->mlp_small);
         else if (h->mlp_v2 && !h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp2<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
         else std::snprintf(buf, n, "mppi::%s<%d, %s>", h->mlp_bx3 ? "k_rollout_mlp_bx3" : "k_rollout_mlp", h->a, h->sigma_diag ? "true" : "false");
     else if (!h->normalize && pc_eligible(h))
@@ -1141,6 +1148,9 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
         h->mlp_v2 = (value == 0 && h->a <= 3) ? 1 : 0;
         h->nb_mlp = h->mlp_v2 ? (h->K_local + kMlp2R - 1) / kMlp2R : (h->K_local + kMlpR - 1) / kMlpR; // d_part is sized for the larger count
         break;
+    case MPPI_TUNE_MLP32_VALU:
+        if (h->mlp_small != 32) return fail(h, MPPI_ERR_INVALID_ARG, "not a Dense(32) MLP handle");
+        h->mlp32_valu = value != 0; break;
     case MPPI_TUNE_P2P_FAULT:
         if (value < 0 || value > 2) return fail(h, MPPI_ERR_INVALID_ARG, "fault: 0 none, 1 export, 2 probe");
         h->p2p_fault = value; break;

@@ -1314,6 +1314,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
 } // namespace mppi
 #include "mppi_mlp2.hip.h"
 #include "mppi_mlp_small.hip.h"
+#include "mppi_mlp32.hip.h"
 namespace mppi {
 
 // min / max of the costs (Py normalizeCost, controller_base.py:468-474): out[0]=min, out[1]=max-min

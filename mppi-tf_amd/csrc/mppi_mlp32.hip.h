@@ -1,0 +1,201 @@
+// mppi_mlp32.hip.h — k_rollout_mlp32: the reference's Dense(32, relu) x 1..3 + Dense(s) network (nn_model.py:54-60) on
+// the matrix cores, weights stationary in registers. Included by mppi_kernels.hip.h.
+//
+// k_rollout_mlp_small (one rollout per lane, weights through the scalar cache) is starved at BASELINE sizes: K=65536 is
+// 1024 waves = ONE per SIMD, every s_load wait exposed (0.36 ms per step, 0.38 of the vector peak). A 32-wide layer is
+// exactly one v_mfma_f32_32x32x2_f32 tile (32 units x 32 rollouts, 16 k pairs), and — the point of this kernel — the
+// accumulator layout of one layer IS the B-operand layout of the next: lane (j, hh) holds in accumulator register r the
+// unit u(r, hh) = 8 (r >> 2) + 4 hh + (r & 3) of rollout j, and the B operand of k pair s wants "input 2 s + hh of rollout
+// j" in lane (j, hh). Numbering the next layer's inputs so that input (2 s + hh) is unit u(s, hh) makes accumulator
+// register s, after relu, the B operand of MFMA s: no LDS, no shuffle, no barrier between layers. The weights (A operands:
+// lane (m, hh) holds W[u(s, hh)][m]) and the biases (the C operand of a layer's first MFMA: lane (., hh), register r holds
+// b[u(r, hh)]) are loaded once per wave: 5 + 16 + 2 x (16 + 16) registers.
+//   * one wave = 32 rollouts (both lane halves carry rollout j's state, as in k_rollout_mlp2); a workgroup = 2 waves = one
+//     64-rollout tile record; K=65536 gives 2 waves per SIMD, which is what fills the MFMA -> relu dependency gaps;
+//   * the output layer (s of 32 rows used) stays on the vector ALU straight from the accumulators, W3 rows broadcast from
+//     LDS, lane halves combined with v_permlane32_swap;
+//   * per step and wave: 5 + 16 (n_hidden - 1) MFMAs (64 cycles each) + ~300 vector instructions.
+// Arithmetic: fmaf chains in the layer's k order (units in u(s, hh) order instead of ascending; bias first instead of
+// last): within the same tolerance class as the other MLP kernels, held to the same tests.
+#pragma once
+
+namespace mppi {
+
+constexpr int kMlp32Threads = 128;
+constexpr int kMlp32R = 64; // rollouts per workgroup (2 waves x 32)
+
+template <int A>
+__global__ __launch_bounds__(kMlp32Threads) void k_rollout_mlp32(
+    const DevConsts *__restrict__ C, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
+    const float *__restrict__ U_dev, const float *__restrict__ eps_hbm,
+    const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
+    const int SRC, const int MODE, const int rsb, const int rsc)
+{
+    constexpr int S = 2 * A, NIN = S + A, SP = S / 2, HID = 32;
+    constexpr int K1H = (NIN + 1) / 2; // k pairs of layer 1
+    constexpr bool QFULL = false, DIAG = false;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float w3_s[HID * 8];     // output-layer rows, padded to 8
+    __shared__ float z_s[2][4 * A][32];                               // per wave: the normals of one horizon group
+    __shared__ float cost_s[kMlp32R];
+    const int H = C->H, HA = H * A, K = C->K_local;
+    const int NG = (H + 3) / 4;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
+    const int k0 = blockIdx.x * kMlp32R;
+    const int kk = min(k0 + 32 * w + j, K - 1); // rollouts past K recompute the last sample, outside every sum
+    const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
+    const unsigned long long seed = C->seed;
+    const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)kk;
+    const int n_hidden = M->n_layers - 1;
+    auto unit_of = [](int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); };
+
+    // ---- stationary operands
+    float a1[K1H];
+#pragma unroll
+    for (int s1 = 0; s1 < K1H; ++s1) a1[s1] = (2 * s1 + hh) < NIN ? M->Wl[0][(2 * s1 + hh) * HID + j] : 0.0f;
+    f32x16 b1t, bht[2];
+    float ah[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b1t[r] = M->bl[0][unit_of(r, hh)];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const bool have = l + 2 <= n_hidden; // hidden-to-hidden layer l exists
+        const float *Wl = have ? M->Wl[l + 1] : M->Wl[0], *bl = have ? M->bl[l + 1] : M->bl[0];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) ah[l][s] = have ? Wl[unit_of(s, hh) * HID + j] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bht[l][r] = have ? bl[unit_of(r, hh)] : 0.0f;
+    }
+    const float *W3g = M->Wl[n_hidden], *b3g = M->bl[n_hidden];
+    for (int i = tid; i < HID * 8; i += kMlp32Threads) w3_s[i] = (i & 7) < S ? W3g[(i >> 3) * S + (i & 7)] : 0.0f;
+    float xm[NIN], xr[NIN], b3v[S], ysd[S], ymn[S];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) { xm[i] = M->xmean[i]; xr[i] = 1.0f / M->xstd[i]; }
+#pragma unroll
+    for (int i = 0; i < S; ++i) { b3v[i] = b3g[i]; ysd[i] = M->ystd[i]; ymn[i] = M->ymean[i]; }
+    float x[S], c = 0.0f;
+#pragma unroll
+    for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+    __syncthreads();
+
+    // MFMAs and the relu that reads their result as inline asm with "v" operands: through the intrinsic hipcc keeps the
+    // accumulators in AGPRs and the relu becomes v_accvgpr_read + a canonicalising v_max + v_max per register. Hazards
+    // are ours then: s_nop 1 in front of an MFMA (its B operand may just have been written by the relu), 18 wait states
+    // between a layer's last MFMA and the first read of its result (16 passes + 2; the other wave of the SIMD runs meanwhile).
+    auto mfma_first = [&](f32x16 &acc, float a, float b, const f32x16 &cin) {
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(cin));
+    };
+    auto mfma_more = [&](f32x16 &acc, float a, float b) {
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    };
+    auto relu16 = [&](f32x16 &acc) {
+        asm volatile("s_nop 15\n\ts_nop 1\n\t"
+                     "v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3\n\t"
+                     "v_max_f32 %4, 0, %4\n\tv_max_f32 %5, 0, %5\n\tv_max_f32 %6, 0, %6\n\tv_max_f32 %7, 0, %7\n\t"
+                     "v_max_f32 %8, 0, %8\n\tv_max_f32 %9, 0, %9\n\tv_max_f32 %10, 0, %10\n\tv_max_f32 %11, 0, %11\n\t"
+                     "v_max_f32 %12, 0, %12\n\tv_max_f32 %13, 0, %13\n\tv_max_f32 %14, 0, %14\n\tv_max_f32 %15, 0, %15"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                       "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
+    };
+    auto hidden = [&](f32x16 &acc, const f32x16 &in, const float (&a)[16], const f32x16 &bias) {
+        mfma_first(acc, a[0], in[0], bias);
+#pragma unroll
+        for (int s = 1; s < 16; ++s) mfma_more(acc, a[s], in[s]);
+        relu16(acc);
+    };
+    // output layer + state update + step cost, from the (relu'd) accumulators of the last hidden layer
+    auto finish = [&](const f32x16 &hacc, float ac) {
+        f32x2 py[SP];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 8 * (r >> 2) + (r & 3); // + 4 hh through the lane's base
+            const float *wp = w3_s + (4 * hh + row) * 8;
+            const f32x4 lo = *static_cast<const f32x4 *>(__builtin_assume_aligned(wp, 16));
+            const f32x4 hi = *static_cast<const f32x4 *>(__builtin_assume_aligned(wp + 4, 16));
+            const float wv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const f32x2 h2 = {hacc[r], hacc[r]};
+#pragma unroll
+            for (int p2 = 0; p2 < SP; ++p2) {
+                const f32x2 w2 = {wv[2 * p2], wv[2 * p2 + 1]};
+                py[p2] = r == 0 ? h2 * w2 : __builtin_elementwise_fma(h2, w2, py[p2]);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < S; ++n) { // the other half's rows: lower + upper, in every lane
+            float a = (n & 1) ? py[n / 2].y : py[n / 2].x, b = a;
+            permlane32_swap(a, b); // a = the lower half's partial in all lanes, b = the upper half's
+            const float y = (a + b) + b3v[n];
+            x[n] = x[n] + (y * ysd[n] + ymn[n]);
+        }
+        const float sc = state_cost<S, QFULL>(C, x); // cost on the POST-step state
+        const float tmp = sc + ac;
+        c = c + tmp;
+    };
+
+    for (int t = 0; t < H; ++t) {
+        if (SRC == SRC_PHILOX && (t & 3) == 0) { // this wave's normals of the group: block q by the half with q & 1 == hh
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < A; ++q) {
+                if ((q & 1) == hh) {
+                    const uint4 r = philox4x32_10_block(seed, gk, (base + (unsigned long long)(t >> 2)) * A + q);
+                    const float2 n0 = box_muller_hw(r.x, r.y), n1 = box_muller_hw(r.z, r.w);
+                    z_s[w][4 * q + 0][j] = n0.x; z_s[w][4 * q + 1][j] = n0.y; z_s[w][4 * q + 2][j] = n1.x; z_s[w][4 * q + 3][j] = n1.y;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): one wave's LDS accesses complete in order
+            __builtin_amdgcn_wave_barrier();
+        }
+        float u[A], e[A], v[A];
+        if (SRC == SRC_PHILOX) {
+            float z1[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) z1[i] = z_s[w][(t & 3) * A + i][j];
+            scale_noise<A, DIAG>(C, z1, e);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
+        }
+#pragma unroll
+        for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
+        const float ac = action_cost<A, DIAG>(C, u, e);
+        // layer 1: the B operand of lane (j, hh), k pair s1, is input 2 s1 + hh of rollout j — the lane's own value
+        f32x16 acc0;
+#pragma unroll
+        for (int s1 = 0; s1 < K1H; ++s1) {
+            const int i0 = 2 * s1, i1 = 2 * s1 + 1;
+            const float r0 = i0 < S ? x[i0] : v[i0 - S], m0 = xm[i0], q0 = xr[i0];
+            const float r1 = i1 < NIN ? (i1 < S ? x[i1] : v[i1 - S]) : 0.0f, m1 = i1 < NIN ? xm[i1] : 0.0f, q1 = i1 < NIN ? xr[i1] : 0.0f;
+            const float b = hh ? (r1 - m1) * q1 : (r0 - m0) * q0;
+            if (s1 == 0) mfma_first(acc0, a1[s1], b, b1t);
+            else mfma_more(acc0, a1[s1], b);
+        }
+        relu16(acc0);
+        if (n_hidden >= 2) {
+            f32x16 acc1;
+            hidden(acc1, acc0, ah[0], bht[0]);
+            if (n_hidden >= 3) {
+                hidden(acc0, acc1, ah[1], bht[1]);
+                finish(acc0, ac);
+            } else {
+                finish(acc1, ac);
+            }
+        } else {
+            finish(acc0, ac);
+        }
+    }
+    c = c + state_cost<S, QFULL>(C, x); // terminal cost, controller_base.cpp:271-272
+    // lane l of BOTH waves now stands for rollout k0 + l of the tile
+    if (hh == 0) cost_s[32 * w + j] = c;
+    __syncthreads();
+    const float ct = cost_s[lane];
+    const bool valid = (k0 + lane) < K;
+    const int kt = valid ? k0 + lane : K - 1;
+    if (w == 0 && valid) cost[k0 + lane] = ct;
+    if (MODE == MODE_COST_ONLY) return;
+    mlp_tile_record<A, DIAG, 2>(C, ct, valid, w, lane, kt, H, NG, SRC, eps_hbm, seed, (unsigned long long)C->k_offset + (unsigned long long)kt,
+                                base, partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc);
+}
+
+} // namespace mppi

@@ -667,20 +667,26 @@ def test_small_mlp_single_step_reference_order_is_bit_exact(m, hid, n_hidden):
     a, s = 3, 6
     mlp = make_mlp(s, a, seed=11, hid=hid, n_hidden=n_hidden)
     h, p32, _ = make_mlp_pair(m, 64, 4, a, mlp)
-    assert h.rollout_kernel_name() == "mppi::k_rollout_mlp_small<3, %d>" % hid
+    assert h.rollout_kernel_name() == ("mppi::k_rollout_mlp32<3>" if hid == 32 else "mppi::k_rollout_mlp_small<3, %d>" % hid)
     rng = np.random.default_rng(0)
     X, V = rng.standard_normal((50, s)).astype(F32), rng.standard_normal((50, a)).astype(F32)
     np.testing.assert_array_equal(h.model_next(X, V), np.stack([p32.mlp_step(X[i], V[i]) for i in range(50)]))
 
 
-@pytest.mark.parametrize("hid,n_hidden", SMALL_NETS, ids=SMALL_IDS)
+# (hidden width, hidden layers, Handle tuning): Dense(32) runs on the matrix cores (k_rollout_mlp32) by default and on the
+# vector ALU (k_rollout_mlp_small) with mlp32_valu; Dense(16) on the vector ALU
+SMALL_KERNELS = [(32, 3, None), (32, 3, {"mlp32_valu": 1}), (16, 3, None), (32, 1, None), (32, 2, None), (16, 2, None), (32, 1, {"mlp32_valu": 1})]
+SMALL_KERNEL_IDS = ["32x3-mfma", "32x3-valu", "16x3", "32x1-mfma", "32x2-mfma", "16x2", "32x1-valu"]
+
+
+@pytest.mark.parametrize("hid,n_hidden,tuning", SMALL_KERNELS, ids=SMALL_KERNEL_IDS)
 @pytest.mark.parametrize("K,H,a", [(4096, 32, 3), (100, 16, 3), (33, 5, 2), (1000, 130, 1), (512, 24, 4)])
-def test_small_mlp_control_step_against_oracle(m, K, H, a, hid, n_hidden):
+def test_small_mlp_control_step_against_oracle(m, K, H, a, hid, n_hidden, tuning):
     """One control step on injected noise: sample costs as close to the fp64 oracle as an fp32 CPU evaluation is (4x),
     U' within north_star's 1e-5 wherever the fp32 CPU evaluation itself is (see MLP_VARIANTS: K=1000, H=130, a=1 at
     lambda=1 is not — fp32 CPU 2.2e-5, this kernel 1.6e-5); ragged K (33, 100, 1000: partial last tile) and a horizon
     that is no multiple of 4."""
-    check_mlp_step(m, K, H, a, 300 + H, {}, 1e-5, 4.0, hid=hid, n_hidden=n_hidden, well_conditioned=False)
+    check_mlp_step(m, K, H, a, 300 + H, dict(tuning=tuning) if tuning else {}, 1e-5, 4.0, hid=hid, n_hidden=n_hidden, well_conditioned=False)
 
 
 def test_small_mlp_fused_philox_step_and_sharding(m):
@@ -707,11 +713,12 @@ def test_small_mlp_fused_philox_step_and_sharding(m):
     shards = [m.Handle(shard_rank=r, shard_count=4, **cfg) for r in range(4)]
     xd = torch.tensor(x, device="cuda")
     recs = torch.empty((4, 2 + H * a), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream  # ONE stream for all shards (each handle's own stream would race)
     for r, sh in enumerate(shards):
-        sh.shard_partial(xd.data_ptr(), recs[r].data_ptr())
+        sh.shard_partial(xd.data_ptr(), recs[r].data_ptr(), st)
     ud = torch.empty(a, dtype=torch.float32, device="cuda")
-    shards[0].shard_finish(recs.data_ptr(), 4, ud.data_ptr())
-    shards[0].synchronize()
+    shards[0].shard_finish(recs.data_ptr(), 4, ud.data_ptr(), st)
+    torch.cuda.synchronize()
     assert np.abs(ud.cpu().numpy() - u).max() <= 2e-6
 
 
