@@ -1,17 +1,28 @@
 """Build recipe for libmppi_hip.so (the product) — hipcc, gfx950 only, in-tree output.
 
+The library is several translation units (csrc/*.hip): the C-ABI, and one object per (kernel family, action dimension)
+— the rollout kernels are heavily unrolled templates and a single unit took 3-6 minutes. The units are compiled in
+parallel (one hipcc -c per unit, a thread per CPU) into build/obj/ and linked into mppi-tf_amd/libmppi_hip.so.
+
 -ffp-contract=off: the rollout arithmetic is the reference's op-by-op fp32 rounding (no fused
 multiply-add), which is what makes sample costs bit-identical to an unfused fp32 evaluation on any IEEE CPU.
 """
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libmppi_hip.so")
-SOURCES = ["mppi_capi.hip"]
-HEADERS = ["mppi_device.hip.h", "mppi_kernels.hip.h", "mppi_mlp2.hip.h", "mppi_mlp_small.hip.h", "mppi_mlp32.hip.h"]
+# (source, defines, object stem). Heaviest first: the pool starts them first.
+UNITS = ([("mppi_launch_mlp.hip", ["MPPI_UNIT_A=%d" % a], "mlp_a%d" % a) for a in (3, 2, 1, 4)]
+         + [("mppi_launch_pc.hip", ["MPPI_UNIT_A=%d" % a], "pc_a%d" % a) for a in (4, 3, 2, 1)]
+         + [("mppi_launch_tile.hip", ["MPPI_UNIT_A=%d" % a], "tile_a%d" % a) for a in (4, 3, 2, 1)]
+         + [("mppi_capi.hip", [], "capi")])
+SOURCES = sorted({u[0] for u in UNITS})
+HEADERS = ["mppi_device.hip.h", "mppi_kernels.hip.h", "mppi_mlp2.hip.h", "mppi_mlp_small.hip.h", "mppi_mlp32.hip.h",
+           "mppi_handle.hip.h"]
 ARCH = "gfx950"
 
 
@@ -22,10 +33,12 @@ def hipcc():
     return "hipcc"
 
 
-def command(out=SO, extra=()):
-    return [hipcc(), "-O3", "--offload-arch=" + ARCH, "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
-            "-I", os.path.join(ROOT, "include"), *extra,
-            *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+def flags(extra=()):
+    return ["-O3", "--offload-arch=" + ARCH, "-ffp-contract=off", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), *extra]
+
+
+def _deps(src):
+    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "mppi_c.h"), __file__]
 
 
 def source_sha():
@@ -37,30 +50,61 @@ def source_sha():
     return hsh.hexdigest()[:16]
 
 
-def stale():
-    if not os.path.exists(SO):
+def stale(so=SO):
+    if not os.path.exists(so):
         return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "mppi_c.h"), __file__]
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(so)
+    return any(os.path.getmtime(d) > t for src in SOURCES for d in _deps(src))
+
+
+def _jobs():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, int(os.environ.get("MPPI_BUILD_JOBS", "8"))))
+
+
+def _compile_all(objdir, extra, force, verbose):
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+
+    def one(unit):
+        src, defs, stem = unit
+        obj = os.path.join(objdir, stem + ".o")
+        if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps(src)):
+            return obj
+        cmd = [cc, *flags(extra), *["-D" + d for d in defs], "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(_jobs()) as pool:
+        return list(pool.map(one, UNITS))
+
+
+def _link(objs, out, verbose):
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", *objs, "-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
 
 
 def build(force=False, verbose=False):
     """Compile the HIP library if sources are newer than the in-tree .so. Returns its path."""
     if force or stale():
-        cmd = command()
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        objs = _compile_all(os.path.join(ROOT, "build", "obj", "default"), (), force, verbose)
+        _link(objs, SO, verbose)
     return SO
 
 
-def build_variant(name, defines=(), extra=()):
-    """Timing-only variant builds for ablation (tools/ablate.py) -> build/variants/libmppi_hip_<name>.so"""
+def build_variant(name, defines=(), extra=(), force=False):
+    """Variant builds of the SAME library (timing ablations, tools/ablate.py; the rocRAND-verbatim noise variant)
+    -> build/variants/libmppi_hip_<name>.so"""
     d = os.path.join(ROOT, "build", "variants")
     os.makedirs(d, exist_ok=True)
     out = os.path.join(d, "libmppi_hip_%s.so" % name)
-    subprocess.check_call(command(out, ["-D" + x for x in defines] + list(extra)))
+    if force or stale(out):
+        objs = _compile_all(os.path.join(ROOT, "build", "obj", name), ["-D" + x for x in defines] + list(extra), force, False)
+        _link(objs, out, False)
     return out
 
 

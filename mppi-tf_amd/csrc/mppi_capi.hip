@@ -1,8 +1,6 @@
 // mppi_capi.hip — host side of libmppi_hip.so: the C-ABI of include/mppi_c.h over the kernels
 // of mppi_kernels.hip.h.  No CPU compute path exists here: every numeric entry point launches
 // HIP kernels and fails with MPPI_ERR_NO_DEVICE / MPPI_ERR_HIP when it cannot.
-#include "mppi_kernels.hip.h"
-#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -13,92 +11,13 @@
 #include <string>
 #include <vector>
 
-using namespace mppi;
-
 #define MPPI_VERSION_STRING "mppi-hip 0.1.0 (gfx950)"
 
-// ----------------------------------------------------------------------------------------
-struct mppi_handle {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    DevConsts hc{};
-    DevConsts *dC = nullptr;
-    int K_global = 0, K_local = 0, k_offset = 0, shard_rank = 0, shard_count = 1;
-    int H = 0, s = 0, a = 0, HA = 0;
-    int R = 64, nb = 0;   // tile size / record count of the point-mass tile kernels
-    int nb_mlp = 0;       // record count of the MLP rollout kernel (64 rollouts per workgroup)
-    int nbp = 0;          // record slots in d_part: record_pad(max(nb, nb_mlp)), the column stride of every rollout launch
-    int part_nb = 0;      // tile count whose slots currently hold records (0: all slots neutral)
-    int mlp_bx3 = 0;      // MPPI_FLAG_MLP_BF16X3: split-bf16 matrix-core variant of the MLP rollout
-    int mlp_small = 0;    // hidden width (16 or 32) of a small learned model served by k_rollout_mlp_small, else 0
-    MlpSmallArgs small_args{};
-    int mlp32_valu = 0;   // tuning: a Dense(32) network on k_rollout_mlp_small instead of k_rollout_mlp32
-    int n_cu = 256;       // compute units of the device (k_rollout_mlp2 runs one tile-walking workgroup per CU)
-    int mlp_v2 = 0;       // exact-fp32 MLP rollouts run k_rollout_mlp2 (one wave per SIMD, two pipelined sets; a_dim <= 3)
-    MlpDev hm{};          // learned model: device pointers + normalisation (host copy)
-    MlpDev *dM = nullptr;
-    float *d_mlp_w = nullptr; // one allocation holding W1,b1,W2,b2,W3,b3
-    size_t tile_lds = 0;
-    int normalize = 0;
-    int sigma_diag = 0; // Σ and Σ⁻¹ are exactly diagonal (the DIAG kernel instances are bit-identical then)
-    int pc_np = 5;      // producer waves per workgroup of k_rollout_pc (chosen by tiles per CU; MPPI_TUNE_PC_PRODUCERS overrides)
-    // diagnostic switches, set only through mppi_set_tuning (the library reads no environment variable)
-    int force_tile = 0;   // MPPI_TUNE_FORCE_TILE_KERNEL: the LDS-tile kernel instead of the producer/consumer one (A/B timing)
-    int pc_no_balance = 0; // MPPI_TUNE_PC_BALANCE = 0: no SIMD-true roles / progress priorities
-    int pc_lds_min = 0;   // MPPI_TUNE_PC_LDS_MIN: pad the dynamic LDS (caps workgroups per CU)
-    int sync_spin = 1;    // MPPI_TUNE_SYNC_SPIN: the synchronous step watches the pinned u slot (0: waits for the stream)
-    int p2p_fault = 0;    // MPPI_TUNE_P2P_FAULT: 1 = inbox export refused, 2 = probe reports failure (fallback tests)
-    unsigned attr_done = 0; // kernels whose dynamic-LDS ceiling has been raised ON THIS HANDLE'S DEVICE (bit per kernel family)
-    size_t tile_attr_set = 0;
-    float *d_x = nullptr, *d_u = nullptr, *d_cost = nullptr, *d_cost2 = nullptr;
-    // The nominal sequence lives in one of two buffers of tau*a + a floats whose last a floats stay zero. A step
-    // reads U from ubuf[u_cur] + u_off and writes U' to the other buffer at offset 0; the shifted sequence
-    // (mShift + mInit0, controller_base.cpp:310-324) is then simply that buffer read from offset a_dim.
-    float *d_Ubuf[2] = {nullptr, nullptr};
-    int u_cur = 0, u_off = 0;
-    float *U_cur() const { return d_Ubuf[u_cur] + u_off; }
-    float *U_other() const { return d_Ubuf[1 - u_cur]; }
-    float *d_Uupd = nullptr; // U' of the last step (MPPI_DBG_U_UPDATED)
-    void U_advance() { u_cur = 1 - u_cur; u_off = a; d_Uupd = d_Ubuf[u_cur]; }
-    // options of the Python reference's update: clip_act limits [a_min | a_max] and the Savitzky-Golay filter
-    float *d_clip = nullptr;
-    int sg_window = 0;
-    float *d_sg_rows = nullptr;
-    int *d_sg_start = nullptr;
-    float *d_part = nullptr, *d_part2 = nullptr, *d_part3 = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_mm = nullptr;
-    float *d_eps = nullptr; // lazily allocated [K_local, H, a] for injected noise / debug export
-    unsigned long long *d_step = nullptr;
-    // pinned, device-mapped host staging for the synchronous path: x slot 0 | x slot 1 | u. The kernels read
-    // x and write u straight through these (zero-copy over PCIe, 24 B / 12 B): no H2D / D2H copy nodes per step.
-    float *h_pin = nullptr, *d_pin = nullptr;
-    int pin_slot = 0;
-    std::string err;
-    // profiling: event pairs around the rollout / finish kernels (mppi_profile_begin/end)
-    std::vector<hipEvent_t> ev;   // 4 events per step: rollout begin/end, finish begin/end
-    int prof_cap = 0, prof_n = 0; // steps that can be / have been recorded
-    hipStream_t prof_stream = nullptr;
-    // when a step is being profiled the dominant kernel is launched with hipExtLaunchKernel, whose start/stop events
-    // carry the dispatch's own begin/end timestamps (what rocprofv3 reports), not the stream-level gaps around it
-    hipEvent_t kev0 = nullptr, kev1 = nullptr;
-    std::string no_rollout; // non-empty: why this handle cannot run rollouts (helpers still work)
-    // transition log (m_db of the reference: addX/addU/addNext/toCSV, data_base.cpp:29-71): off until
-    // mppi_set_transition_log gives it a capacity; a ring of rows (x | u | x_next | has_next), allocated once there
-    std::vector<float> log_rows;
-    size_t log_cap = 0, log_count = 0, log_head = 0; // capacity in rows, rows held, index of the oldest row
-    size_t log_stride() const { return (size_t)2 * s + a + 1; }
-    // direct record exchange (mppi_shard_p2p_*): own inbox, the peers' mapped inboxes, call sequence number
-    unsigned long long *xchg_inbox = nullptr;
-    XchgPeers xchg_peers{};
-    std::vector<void *> xchg_opened; // hipIpcOpenMemHandle mappings to close
-    bool xchg_attached = false;
-    unsigned xchg_seq = 0, probe_seq = 0;
-    long long xchg_timeout_ticks = 0;
-    unsigned *h_xchg_status = nullptr, *d_xchg_status = nullptr; // pinned, device-mapped: deadline flag for the host
-    unsigned *d_xchg_dead = nullptr;                             // the same flag in device memory, read by every launch
-    float *d_probe_got = nullptr;
-    size_t xchg_step_slots() const { return (size_t)2 * HA * shard_count * 3; }
-    size_t xchg_inbox_bytes() const { return sizeof(unsigned long long) * (xchg_step_slots() + (size_t)2 * shard_count); }
-};
+#define MPPI_UNIT_CAPI 1
+#include "mppi_handle.hip.h"
+
+#include <map>
+#include <mutex>
 
 static thread_local std::string g_create_err;
 
@@ -116,6 +35,21 @@ static mppi_status fail(mppi_handle *h, mppi_status st, const std::string &msg)
         if (_e != hipSuccess)                                                                     \
             return fail((h), MPPI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
     } while (0)
+
+
+// see mppi_handle.hip.h: process-wide, per (kernel instance, device), only ever raised
+hipError_t mppi_raise_lds_ceiling(const void *kernel, int device, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> ceiling;
+    if (bytes <= 48 * 1024) return hipSuccess; // the default ceiling
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &cur = ceiling[{kernel, device}];
+    if (bytes <= cur) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
 
 // ----------------------------------------------------------------------------------------
 extern "C" int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
@@ -402,84 +336,19 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     return MPPI_OK;
 }
 
-// ----------------------------------------------------------------------------------------
-// kernel dispatch
-template <int A, int R, bool QFULL, int SRC, int MODE>
-static hipError_t launch_tile_inst(mppi_handle *h, hipStream_t st, const float *x_dev, const float *U_dev,
-                                   const float *eps, float *cost, float *part, float *noise_out)
-{
-    auto kern = k_rollout_tile<A, R, QFULL, SRC, MODE>;
-    // raise the dynamic-LDS ceiling above the default: per launch (the attribute belongs to the (kernel, device) pair and
-    // several handles / devices share a template instance; the call is a table update on the host, ~0.2 us)
-    if (h->tile_lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tile_lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(h->nb), dim3(kThreads), h->tile_lds, st, h->dC, x_dev, U_dev, eps, h->d_step, cost, part, noise_out, 1, h->nbp);
-    return hipGetLastError();
-}
-
-template <int A, int R, bool QFULL>
-static hipError_t launch_tile_ar(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
-                                 const float *eps, float *cost, float *part, float *noise_out)
-{
-#define MPPI_TILE_CASE(SRC, MODE) \
-    if (src == SRC && mode == MODE) return launch_tile_inst<A, R, QFULL, SRC, MODE>(h, st, x_dev, U_dev, eps, cost, part, noise_out);
-    MPPI_TILE_CASE(SRC_PHILOX, MODE_ROLLOUT)
-    MPPI_TILE_CASE(SRC_HBM, MODE_ROLLOUT)
-    MPPI_TILE_CASE(SRC_PHILOX, MODE_COSTS_GIVEN)
-    MPPI_TILE_CASE(SRC_HBM, MODE_COSTS_GIVEN)
-    MPPI_TILE_CASE(SRC_PHILOX, MODE_COST_ONLY)
-    MPPI_TILE_CASE(SRC_HBM, MODE_COST_ONLY)
-    MPPI_TILE_CASE(SRC_PHILOX, MODE_NOISE_ONLY)
-#undef MPPI_TILE_CASE
-    return hipErrorInvalidValue;
-}
-
-template <int A>
-static hipError_t launch_tile_a(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
-                                const float *eps, float *cost, float *part, float *noise_out)
-{
-    const bool qf = h->hc.q_full != 0;
-#define MPPI_R_CASE(RR)                                                                                       \
-    if (h->R == RR) return qf ? launch_tile_ar<A, RR, true>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out) \
-                              : launch_tile_ar<A, RR, false>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
-    MPPI_R_CASE(64)
-    MPPI_R_CASE(32)
-    MPPI_R_CASE(16)
-#undef MPPI_R_CASE
-    return hipErrorInvalidValue;
-}
-
+// kernel dispatch: the rollout kernels are instantiated in their own translation units (mppi_launch_*.hip, one per
+// kernel family and action dimension, compiled in parallel); mppi_handle.hip.h declares their launchers.
 static hipError_t launch_tile(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
                               const float *eps, float *cost, float *part, float *noise_out)
 {
     if (!h->no_rollout.empty()) return hipErrorNotSupported;
     switch (h->a) {
-    case 1: return launch_tile_a<1>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
-    case 2: return launch_tile_a<2>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
-    case 3: return launch_tile_a<3>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
-    case 4: return launch_tile_a<4>(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
+    case 1: return mppi_launch_tile_a1(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
+    case 2: return mppi_launch_tile_a2(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
+    case 3: return mppi_launch_tile_a3(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
+    case 4: return mppi_launch_tile_a4(h, st, src, mode, x_dev, U_dev, eps, cost, part, noise_out);
     }
     return hipErrorInvalidValue;
-}
-
-// the hot configuration: producer/consumer kernel (k_rollout_pc) when the horizon fits its register file
-template <int A, int NP, int NSLOT>
-static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_dev)
-{
-    const size_t lds = std::max(pc_lds_floats(A, NP) * 4, (size_t)h->pc_lds_min);
-    const int nb = (h->K_local + 63) / 64;
-    const dim3 g(nb), b(64 * (NP + 1));
-    // tile records go out column-major ([2+HA][nb]): the finish kernel reads one column per workgroup
-    // one round of workgroups (<= 4 per CU, all resident from the start): SIMD-true roles + progress priorities
-    const int balance = (nb <= 4 * 256 && !h->pc_no_balance) ? 1 : 0;
-    const DevConsts *dC = h->dC;
-    const float *U = h->U_cur();
-    const unsigned long long *stp = h->d_step;
-    if (h->sigma_diag) hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
-    else hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
-    return hipGetLastError();
 }
 
 // diagonal-Q handles only (a dense Q runs the tile kernel); horizon groups per producer must fit the registers
@@ -491,93 +360,23 @@ static bool pc_eligible(const mppi_handle *h)
 
 static hipError_t launch_pc(mppi_handle *h, hipStream_t st, const float *x_dev)
 {
-    const int NG = (h->H + 3) / 4;
-    if (h->pc_np == 3) { // MPPI_PC_PRODUCERS=3: the 4-wave variant, kept for A/B timing
-        const bool small = NG <= 18;
-#define MPPI_PC_CASE(AA) case AA: return small ? launch_pc_inst<AA, 3, 6>(h, st, x_dev) : launch_pc_inst<AA, 3, 11>(h, st, x_dev);
-        switch (h->a) { MPPI_PC_CASE(1) MPPI_PC_CASE(2) MPPI_PC_CASE(3) MPPI_PC_CASE(4) }
-#undef MPPI_PC_CASE
-        return hipErrorInvalidValue;
+    switch (h->a) {
+    case 1: return mppi_launch_pc_a1(h, st, x_dev);
+    case 2: return mppi_launch_pc_a2(h, st, x_dev);
+    case 3: return mppi_launch_pc_a3(h, st, x_dev);
+    case 4: return mppi_launch_pc_a4(h, st, x_dev);
     }
-    const bool small = NG <= 20;
-#define MPPI_PC_CASE(AA) case AA: return small ? launch_pc_inst<AA, 5, 4>(h, st, x_dev) : launch_pc_inst<AA, 5, 8>(h, st, x_dev);
-    switch (h->a) { MPPI_PC_CASE(1) MPPI_PC_CASE(2) MPPI_PC_CASE(3) MPPI_PC_CASE(4) }
-#undef MPPI_PC_CASE
     return hipErrorInvalidValue;
-}
-
-// learned-model rollouts (k_rollout_mlp): 64 rollouts per workgroup of 8 waves
-template <int A>
-static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
-                               const float *eps, float *cost)
-{
-    const size_t lds = (h->mlp_v2 ? mlp2_lds_floats(2 * A, A, h->H) : mlp_lds_floats(2 * A, A)) * 4;
-    const dim3 g(h->mlp_v2 ? std::min(h->nb_mlp, h->n_cu) : h->nb_mlp), b(h->mlp_v2 ? kMlp2Threads : kMlpThreads);
-    if (mode != MODE_ROLLOUT && mode != MODE_COST_ONLY) return hipErrorInvalidValue;
-    if (h->mlp_small == 32 && !h->mlp32_valu) { // matrix cores, weights stationary in registers: 2 waves x 32 rollouts per tile
-        hipExtLaunchKernelGGL((k_rollout_mlp32<A>), dim3(h->nb_mlp), dim3(kMlp32Threads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC,
-                              (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);
-        return hipGetLastError();
-    }
-    if (h->mlp_small) { // one wave = one 64-rollout tile, weights through the scalar cache
-        const dim3 gs(h->nb_mlp), bs(64);
-        if (h->mlp_small == 16)
-            hipExtLaunchKernelGGL((k_rollout_mlp_small<A, 16>), gs, bs, 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, h->small_args,
-                                  x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);
-        else
-            hipExtLaunchKernelGGL((k_rollout_mlp_small<A, 32>), gs, bs, 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, h->small_args,
-                                  x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);
-        return hipGetLastError();
-    }
-#define MPPI_MLP_L(KERN, BIT)                                                                                           \
-    do {                                                                                                                \
-        auto kern = KERN;                                                                                               \
-        if (!(h->attr_done & BIT)) { /* per handle = per device: the attribute belongs to the (kernel, device) pair */    \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e_ != hipSuccess) return e_;                                                                            \
-            h->attr_done |= BIT;                                                                                        \
-        }                                                                                                               \
-        hipExtLaunchKernelGGL(kern, g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, x_dev, U_dev, eps, \
-                              (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);                \
-    } while (0)
-    if (h->mlp_bx3) {
-        if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp_bx3<A, true>), 8);
-        else MPPI_MLP_L((k_rollout_mlp_bx3<A, false>), 16);
-    } else if (h->mlp_v2) {
-        if constexpr (A <= 3) {
-#define MPPI_MLP2_L(KERN, BIT)                                                                                          \
-    do {                                                                                                                \
-        auto kern = KERN;                                                                                               \
-        if (!(h->attr_done & BIT)) {                                                                                    \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e_ != hipSuccess) return e_;                                                                            \
-            h->attr_done |= BIT;                                                                                        \
-        }                                                                                                               \
-        hipExtLaunchKernelGGL(kern, g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, x_dev, U_dev, eps, \
-                              (const unsigned long long *)h->d_step, cost, h->d_part, mode, 1, h->nbp);                     \
-    } while (0)
-            if (src == SRC_PHILOX) {
-                if (h->sigma_diag) MPPI_MLP2_L((k_rollout_mlp2<A, true, SRC_PHILOX>), 32);
-                else MPPI_MLP2_L((k_rollout_mlp2<A, false, SRC_PHILOX>), 64);
-            } else if (src == SRC_HBM) { // injected noise (API helpers, tests): one instance, the dense-Sigma arithmetic
-                MPPI_MLP2_L((k_rollout_mlp2<A, false, SRC_HBM>), 256); // (exact for a diagonal Sigma too: it adds 0 * z terms)
-            } else return hipErrorInvalidValue;
-#undef MPPI_MLP2_L
-        } else return hipErrorInvalidValue;
-    } else if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp<A, true>), 2);
-    else MPPI_MLP_L((k_rollout_mlp<A, false>), 4);
-#undef MPPI_MLP_L
-    return hipGetLastError();
 }
 
 static hipError_t launch_mlp(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev,
                              const float *eps, float *cost)
 {
     switch (h->a) {
-    case 1: return launch_mlp_a<1>(h, st, src, mode, x_dev, U_dev, eps, cost);
-    case 2: return launch_mlp_a<2>(h, st, src, mode, x_dev, U_dev, eps, cost);
-    case 3: return launch_mlp_a<3>(h, st, src, mode, x_dev, U_dev, eps, cost);
-    case 4: return launch_mlp_a<4>(h, st, src, mode, x_dev, U_dev, eps, cost);
+    case 1: return mppi_launch_mlp_a1(h, st, src, mode, x_dev, U_dev, eps, cost);
+    case 2: return mppi_launch_mlp_a2(h, st, src, mode, x_dev, U_dev, eps, cost);
+    case 3: return mppi_launch_mlp_a3(h, st, src, mode, x_dev, U_dev, eps, cost);
+    case 4: return mppi_launch_mlp_a4(h, st, src, mode, x_dev, U_dev, eps, cost);
     }
     return hipErrorInvalidValue;
 }

@@ -448,16 +448,19 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
 // dependent L2 round trips per thread (measured 76 µs at K=65536); this level runs on
 // ceil(nb/kGroup) CUs with kGroup independent loads in flight per thread instead.
 // neutral records in every slot (see record_slot): launched at create and when a handle changes its record count
+#if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ void k_fill_records(float *__restrict__ recs, int nbp, int ncol)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nbp * ncol) recs[i] = i < nbp ? kPadBeta : 0.0f;
 }
+#endif
 
 constexpr int kGroup = 16;
 // Scalars arrive as kernel arguments (SGPRs at wave start) rather than through DevConsts: these
 // kernels are a chain of dependent memory round trips, and every hop removed is ~0.5-1 µs.
 // Input element (b, col) at recs[b*sb + col*sc]; output records are row-major [ng, 2+HA].
+#if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ __launch_bounds__(kThreads) void k_combine_group(
     const float *__restrict__ recs, int sb, int sc, int nb, int HA, float neg_inv_lambda, float *__restrict__ out)
 {
@@ -494,6 +497,7 @@ __global__ __launch_bounds__(kThreads) void k_combine_group(
         out[(size_t)blockIdx.x * stride + 1 + col] = (float)acc;
     }
 }
+#endif
 
 // ----------------------------------------------------------------------------------------
 // k_finish_cols: the whole combine + update in ONE launch, one workgroup per horizon-action column c:
@@ -558,6 +562,7 @@ __device__ __forceinline__ void column_combine(Load ld, int nb, float neg_inv_la
     beta_out = beta; eta_out = eta; V_out = V;
 }
 
+#if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ __launch_bounds__(kThreads) void k_finish_cols(
     const float *__restrict__ recs, int sb, int sc, int nb, int /*HA*/, int a, float neg_inv_lambda,
     const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
@@ -589,6 +594,7 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols(
         }
     }
 }
+#endif
 
 // ----------------------------------------------------------------------------------------
 // k_finish_cols_xchg: the K-sharded step's finish with the record exchange INSIDE the kernel.
@@ -632,6 +638,7 @@ __device__ __forceinline__ unsigned long long xchg_wait(const unsigned long long
 // no spins, zero update — instead of burning one deadline per queued step; mppi_shard_p2p_step refuses further steps
 // as soon as the host sees the flag (MPPI_ERR_EXCHANGE), and ShardedController re-synchronises U and the step counter
 // from rank 0 before it continues on the all-gather path (distributed.py).
+#if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ __launch_bounds__(kThreads) void k_finish_cols_xchg(
     const float *__restrict__ recs, int sb, int sc, int nb, int HA, int a, float neg_inv_lambda,
     const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
@@ -677,10 +684,12 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols_xchg(
         if (c == 0) step_ctr[0] = step_old + 1ull;
     }
 }
+#endif
 
 // k_savgol: filterSeq (controller_base.py:277-291): out[t,j] = Σ_i rows[t,i]·in[start[t]+i, j]. rows holds, for
 // every t, the `window` Savitzky-Golay weights that evaluate the least-squares polynomial of the window starting at
 // start[t] at position t (centre for interior rows, off-centre for the 'interp' edges); built on the host in fp64.
+#if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ void k_savgol(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ rows,
                          const int *__restrict__ start, int H, int a, int window)
 {
@@ -693,10 +702,12 @@ __global__ void k_savgol(const float *__restrict__ in, float *__restrict__ out, 
     for (int i = 0; i < window; ++i) acc += (double)r[i] * (double)src[(size_t)i * a];
     out[idx] = (float)acc;
 }
+#endif
 
 // k_xchg_probe: the exchange's self-test, run once after the inboxes are attached and before the first step: the
 // same packets, stores and spins on a separate probe region of the inbox (after the 2*HA*G*3 step slots), with a
 // known payload. got[g] = the value received from rank g (the host checks got[g] == payload(g, seq)).
+#if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ void k_xchg_probe(XchgPeers peers, size_t probe_off, int G, int rank, unsigned seq, float payload,
                              long long timeout_ticks, unsigned *status, unsigned *status_dev, float *got)
 {
@@ -709,6 +720,7 @@ __global__ void k_xchg_probe(XchgPeers peers, size_t probe_off, int G, int rank,
     const unsigned long long r = xchg_wait(peers.inbox[rank] + slot0 + p, seq, timeout_ticks, status, status_dev, &ok);
     got[p] = ok ? __uint_as_float((unsigned)r) : __uint_as_float(0x7fc00000u);
 }
+#endif
 
 // ----------------------------------------------------------------------------------------
 // Learned model_base (BASELINE configs[3]/[4]):
@@ -727,6 +739,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // One sample per thread, plain loops in the reference order (mul and add rounded separately,
 // input index ascending): the slow, exactly-ordered evaluation behind mppi_model_step for MLP handles.
+#if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ void k_mlp_step_ref(const DevConsts *__restrict__ C, const MlpDev *__restrict__ M,
                                const float *__restrict__ x, int kx, const float *__restrict__ v, int k,
                                float *__restrict__ scratch, float *__restrict__ out_next)
@@ -753,6 +766,7 @@ __global__ void k_mlp_step_ref(const DevConsts *__restrict__ C, const MlpDev *__
     }
     for (int o = 0; o < s; ++o) out_next[(size_t)i * s + o] = xi[o] + (cur[o] * M->ystd[o] + M->ymean[o]);
 }
+#endif
 
 // Tile record of the MLP rollout kernels: every wave holds the same 64 costs; beta, eta by wave 0, and
 // V_b[t,i] = Σ_k e_k·eps[k,t,i] with wave w regenerating the noise of horizon groups g = w, w+8, ... from the Philox
@@ -1318,6 +1332,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
 namespace mppi {
 
 // min / max of the costs (Py normalizeCost, controller_base.py:468-474): out[0]=min, out[1]=max-min
+#if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ __launch_bounds__(kFinishThreads) void k_cost_minmax(const float *__restrict__ cost, int K, float *__restrict__ out)
 {
     __shared__ float mn_s[kFinishThreads / 64], mx_s[kFinishThreads / 64];
@@ -1332,15 +1347,19 @@ __global__ __launch_bounds__(kFinishThreads) void k_cost_minmax(const float *__r
         out[0] = mn; out[1] = mx - mn;
     }
 }
+#endif
 
 // c' = (c - min)/(max - min)  (norm_arg with normalize=True, controller_base.py:468-474)
+#if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ void k_cost_normalize(const float *__restrict__ cost, int K, const float *__restrict__ mm, float *__restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < K) out[i] = (cost[i] - mm[0]) / mm[1];
 }
+#endif
 
 // Per-sample intermediates of the update for inspection (mExpArg, mExp, mWeights :170-186)
+#if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ void k_weights(const DevConsts *__restrict__ C, const float *__restrict__ cost, int K,
                           const float *__restrict__ beta_eta, float *__restrict__ arg_out,
                           float *__restrict__ exp_out, float *__restrict__ w_out)
@@ -1353,6 +1372,7 @@ __global__ void k_weights(const DevConsts *__restrict__ C, const float *__restri
     if (exp_out) exp_out[i] = e;
     if (w_out) w_out[i] = e / beta_eta[1];
 }
+#endif
 
 // ----------------------------------------------------------------------------------------
 // The reference's public graph helpers as kernels (one thread per sample) — the SAME device

@@ -1,0 +1,36 @@
+// mppi_launch_pc.hip — instantiates k_rollout_pc (the hot configuration) for ONE action dimension (-DMPPI_UNIT_A).
+#include "mppi_handle.hip.h"
+#ifndef MPPI_UNIT_A
+#error "compile with -DMPPI_UNIT_A=<action dimension 1..4> (mppi-tf_amd/build.py)"
+#endif
+
+// the hot configuration: producer/consumer kernel (k_rollout_pc) when the horizon fits its register file
+template <int A, int NP, int NSLOT>
+static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_dev)
+{
+    const size_t lds = std::max(pc_lds_floats(A, NP) * 4, (size_t)h->pc_lds_min);
+    const int nb = (h->K_local + 63) / 64;
+    const dim3 g(nb), b(64 * (NP + 1));
+    // tile records go out column-major ([2+HA][nb]): the finish kernel reads one column per workgroup
+    // one round of workgroups (<= 4 per CU, all resident from the start): SIMD-true roles + progress priorities
+    const int balance = (nb <= 4 * 256 && !h->pc_no_balance) ? 1 : 0;
+    const DevConsts *dC = h->dC;
+    const float *U = h->U_cur();
+    const unsigned long long *stp = h->d_step;
+    if (hipError_t e = mppi_raise_lds_ceiling(h->sigma_diag ? reinterpret_cast<const void *>(k_rollout_pc<A, NP, NSLOT, true>) : reinterpret_cast<const void *>(k_rollout_pc<A, NP, NSLOT, false>), h->device, lds); e != hipSuccess) return e;
+    if (h->sigma_diag) hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
+    else hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
+    return hipGetLastError();
+}
+
+hipError_t MPPI_CAT(mppi_launch_pc_a, MPPI_UNIT_A)(MPPI_PC_PARAMS)
+{
+    constexpr int AA = MPPI_UNIT_A;
+    const int NG = (h->H + 3) / 4;
+    if (h->pc_np == 3) { // MPPI_PC_PRODUCERS=3: the 4-wave variant, kept for A/B timing
+        const bool small = NG <= 18;
+        return small ? launch_pc_inst<AA, 3, 6>(h, st, x_dev) : launch_pc_inst<AA, 3, 11>(h, st, x_dev);
+    }
+    const bool small = NG <= 20;
+    return small ? launch_pc_inst<AA, 5, 4>(h, st, x_dev) : launch_pc_inst<AA, 5, 8>(h, st, x_dev);
+}
