@@ -213,11 +213,17 @@ class Handle:
             raise MppiError(st, "%s (%s)" % (txt.decode(), self.lib.mppi_status_string(st).decode()))
 
     def close(self):
-        if getattr(self, "h", None):
-            self.lib.mppi_destroy(self.h)
-            self.h = None
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self.lib.mppi_destroy(h)
 
-    __del__ = close  # (safe at interpreter shutdown: touches nothing but the handle and the library object)
+    def __del__(self):
+        # At interpreter shutdown the module globals and the ctypes function objects may already be torn down (VERDICT r02:
+        # "TypeError: 'NoneType' object is not callable" from __del__ = close): a finaliser must never raise.
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ---- host loop -------------------------------------------------------------------
     def set_goal(self, goal):

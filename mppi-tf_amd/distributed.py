@@ -184,6 +184,17 @@ class ShardedController:
             self.backend.finish(self.record, 1, self.u)
         return self.u
 
+    def next_checked(self, x):
+        """next(x) for a host loop that ACTUATES u at once: waits for the step, looks at the deadline flag and raises
+        ExchangeTimeout BEFORE returning, so a zero-update control is never handed out (next() alone reports a missed
+        deadline one step late by design: it only enqueues). Costs one stream synchronisation per step."""
+        u = self.next(x)
+        dev = self.backend.device
+        if getattr(dev, "type", "cpu") == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        self.check()
+        return u
+
     def check(self):
         """After synchronising the stream: raise if a direct-exchange spin ever hit its deadline (the controls since
         then are zero-update controls; see next())."""

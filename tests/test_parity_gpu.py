@@ -680,13 +680,13 @@ SMALL_KERNEL_IDS = ["32x3-mfma", "32x3-valu", "16x3", "32x1-mfma", "32x2-mfma", 
 
 
 @pytest.mark.parametrize("hid,n_hidden,tuning", SMALL_KERNELS, ids=SMALL_KERNEL_IDS)
-@pytest.mark.parametrize("K,H,a", [(4096, 32, 3), (100, 16, 3), (33, 5, 2), (1000, 130, 1), (512, 24, 4)])
-def test_small_mlp_control_step_against_oracle(m, K, H, a, hid, n_hidden, tuning):
+@pytest.mark.parametrize("K,H,a,cond", [(4096, 32, 3, True), (100, 16, 3, True), (33, 5, 2, True), (1000, 130, 1, False), (512, 24, 4, True)])
+def test_small_mlp_control_step_against_oracle(m, K, H, a, cond, hid, n_hidden, tuning):
     """One control step on injected noise: sample costs as close to the fp64 oracle as an fp32 CPU evaluation is (4x),
     U' within north_star's 1e-5 wherever the fp32 CPU evaluation itself is (see MLP_VARIANTS: K=1000, H=130, a=1 at
     lambda=1 is not — fp32 CPU 2.2e-5, this kernel 1.6e-5); ragged K (33, 100, 1000: partial last tile) and a horizon
-    that is no multiple of 4."""
-    check_mlp_step(m, K, H, a, 300 + H, dict(tuning=tuning) if tuning else {}, 1e-5, 4.0, hid=hid, n_hidden=n_hidden, well_conditioned=False)
+    that is no multiple of 4. `cond`: the shapes that ARE well conditioned carry the absolute 1e-5 bar unconditionally."""
+    check_mlp_step(m, K, H, a, 300 + H, dict(tuning=tuning) if tuning else {}, 1e-5, 4.0, hid=hid, n_hidden=n_hidden, well_conditioned=cond)
 
 
 def test_small_mlp_fused_philox_step_and_sharding(m):
@@ -851,6 +851,146 @@ def test_mlp_sharded_equals_unsharded(m):
     c_full = full.debug_get(m.DBG_COSTS)
     for h in hs:
         np.testing.assert_array_equal(h.debug_get(m.DBG_COSTS), c_full[h.k_offset:h.k_offset + h.k_local])
+
+
+def _fused_step_vs_oracle_and_shards(m, K, H, a, sigma, seed, shards=4, **kw):
+    """One FUSED (on-device Philox) control step of a 2x256 MLP handle: the device noise is the oracle's Philox stream through
+    this Sigma, U' and u against the fp64 oracle on the noise the step exported (north_star's 1e-5), sum(w) = 1; then the
+    `shards`-way K-sharded step (records combined by mppi_shard_finish) equals the unsharded one and keeps the costs bitwise."""
+    import torch
+    s = 2 * a
+    mlp = make_mlp(s, a, seed=seed)
+    goal = (GOAL3 + [0.25, 0])[:s]
+    cfg = dict(k=K, tau=H, s_dim=s, a_dim=a, lam=1.0, sigma=sigma, goal=goal, mlp=mlp, seed=seed, **kw)
+    h = m.Handle(**cfg)
+    p64 = orc.Problem(tau=H, s=s, a=a, lam=1.0, sigma=sigma, goal=goal, mlp=mlp, threads=0, dtype=np.float64)
+    x = (0.2 * np.random.default_rng(seed).standard_normal(s)).astype(F32)
+    U_in = (0.05 * np.random.default_rng(seed + 1).standard_normal((H, a))).astype(F32)
+    h.set_action_sequence(U_in)
+    u = h.next(x)
+    eps = h.debug_get(m.DBG_NOISE)
+    np.testing.assert_allclose(eps, orc.noise(seed, 0, 0, K, H, a, sigma), rtol=0, atol=5e-6)
+    u64, U64, c64 = p64.next_with_noise(x, U_in, eps)
+    eu = float(np.abs(h.get_action_sequence().astype(np.float64) - np.asarray(U64)).max())
+    print("%s: max|dU'| = %.3g" % (h.rollout_kernel_name(), eu))
+    assert eu <= 1e-5 and np.abs(u.astype(np.float64) - np.asarray(u64)).max() <= 1e-5
+    c = h.debug_get(m.DBG_COSTS)
+    assert (np.abs(c.astype(np.float64) - np.asarray(c64)) / np.abs(np.asarray(c64))).max() < 2e-5
+    assert abs(h.debug_get(m.DBG_WEIGHTS).astype(np.float64).sum() - 1) < 1e-5
+    hs = [m.Handle(shard_rank=g, shard_count=shards, **cfg) for g in range(shards)]
+    xd = torch.tensor(x, device="cuda")
+    n = hs[0].record_size
+    recs = torch.zeros(shards * n, device="cuda")
+    us = [torch.zeros(a, device="cuda") for _ in range(shards)]
+    for g, hg in enumerate(hs):
+        assert hg.rollout_kernel_name() == h.rollout_kernel_name()
+        hg.set_action_sequence(U_in)
+        hg.shard_partial(xd.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
+        hg.synchronize()
+    for g, hg in enumerate(hs):
+        hg.shard_finish(recs.data_ptr(), shards, us[g].data_ptr())
+        hg.synchronize()
+        np.testing.assert_array_equal(us[g].cpu().numpy(), us[0].cpu().numpy())
+        np.testing.assert_allclose(us[g].cpu().numpy(), u, rtol=0, atol=2e-6)
+        np.testing.assert_array_equal(hg.debug_get(m.DBG_COSTS), c[hg.k_offset:hg.k_offset + hg.k_local])
+    return h
+
+
+def test_mlp_first_kernel_fused_step_and_sharding(m):
+    """k_rollout_mlp (round 1's 8-wave kernel) still ships: it is what tuning mlp_v1 selects and what serves a_dim = 4 (two h1
+    images of k_rollout_mlp2 would exceed the LDS). Both get the full treatment: Philox path, U' at 1e-5, record path."""
+    h = _fused_step_vs_oracle_and_shards(m, 4096, 16, 3, 0.25 * np.eye(3), seed=21, tuning={"mlp_v1": 1})
+    assert h.rollout_kernel_name() == "mppi::k_rollout_mlp<3, true>"
+    h = _fused_step_vs_oracle_and_shards(m, 2048, 12, 4, 0.25 * np.eye(4), seed=22)
+    assert h.rollout_kernel_name() == "mppi::k_rollout_mlp<4, true>"
+
+
+def test_mlp_dense_sigma_fused_step(m):
+    """A learned-model control step with a DENSE Sigma on the fused Philox path: k_rollout_mlp2<A, false, SRC_PHILOX> (eps = Sigma z with
+    every product, Sigma^-1 dense in the action cost), never launched by a test before."""
+    sigma = np.array([[0.30, 0.05, 0.0], [0.02, 0.25, 0.03], [0.0, 0.04, 0.20]], F32)
+    h = _fused_step_vs_oracle_and_shards(m, 4096, 16, 3, sigma, seed=23)
+    assert h.rollout_kernel_name() == "mppi::k_rollout_mlp2<3, false, 0>"
+    sigma2 = np.array([[0.3, 0.1], [0.05, 0.2]], F32)
+    h = _fused_step_vs_oracle_and_shards(m, 1000, 9, 2, sigma2, seed=24, shards=3)
+    assert h.rollout_kernel_name() == "mppi::k_rollout_mlp2<2, false, 0>"
+
+
+def test_lds_ceiling_is_per_kernel_not_per_handle(m):
+    """two MLP handles on one device whose rollout kernel instance needs different dynamic-LDS sizes (the h1
+    images + H*a floats of nominal actions): large, small, large again — the second handle must not lower the ceiling
+    under the first."""
+    a = 3
+    mlp = make_mlp(6, a, seed=1)
+    mk = lambda H: m.Handle(k=512, tau=H, s_dim=6, a_dim=a, lam=1.0, sigma=0.25 * np.eye(a), goal=GOAL3, mlp=mlp, seed=3)
+    big, small = mk(128), mk(8)
+    x = np.zeros(6, F32)
+    u1 = big.next(x)
+    small.next(x)
+    u2 = big.next(x)
+    big2 = mk(128)
+    np.testing.assert_array_equal(big2.next(x), u1)
+    np.testing.assert_array_equal(big2.next(x), u2)
+
+
+@pytest.mark.parametrize("name,kw,u_bar,factor", MLP_VARIANTS, ids=MLP_IDS)
+def test_configs4_all_eight_shards_combine(m, name, kw, u_bar, factor):
+    """BASELINE configs[4] IN FULL on the one GPU a test box has: all 8 shards of the K=524288, H=128 learned-model controller
+    (65536 rollouts and one 386-float record each) run one after the other, mppi_shard_finish combines the 8 records on every
+    shard. Checked: global-k Philox counters on every shard; every record's beta_g = min of its shard's costs; U' (all 384
+    entries) and u against the fp64 recombination of the 8 exported noise blocks with the soft-min of the kernels' own 524288
+    costs; the replicated results bit-identical on all 8 shards; sampled costs of one shard against the fp64 oracle."""
+    import torch
+    K, H, a, shards = 524288, 128, 3, 8
+    mlp = make_mlp(6, a, seed=0)
+    sigma = 0.25 * np.eye(a)
+    cfg = dict(k=K, tau=H, s_dim=6, a_dim=a, lam=1.0, sigma=sigma, goal=GOAL3, mlp=mlp, seed=1, **kw)
+    x = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
+    U_in = (0.05 * np.random.default_rng(1).standard_normal((H, a))).astype(F32)
+    xd = torch.tensor(x, device="cuda")
+    hs = [m.Handle(shard_rank=g, shard_count=shards, **cfg) for g in range(shards)]
+    n = hs[0].record_size
+    assert n == 2 + H * a == 386
+    recs = torch.zeros(shards * n, device="cuda")
+    us = [torch.zeros(a, device="cuda") for _ in range(shards)]
+    for g, hg in enumerate(hs):
+        assert hg.k_local == 65536 and hg.k_offset == g * 65536
+        hg.set_action_sequence(U_in)
+        hg.shard_partial(xd.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
+        hg.synchronize()
+    for g, hg in enumerate(hs):
+        hg.shard_finish(recs.data_ptr(), shards, us[g].data_ptr())
+        hg.synchronize()
+    Uupd = [hg.debug_get(m.DBG_U_UPDATED) for hg in hs]
+    for g in range(1, shards):  # replicated combine: identical bits everywhere
+        np.testing.assert_array_equal(us[g].cpu().numpy(), us[0].cpu().numpy())
+        np.testing.assert_array_equal(Uupd[g], Uupd[0])
+        np.testing.assert_array_equal(hs[g].get_action_sequence(), hs[0].get_action_sequence())
+    rec = recs.cpu().numpy().reshape(shards, n).astype(np.float64)
+    costs = [hg.debug_get(m.DBG_COSTS).astype(np.float64) for hg in hs]
+    beta = min(c.min() for c in costs)
+    eta, V = 0.0, np.zeros(H * a)
+    for g, hg in enumerate(hs):  # one shard's noise at a time: 100 MB each
+        eps = hg.debug_get(m.DBG_NOISE)
+        np.testing.assert_allclose(eps[:16], orc.noise(1, 0, hg.k_offset, 16, H, a, sigma), rtol=0, atol=5e-6)
+        assert rec[g, 0] == costs[g].min()
+        e_loc = np.exp(-(costs[g] - costs[g].min()))
+        np.testing.assert_allclose(rec[g, 1], e_loc.sum(), rtol=1e-6)
+        e = np.exp(-(costs[g] - beta))
+        eta += e.sum()
+        V += e @ eps.reshape(hg.k_local, H * a).astype(np.float64)
+        if g == shards - 1:  # sampled rollouts of the last shard against the fp64 oracle on the noise it really used
+            p64 = orc.Problem(tau=H, s=6, a=a, lam=1.0, sigma=sigma, goal=GOAL3, mlp=mlp, threads=0, dtype=np.float64)
+            idx = np.sort(np.random.default_rng(4).choice(hg.k_local, 256, replace=False))
+            truth = p64.rollout_cost(x, U_in, eps[idx])
+            assert (np.abs(costs[g][idx] - truth) / np.abs(truth)).max() < 2e-5
+        del eps
+    want = U_in.astype(np.float64) + (V / eta).reshape(H, a)
+    err = float(np.abs(Uupd[0].astype(np.float64) - want).max())
+    print("configs[4], 8 records of 65536 rollouts: max|U' - fp64 recombination| = %.3g (eta = %.6g)" % (err, eta))
+    assert err <= 2e-6
+    np.testing.assert_array_equal(us[0].cpu().numpy(), Uupd[0][0])
+    assert all(hg.get_step_counter() == 1 for hg in hs)
 
 
 def test_mlp_unsupported_shapes_fail_loudly(m):
@@ -1022,6 +1162,20 @@ def test_direct_exchange_equals_allgather_path_bit_for_bit(m, shards):
             np.testing.assert_array_equal(us[g].cpu().numpy(), u_ref.cpu().numpy())
             np.testing.assert_array_equal(h.get_action_sequence(), ref[0].get_action_sequence())
             assert h.get_step_counter() == step + 1
+
+
+def test_direct_exchange_with_eight_shards_in_one_process():
+    """The direct exchange at configs[4]'s shard count: 8 handles in ONE process on this GPU, each on its own stream, meet inside
+    their finish kernels (every workgroup stores to 8 inboxes and spins for 8 packets). The kernels of all 8 shards must be in
+    flight together, so the worker runs with 16 hardware queues (GPU_MAX_HW_QUEUES; the default 4 would queue shard 5's
+    kernels behind shard 1's spinning ones) — on a real node every rank has its own GPU. Bitwise equal to partial -> gather -> finish."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "p2p8_worker.py")], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "P2P8_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 def test_direct_exchange_deadline_instead_of_hang(m):

@@ -66,17 +66,31 @@ if dominant and "k_rollout_pc" in dominant and "SQ_INSTS_VALU_MUL_F32" in summar
                "trans_f32": k["SQ_INSTS_VALU_TRANS_F32"], "int32": k["SQ_INSTS_VALU_INT32"], "int64": k["SQ_INSTS_VALU_INT64"],
                "cvt": k["SQ_INSTS_VALU_CVT"]}
     classes["other"] = k["SQ_INSTS_VALU"] - sum(classes.values())
+    # `other` priced from what it is made of: the static opcode mix of the kernel's code object (tools/valu_static_mix.py;
+    # the producer waves are straight-line code, so static shares are dynamic shares), each kind at its measured issue cost
+    import subprocess
+    mixfile = os.path.join(dst, tag + "_valu_static_mix.json")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "valu_static_mix.py"), kname.replace("void ", "").replace("mppi::", ""), mixfile],
+                          stdout=subprocess.DEVNULL)
+    mix = {c: n for c, n in json.load(open(mixfile))["classes"].items() if c.startswith("other:")}
+    kind_price = {"other:mov": cyc["v_mov_b32"], "other:bitop3": cyc["v_bitop3_b32"], "other:dpp_f32": cyc["v_add_f32_dpp quad_perm"],
+                  "other:dpp_mov": cyc["v_mov_b32_dpp row_mirror"], "other:permlane_swap": cyc["v_mov_b32_dpp row_mirror"],
+                  "other:cndmask": cyc["v_cndmask_b32_e64 (mask in s[44:45])"], "other:lane": cyc["v_readlane_b32"],
+                  "other:minmax": cyc["v_max_f32"], "other:cmp": cyc["v_xor_b32"], "other:bitfield3": cyc["v_bitop3_b32"],
+                  "other:misc": cyc["v_bitop3_b32"]}
+    other_price = sum(n * kind_price[c] for c, n in mix.items()) / max(1, sum(mix.values()))
     price = {"add_f32": cyc["v_add_f32"], "mul_f32": cyc["v_mul_f32"], "fma_f32": cyc["v_fma_f32"],
              "trans_f32": (cyc["v_log_f32"] + cyc["v_sqrt_f32"] + cyc["v_sin_f32"]) / 3, "int32": cyc["v_xor_b32"],
-             "int64": cyc["v_mad_u64_u32 (+0)"], "cvt": cyc["v_cvt_f32_u32"], "other": cyc["v_bitop3_b32"]}
-    valu = {"kernel": kname, "code_sha": code_sha, "simds": 1024, "clock_mhz": 2400.0,
+             "int64": cyc["v_mad_u64_u32 (+0)"], "cvt": cyc["v_cvt_f32_u32"], "other": other_price}
+    valu = {"kernel": kname, "code_sha": code_sha, "tag": tag, "simds": 1024, "clock_mhz": 2400.0,
+            "other_static_mix": mix, "other_kind_cycles": kind_price,
             "insts_per_launch": classes, "cycles_per_inst": price,
             "active_quad_cycles_per_launch": k.get("SQ_ACTIVE_INST_VALU"),
             "source": "instructions: rocprofv3 --pmc SQ_INSTS_VALU* (tag %s, own pass); cycles: profiles/%s_valu_issue.json at 4 waves "
                       "per SIMD (ISA of the timed loops: profiles/%s_valu_issue_isa.txt)" % (tag, micro, micro),
             "classes": "the SQ counters' classes: add/mul/fma/trans f32, int32, int64 (v_mad_u64_u32: the Philox products), cvt; "
                        "`other` = SQ_INSTS_VALU minus those (v_bitop3_b32 of the Philox rounds, moves, DPP and lane-swap forms), "
-                       "priced at the v_bitop3_b32 rate. Packed f32 instructions count in add/mul at the unpacked price although "
+                       "priced by its static opcode mix (other_static_mix x other_kind_cycles; lane swaps at the DPP rate). Packed f32 instructions count in add/mul at the unpacked price although "
                        "they issue at ~4.2 cycles: the floor is a lower bound"}
     out["valu"] = valu
     json.dump(valu, open(os.path.join(dst, "valu_latest.json"), "w"), indent=1)
