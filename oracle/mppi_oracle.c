@@ -12,6 +12,7 @@
 #define REAL float
 #define REAL_EXP(x) expf(x)
 #include "mppi_oracle_impl.inc"
+#include "mppi_oracle_auv.inc"
 #undef SUF
 #undef REAL
 #undef REAL_EXP
@@ -20,6 +21,7 @@
 #define REAL double
 #define REAL_EXP(x) exp(x)
 #include "mppi_oracle_impl.inc"
+#include "mppi_oracle_auv.inc"
 #undef SUF
 #undef REAL
 #undef REAL_EXP

@@ -45,8 +45,12 @@ extern "C" {
 #define ORC_ACTION_COST_PY 1  /* ½[γ(uᵀΣ⁻¹u+2uᵀΣ⁻¹ε)+λ(1-1/υ)εᵀΣ⁻¹ε]  cost_base.py:114-170 */
 #define ORC_STATE_COST_QUADRATIC 0 /* (x-g)ᵀQ(x-g)                  cost_base.cpp:56-61, static_cost.py:40-63 */
 #define ORC_STATE_COST_ELLIPSE 1   /* 2D elliptic track               costs/elipse_cost.py:48-85 */
+#define ORC_STATE_COST_QUAT 2      /* StaticQuatCost                  costs/static_cost.py:73-159 */
+#define ORC_STATE_COST_ELLIPSE3D 3 /* ElipseCost3D                    costs/elipse_cost.py:101-246 */
 #define ORC_MODEL_POINT_MASS 0
 #define ORC_MODEL_MLP 1
+#define ORC_MODEL_AUV 2            /* Fossen AUVModel                 models/auv_model.py:282-562 */
+#define ORC_MODEL_NNAUV 3          /* NNAUVModel                      models/nn_model.py:215-304 */
 
 #define SUF(x) x##_f32
 #define REAL float

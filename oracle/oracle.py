@@ -18,13 +18,14 @@ _SO = os.path.join(_HERE, "libmppi_oracle.so")
 
 MAX_LAYERS = 8
 ACTION_COST_CPP, ACTION_COST_PY = 0, 1
-MODEL_POINT_MASS, MODEL_MLP = 0, 1
+MODEL_POINT_MASS, MODEL_MLP, MODEL_AUV, MODEL_NNAUV = 0, 1, 2, 3
+STATE_COST_QUADRATIC, STATE_COST_ELLIPSE, STATE_COST_QUAT, STATE_COST_ELLIPSE3D = 0, 1, 2, 3
 
 
 def build(force=False):
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
     srcs = [os.path.join(_HERE, f) for f in
-            ("mppi_oracle.c", "mppi_oracle_impl.inc", "mppi_oracle_decl.inc", "mppi_oracle.h", "Makefile")]
+            ("mppi_oracle.c", "mppi_oracle_impl.inc", "mppi_oracle_auv.inc", "mppi_oracle_decl.inc", "mppi_oracle.h", "Makefile")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -36,11 +37,19 @@ def build(force=False):
 def _structs(real):
     P = C.POINTER(real)
 
+    class Ellipse3d(C.Structure):
+        _fields_ = [("q", real * 4), ("axis", real * 3), ("mapping", real * 3), ("gv", real), ("mS", real), ("mV", real)]
+
+    class Auv(C.Structure):
+        _fields_ = [("mass", real), ("volume", real), ("density", real), ("gravity", real), ("dt", real), ("rk", C.c_int),
+                    ("cog", real * 3), ("cob", real * 3), ("mtot", real * 36), ("inv_mtot", real * 36),
+                    ("lin_damp", real * 36), ("lin_damp_fwd", real * 36), ("quad_damp", real * 6)]
+
     class Cost(C.Structure):
         _fields_ = [("s", C.c_int), ("a", C.c_int), ("action_cost_kind", C.c_int),
                     ("lam", real), ("gamma", real), ("upsilon", real),
                     ("goal", P), ("Q", P), ("sigma_inv", P),
-                    ("state_cost_kind", C.c_int), ("ellipse", real * 7)]
+                    ("state_cost_kind", C.c_int), ("ellipse", real * 7), ("e3", Ellipse3d)]
 
     class Mlp(C.Structure):
         _fields_ = [("s", C.c_int), ("a", C.c_int), ("n_layers", C.c_int),
@@ -50,9 +59,9 @@ def _structs(real):
 
     class Problem(C.Structure):
         _fields_ = [("cost", Cost), ("tau", C.c_int), ("model_kind", C.c_int),
-                    ("threads", C.c_int), ("A", P), ("B", P), ("mlp", Mlp)]
+                    ("threads", C.c_int), ("A", P), ("B", P), ("mlp", Mlp), ("auv", Auv)]
 
-    return Cost, Mlp, Problem
+    return Cost, Mlp, Problem, Ellipse3d, Auv
 
 
 class _Inst:
@@ -61,14 +70,15 @@ class _Inst:
     def __init__(self, lib, suffix, real, npdt):
         self.lib, self.suffix, self.real, self.npdt = lib, suffix, real, np.dtype(npdt)
         self.P = C.POINTER(real)
-        self.Cost, self.Mlp, self.Problem = _structs(real)
+        self.Cost, self.Mlp, self.Problem, self.Ellipse3d, self.Auv = _structs(real)
+        self.real = real
 
     def fn(self, name, restype=None):
         f = getattr(self.lib, name + self.suffix)
         f.restype = restype
         return f
 
-    def arr(self, x, shape=None):
+    def arr(self, x, shape=None):  # noqa: E301
         a = np.ascontiguousarray(np.asarray(x, dtype=self.npdt))
         if shape is not None:
             a = a.reshape(shape)
@@ -209,9 +219,13 @@ class Problem:
 
     def __init__(self, tau, s, a, dt=0.1, mass=1.0, lam=1.0, sigma=None, goal=None, Q=None,
                  gamma=1.0, upsilon=1.0, action_cost=ACTION_COST_CPP, mlp=None, threads=1,
-                 dtype=np.float32, ellipse=None):
+                 dtype=np.float32, ellipse=None, auv=None, nnauv=None, quat_cost=False, ellipse3d=None):
         """ellipse: dict(a, b, cx, cy, speed, m_state, m_vel) selects ElipseCost's state cost (elipse_cost.py:9-85)
-        instead of the quadratic one."""
+        instead of the quadratic one.
+        auv: the reference's AUVModel `parameters` dict (auv_model.py:85-245; + "dt") selects the Fossen model (s=13, a=6);
+        nnauv: an mlp dict with input width s+a-3 selects NNAUVModel (nn_model.py:215-304);
+        quat_cost: StaticQuatCost (static_cost.py:73-159): goal [13], Q [10,10] (or its diagonal);
+        ellipse3d: dict(normal, aVec, axis, speed, m_state, m_vel) selects ElipseCost3D (elipse_cost.py:101-246)."""
         I = self.I = _get(dtype)
         self.tau, self.s, self.a = tau, s, a
         self.sigma = I.arr(np.eye(a) if sigma is None else sigma, (a, a))
@@ -219,7 +233,7 @@ class Problem:
         if goal is None:  # controller_base.cpp:43-46: (1,0) per axis
             goal = np.tile([1.0, 0.0], s // 2)
         self.goal = I.arr(goal, (s,))
-        self.Q = _q_full(I, np.ones(s) if Q is None else Q, s)
+        self.Q = _q_full(I, np.ones(10 if quat_cost else s) if Q is None else Q, 10 if quat_cost else s)
         self.lam = float(lam)
         p = self.c = I.Problem()
         p.cost.s, p.cost.a, p.cost.action_cost_kind = s, a, action_cost
@@ -229,9 +243,20 @@ class Problem:
             p.cost.state_cost_kind = 1  # ORC_STATE_COST_ELLIPSE
             for i, key in enumerate(("a", "b", "cx", "cy", "speed", "m_state", "m_vel")):
                 p.cost.ellipse[i] = ellipse[key]
+        if quat_cost:
+            p.cost.state_cost_kind = STATE_COST_QUAT
+        if ellipse3d is not None:
+            p.cost.state_cost_kind = STATE_COST_ELLIPSE3D
+            self.R3 = ellipse3d_prepare(p.cost.e3, dtype=dtype, **ellipse3d)
         p.tau, p.threads = tau, threads
         self._keep = []
-        if mlp is None:
+        if auv is not None:
+            p.model_kind = MODEL_AUV
+            fill_auv(I, p.auv, auv, dt)
+        elif nnauv is not None:
+            p.model_kind = MODEL_NNAUV
+            self._fill_mlp(p.mlp, nnauv, n_in=s + a - 3)
+        elif mlp is None:
             p.model_kind = MODEL_POINT_MASS
             self.A, self.B = pm_matrices(dt, mass, s, a, dtype)
             p.A, p.B = I.ptr(self.A), I.ptr(self.B)
@@ -239,7 +264,7 @@ class Problem:
             p.model_kind = MODEL_MLP
             self._fill_mlp(p.mlp, mlp)
 
-    def _fill_mlp(self, m, mlp):
+    def _fill_mlp(self, m, mlp, n_in=None):
         I = self.I
         Ws, bs = mlp["W"], mlp["b"]
         m.s, m.a, m.n_layers = self.s, self.a, len(Ws)
@@ -248,7 +273,7 @@ class Problem:
             self._keep += [W, b]
             m.widths[l] = W.shape[1]
             m.W[l], m.b[l] = I.ptr(W), I.ptr(b)
-        n_in = self.s + self.a
+        n_in = self.s + self.a if n_in is None else n_in
         for name, default, n in (("xmean", 0.0, n_in), ("xstd", 1.0, n_in),
                                  ("ymean", 0.0, self.s), ("ystd", 1.0, self.s)):
             v = I.arr(mlp.get(name, np.full(n, default)), (n,))
@@ -281,6 +306,18 @@ class Problem:
         x, u, eps = I.arr(x, (-1, self.s)), I.arr(u, (self.a,)), I.arr(eps, (-1, self.a))
         out = np.zeros(x.shape[0], I.npdt)
         I.fn("orc_step_cost")(C.byref(self.c.cost), I.ptr(x), I.ptr(u), I.ptr(eps), x.shape[0], I.ptr(out))
+        return out
+
+    def model_next(self, x, v):
+        """one step x [k,s], v [k,a] -> x' [k,s] of whatever model the problem holds"""
+        I = self.I
+        x, v = I.arr(x, (-1, self.s)), I.arr(v, (-1, self.a))
+        out = np.zeros_like(x)
+        f = I.fn("orc_model_next")
+        for i in range(x.shape[0]):
+            xi, vi, oi = np.ascontiguousarray(x[i]), np.ascontiguousarray(v[i]), np.zeros(self.s, I.npdt)
+            f(C.byref(self.c), I.ptr(xi), I.ptr(vi), I.ptr(oi))
+            out[i] = oi
         return out
 
     def mlp_step(self, x, v):
@@ -386,3 +423,174 @@ def noise(seed, step, k_offset, k, tau, a, sigma):
     _lib.orc_noise(C.c_uint64(seed), C.c_uint64(step), C.c_uint64(k_offset), k, tau, a,
                    sigma.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
+
+
+# --------------------------------------------------------------------------- AUV family, quaternion / 3D-ellipse costs
+def skew(v):
+    """auv_model.py:7-36 skew_op"""
+    return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def auv_matrices(params):
+    """auv_model.py:186-262 in fp64 (the reference's dtype): -> dict(mtot, inv_mtot, lin_damp, lin_damp_fwd, quad_damp), matrices [6,6].
+    rigid-body mass = [[m I, -m S(cog)], [m S(cog), inertial]] (:247-251), total = rigid body + added mass (:253-254)."""
+    m = float(params["mass"])
+    cog = np.asarray(params["cog"], np.float64)
+    i = params["inertial"]
+    inertial = np.array([[i["ixx"], i["ixy"], i["ixz"]], [i["ixy"], i["iyy"], i["iyz"]], [i["ixz"], i["iyz"], i["izz"]]], np.float64)
+    lower = m * skew(cog)
+    rb = np.block([[m * np.eye(3), -lower], [lower, inertial]])
+    mtot = rb + np.asarray(params.get("Ma", np.zeros((6, 6))), np.float64)
+
+    def mat(key):
+        d = np.asarray(params.get(key, np.zeros(6)), np.float64)
+        return np.diag(d) if d.shape == (6,) else d
+    return dict(mtot=mtot, inv_mtot=np.linalg.inv(mtot), lin_damp=mat("linear_damping"), lin_damp_fwd=mat("linear_damping_forward_speed"),
+                quad_damp=np.asarray(params.get("quad_damping", np.zeros(6)), np.float64))
+
+
+def fill_auv(I, c, params, dt):
+    mats = auv_matrices(params)
+    c.mass, c.volume, c.density = params["mass"], params["volume"], params["density"]
+    c.gravity, c.dt, c.rk = 9.81, params.get("dt", dt), int(params.get("rk", 1))  # auv_model.py:236, :111-114
+    for i in range(3):
+        c.cog[i], c.cob[i] = params["cog"][i], params["cob"][i]
+    for key in ("mtot", "inv_mtot", "lin_damp", "lin_damp_fwd"):
+        flat = mats[key].ravel()
+        arr = getattr(c, key)
+        for i in range(36):
+            arr[i] = flat[i]
+    for i in range(6):
+        c.quad_damp[i] = mats["quad_damp"][i]
+
+
+class AuvModel:
+    """AUVModel's pieces (the reference's tests call them one by one, scripts/test.py:237-586)."""
+
+    def __init__(self, params, dt=0.1, dtype=np.float64):
+        I = self.I = _get(dtype)
+        self.c = I.Auv()
+        fill_auv(I, self.c, params, dt)
+
+    def b2i(self, quat):
+        I = self.I
+        q = I.arr(quat, (4,))
+        rot, T = np.zeros((3, 3), I.npdt), np.zeros((4, 3), I.npdt)
+        I.fn("orc_auv_b2i")(I.ptr(q), I.ptr(rot), I.ptr(T))
+        return rot, T
+
+    def restoring(self, quat):
+        I = self.I
+        rot, _ = self.b2i(quat)
+        g = np.zeros(6, I.npdt)
+        I.fn("orc_auv_restoring")(C.byref(self.c), I.ptr(rot), I.ptr(g))
+        return g
+
+    def damping(self, vel):
+        I = self.I
+        v = I.arr(vel, (6,))
+        D = np.zeros((6, 6), I.npdt)
+        I.fn("orc_auv_damping")(C.byref(self.c), I.ptr(v), I.ptr(D))
+        return D
+
+    def coriolis(self, vel):
+        I = self.I
+        v = I.arr(vel, (6,))
+        Cm = np.zeros((6, 6), I.npdt)
+        I.fn("orc_auv_coriolis")(C.byref(self.c), I.ptr(v), I.ptr(Cm))
+        return Cm
+
+    def state_dot(self, x, u):
+        I = self.I
+        x, u = I.arr(x, (13,)), I.arr(u, (6,))
+        out = np.zeros(13, I.npdt)
+        I.fn("orc_auv_state_dot")(C.byref(self.c), I.ptr(x), I.ptr(u), I.ptr(out))
+        return out
+
+    def step(self, x, u):
+        I = self.I
+        x, u = I.arr(x, (13,)), I.arr(u, (6,))
+        out = np.zeros(13, I.npdt)
+        I.fn("orc_auv_step")(C.byref(self.c), I.ptr(x), I.ptr(u), I.ptr(out))
+        return out
+
+
+def ellipse3d_prepare(e3, normal, aVec, axis, speed, m_state, m_vel, dtype=np.float64, center=None):
+    """fills the C struct e3; returns R [3,3] (elipse_cost.py:163-167 self.R). `center` is accepted and unused, as in the reference."""
+    I = _get(dtype)
+    n, a, ax = I.arr(normal, (3,)), I.arr(aVec, (3,)), I.arr(axis, (2,))
+    R = np.zeros((3, 3), I.npdt)
+    I.fn("orc_ellipse3d_prepare")(I.ptr(n), I.ptr(a), I.ptr(ax), I.real(speed), I.real(m_state), I.real(m_vel), C.byref(e3), I.ptr(R))
+    return R
+
+
+class Ellipse3D:
+    """ElipseCost3D's pieces (scripts/test.py:1164-1360)."""
+
+    def __init__(self, normal, aVec, axis, speed, m_state, m_vel, dtype=np.float64, center=None):
+        I = self.I = _get(dtype)
+        self.c = I.Ellipse3d()
+        self.R = ellipse3d_prepare(self.c, normal, aVec, axis, speed, m_state, m_vel, dtype)
+        self.q = np.array(list(self.c.q), I.npdt)
+
+    def position_error(self, p):
+        I = self.I
+        p = I.arr(p, (3,))
+        return I.fn("orc_ellipse3d_position_error", I.real)(C.byref(self.c), I.ptr(p))
+
+    def orientation_error(self, pose):
+        I = self.I
+        p = I.arr(pose, (7,))
+        return I.fn("orc_ellipse3d_orientation_error", I.real)(C.byref(self.c), I.ptr(p))
+
+    def velocity_error(self, vel):
+        I = self.I
+        v = I.arr(vel, (6,))
+        return I.fn("orc_ellipse3d_velocity_error", I.real)(C.byref(self.c), I.ptr(v))
+
+    def state_cost(self, x):
+        I = self.I
+        x = I.arr(x, (13,))
+        return I.fn("orc_state_cost_ellipse3d", I.real)(C.byref(self.c), I.ptr(x))
+
+
+def quat_rotate(p, q, dtype=np.float64):
+    I = _get(dtype)
+    p, q = I.arr(p, (3,)), I.arr(q, (4,))
+    o = np.zeros(3, I.npdt)
+    I.fn("orc_quat_rotate")(I.ptr(p), I.ptr(q), I.ptr(o))
+    return o
+
+
+def quat_multiply(q1, q2, dtype=np.float64):
+    I = _get(dtype)
+    q1, q2 = I.arr(q1, (4,)), I.arr(q2, (4,))
+    o = np.zeros(4, I.npdt)
+    I.fn("orc_quat_multiply")(I.ptr(q1), I.ptr(q2), I.ptr(o))
+    return o
+
+
+def quat_dist(x, goal, dtype=np.float64):
+    """StaticQuatCost.dist (static_cost.py:141-159): [10]"""
+    I = _get(dtype)
+    x, g = I.arr(x, (13,)), I.arr(goal, (13,))
+    d = np.zeros(10, I.npdt)
+    I.fn("orc_quat_dist")(I.ptr(x), I.ptr(g), I.ptr(d))
+    return d
+
+
+def nnauv_prepare_data(state, action, xmean=None, xstd=None):
+    """NNAUVModel.prepare_data (nn_model.py:289-293): concat(state[3:], action) normalised. [k,13],[k,6] -> [k,16]"""
+    st, ac = np.asarray(state, np.float64).reshape(-1, 13), np.asarray(action, np.float64).reshape(-1, 6)
+    X = np.concatenate([st[:, 3:], ac], axis=1)
+    return (X - (0.0 if xmean is None else xmean)) / (1.0 if xstd is None else xstd)
+
+
+def nnauv_prepare_training_data(state_t, state_t1, action, mask=None):
+    """NNAUVModel.prepare_training_data (nn_model.py:241-287), norm=False form: X = concat(stateT[3:], action), Y = stateT1 - stateT
+    in the frame whose origin is stateT's position (the masked components cancel in the difference)."""
+    st, st1 = np.asarray(state_t, np.float64).reshape(-1, 13), np.asarray(state_t1, np.float64).reshape(-1, 13)
+    ac = np.asarray(action, np.float64).reshape(-1, 6)
+    mask = np.array([1, 1, 1] + [0] * 10, np.float64) if mask is None else np.asarray(mask, np.float64).reshape(13)
+    t_from = mask * st
+    return np.concatenate([st[:, 3:], ac], axis=1), (st1 - t_from) - (st - t_from)

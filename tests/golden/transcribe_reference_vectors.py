@@ -4,7 +4,8 @@
 Every number below was transcribed by hand from the literals in the reference's unit tests
 (read as text; the reference cannot be compiled or imported here — SURVEY.md §8c):
   C++  test/test_controller.cpp, test/test_cost.cpp, test/test_model.cpp, test/test_utile.cpp
-  Py   scripts/test.py (TestPointMassModel, TestCost, TestStaticCost, TestElipseCost, TestController)
+  Py   scripts/test.py (TestPointMassModel, TestAUVModel, TestNNAUVModel, TestCost, TestStaticCost, TestElipseCost,
+       TestElipse3DCost, TestController)
 Where the reference test spells an expectation as an arithmetic expression of literals
 (e.g. `(dt*dt)/(2.f*m)`), the same expression is evaluated here in the same precision
 (np.float32 for the C++ tests, python float = fp64 for scripts/test.py) and the RESULT is stored.
@@ -273,6 +274,105 @@ def cost_py():
                          action_cost=base, static_cost=static))
 
 
+# ------------------------------------------------------------------ AUVModel, NNAUVModel, ElipseCost3D
+# scripts/test.py:237-262 TestAUVModel.setUp: the model parameters every test below uses (dt = 0.1, rk = 2)
+AUV_PARAMS = dict(mass=1000., volume=1.5, density=1000., height=1.6, length=2.5, width=1.5, cog=[0., 0., 0.], cob=[0., 0., 0.5],
+                  Ma=(500. * np.eye(6)).tolist(), linear_damping=[-70., -70., -700., -300., -300., -100.],
+                  quad_damping=[-740., -990., -1800., -670., -770., -520.], linear_damping_forward_speed=[1., 2., 3., 4., 5., 6.],
+                  inertial=dict(ixx=650., iyy=750., izz=550., ixy=1., ixz=2., iyz=3.), rk=2, dt=0.1)
+
+
+def model_auv():
+    # test_B2I_transform_and_jacobian (scripts/test.py:264-402): three pose quaternions (x, y, z, w), the rotation matrices
+    # "from lib" (literals, 7 digits), and T_q = 0.5 [[w,-z,y],[z,w,-x],[-y,x,w],[-x,-y,-z]] (the test's exp_TB2Iquat rows
+    # written in the model's row order rxt, ryt, rzt, rwt — auv_model.py:388-396; the test fills row 0 with (-x,-y,-z), which
+    # is the model's LAST row: the test as written does not hold against the model it tests; the model is the specification)
+    quats = [[0., 0., 0., 1.],
+             [0.0438308910967523, 0.25508068761447, 0.171880267220619, 0.950510320581509],
+             [-0.111618880991033, 0.633022223770408, 0.492403876367579, 0.586824089619078]]
+    rot_from_lib = [[[1., 0., 0.], [0., 1., 0.], [0., 0., 1.]],
+                    [[0.8107820, -0.3043871, 0.4999810], [0.3491088, 0.9370720, 0.0043632], [-0.4698463, 0.1710101, 0.8660254]],
+                    [[-0.2863574, -0.7192234, 0.6330222], [0.4365945, 0.4901593, 0.7544065], [-0.8528685, 0.4924039, 0.1736482]]]
+    # test_restoring (:404-487): two poses given as quaternions AND as roll/pitch/yaw; the expectation is built from the Euler
+    # rotation matrix: W = m g, B = V rho g, f_g = R^T (0,0,-W), f_b = R^T (0,0,B), g = -(f_g + f_b, r_g x f_g + r_b x f_b)
+    rq = [[-0.1127657, 0.8086476, 0.0328141, 0.5764513], [-0.4582488, 0.4839407, 0.0503092, 0.7438269]]
+    rpy = np.array([[13., 110., 25.], [280., 50., 325.]]) * (np.pi / 180.)
+    W, B = 1000. * 9.81, 1.5 * 1000. * 9.81
+    rest, rots = [], []
+    for roll, pitch, yaw in rpy:
+        cr, sr, cp, sp, cy, sy = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+        R = np.array([[cy * cp, -sy * cr + cy * sp * sr, sy * sr + cy * cr * sp],
+                      [sy * cp, cy * cr + sr * sp * sy, -cy * sr + sp * sy * cr],
+                      [-sp, cp * sr, cp * cr]])
+        fbg, fbb = R.T @ np.array([0., 0., -W]), R.T @ np.array([0., 0., B])
+        mbg, mbb = np.cross(AUV_PARAMS["cog"], fbg), np.cross(AUV_PARAMS["cob"], fbb)
+        rest.append(np.concatenate([-(fbb + fbg), -(mbb + mbg)]))
+        rots.append(R)
+    # test_damping (:489-503): D = -diag(lin) - v0 diag(fwd) + (-diag(quad)) |v| (the last product broadcast over the rows)
+    dvel = [[1., 1., 1., 1., 1., 1.], [2., 1.5, 1., 3., 3.5, 2.5], [-2., -1.5, -1., -3., -3.5, -2.5]]
+    damp = []
+    for v in dvel:
+        D = -np.diag(AUV_PARAMS["linear_damping"]) - v[0] * np.diag(AUV_PARAMS["linear_damping_forward_speed"])
+        damp.append(D + (-np.diag(AUV_PARAMS["quad_damping"])) * np.abs(np.array(v))[:, None])
+    # test_corrolis (:505-539): vel = (1,1,1,0,0,0); C = C_rb + C_a with m = 1000, Ma = 500 I
+    cv = [1., 1., 1., 0., 0., 0.]
+    m, Mav = 1000., -(500. * np.array(cv))
+    crb = np.array([[0., 0., 0., 0., m * cv[2], -m * cv[1]], [0., 0., 0., -m * cv[2], 0., m * cv[0]], [0., 0., 0., m * cv[1], -m * cv[0], 0.],
+                    [0., m * cv[2], -m * cv[1], 0., 0., 0.], [-m * cv[2], 0., m * cv[0], 0., 0., 0.], [m * cv[1], -m * cv[0], 0., 0., 0., 0.]])
+    ca = np.array([[0., 0., 0., 0., -Mav[2], Mav[1]], [0., 0., 0., Mav[2], 0., -Mav[0]], [0., 0., 0., -Mav[1], Mav[0], 0.],
+                   [0., -Mav[2], Mav[1], 0., -Mav[5], Mav[4]], [Mav[2], 0., -Mav[0], Mav[5], 0., -Mav[3]], [-Mav[1], Mav[0], 0., -Mav[4], Mav[3], 0.]])
+    # test_step1_k1 / test_step1_k5 (:541-586) only print: inputs kept (no expectation in the reference)
+    step_states = [[0., 0., 0., 0., 0., 0., 1., 0., 0., 0., 0., 0., 0.], [1., 1., 1., 0., 0., 0., 1., 0.1, 2., 2., 1., 2., 3.],
+                   [0., 2., 1., 0.2, 0.3, 0., 1., -1., -1., -1., -1., -1., -1.], [5., 0.2, 0., 1.2, 0., 3.1, 1., 0., 0., 0., 0., 0., 0.],
+                   [0., 0., 0., 0., 0., 0., 1., 1., 1., 1., 1., 1., 1.]]
+    step_actions = [[1.] * 6, [1.] * 6, [-1.] * 6, [2.] * 6, [-1.] * 6]
+    dump("model_auv", dict(source="scripts/test.py:237-586 TestAUVModel", tol="assertAllClose rtol=atol=1e-6", params=AUV_PARAMS,
+                           b2i=dict(quat=quats, rot_from_lib=rot_from_lib),
+                           restoring=dict(quat=rq, exp_rot=rots, exp_restoring=rest),
+                           damping=dict(vel=dvel, exp=damp), coriolis=dict(vel=cv, exp=crb + ca),
+                           step_inputs=dict(state=step_states, action=step_actions)))
+
+
+def model_nnauv():
+    # scripts/test.py:587-684 TestNNAUVModel (identity normalisation: Xmean = Ymean = 0, Xstd = Ystd = 1)
+    t1 = dict(state_t=[[1., 1., .5, 0., 0., 0., 1., 1., 0., .25, 0., 0., 0.]], state_t1=[[2., 1., .75, 0., 0., 0., 1., 3., 3.5, 4.5, 5.5, 6.5, 7.5]],
+              action=[[1., 2., 3., 4., 5., 6.]],
+              exp_x=[[0., 0., 0., 1., 1., 0., .25, 0., 0., 0., 1., 2., 3., 4., 5., 6.]],
+              exp_y=[[1., 0., .25, 0., 0., 0., 0., 2., 3.5, 4.25, 5.5, 6.5, 7.5]])
+    n1 = dict(state=[[float(i) for i in range(13)]], action=[[13., 14., 15., 16., 17., 18.]], exp=[[float(i) for i in range(3, 19)]])
+    st = [[float(i) for i in range(13)], [18. - i for i in range(13)], [-float(i) for i in range(13)], [-(18. - i) for i in range(13)],
+          [-(i + .5) for i in range(13)], [i + .5 for i in range(13)]]
+    ac = [[13., 14., 15., 16., 17., 18.], [5., 4., 3., 2., 1., 0.], [-13., -14., -15., -16., -17., -18.], [-5., -4., -3., -2., -1., -0.],
+          [-13.5, -14.5, -15.5, -16.5, -17.5, -18.5], [13.5, 14.5, 15.5, 16.5, 17.5, 18.5]]
+    exp = [[float(i) for i in range(3, 19)], [15. - i for i in range(16)], [-float(i) for i in range(3, 19)], [-(15. - i) for i in range(16)],
+           [-(i + .5) for i in range(3, 19)], [i + .5 for i in range(3, 19)]]
+    dump("model_nnauv", dict(source="scripts/test.py:587-684 TestNNAUVModel", training_n1=t1, prepare_n1=n1,
+                             prepare_n6=dict(state=st, action=ac, exp=exp)))
+
+
+def cost_elipse3d():
+    # scripts/test.py:1164-1360 TestElipse3DCost: axis = (2, 1.5), speed = 1, m_state = m_vel = 1, lambda = gamma = upsilon = 1
+    base = dict(axis=[2., 1.5], speed=1., m_state=1., m_vel=1.)
+    prep = [dict(normal=[0., 0., 1.], aVec=[1., 0., 0.], center=[0., 0., 0.], exp_R=np.eye(3)),
+            dict(normal=[0., 1., 1.], aVec=[1., 0., 0.], center=[0., 1., -2.], exp_R=np.array([[1., 0., 0.], [0., .5, -.5], [0., .5, .5]]).T)]
+    plane = dict(normal=[0., 1., 1.], aVec=[1., 0., 0.], center=[0., 1., -2.])
+    pos = dict(position=[[.1, .4, .2], [1., 1., -2.], [2., 1., 0.]], exp=[0.8863888888888889, 3.6944444444444446, 0.4444444444444444])
+    ori = dict(pose=[[.1, .4, .2, 0., 0., 0., 1.], [1., 1., -2., 0.48038446, 0.32025631, 0.16012815, 0.80064077],
+                     [2., 1., -2., 0.20628425, -0.30942637, -0.92827912, 0.]],
+               exp=[3.0018837793006306, 2.4098026419889416, 1.1216620246733544])
+    vel = dict(velocity=[[.1, .4, .2, 0., 0., 0.], [1., 1., -2., .3, .2, .1], [2., 1., -2., .2, -.3, -.9]],
+               exp=[abs(0.21 - 1), abs(6 - 1), abs(9 - 1)])
+    # test_state_cost (:1317-1338) has no expectation; inputs kept
+    states = [[.1, .4, .2, 0., 0., 0., 1., .3, .7, 2., 1., 2.4, 5.], [1., 1., -2., .3, .2, .1, .5, .4, 2.7, 2., 0., 0., 0.],
+              [2., 1., -2., .2, -.3, -.9, 0., 2.3, 1.7, 0., .1, .4, .01]]
+    # test_tf_rot (:1340-1359): the two tensorflow_graphics quaternion calls the cost makes
+    tf_rot = dict(q=[0., 0.7071068, 0., 0.7071068], position=[1., 2., 3.], quat=[0.7071068, 0., 0., 0.7071068],
+                  exp_pos=[3., 2., -1.], exp_quat=[.5, .5, -.5, .5])
+    dump("cost_elipse3d", dict(source="scripts/test.py:1164-1360 TestElipse3DCost", tol="assertAllClose rtol=atol=1e-6", base=base,
+                               prep_const=prep, plane=plane, position_error=pos, orientation_error=ori, velocity_error=vel,
+                               state_cost_inputs=states, tf_rot=tf_rot))
+
+
 if __name__ == "__main__":
     controller()
     cost_cpp()
@@ -281,4 +381,7 @@ if __name__ == "__main__":
     blockdiag()
     cost_py()
     cost_elipse()
+    model_auv()
+    model_nnauv()
+    cost_elipse3d()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".json")))

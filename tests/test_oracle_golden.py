@@ -260,3 +260,150 @@ def test_mlp_step_restatement_against_numpy(hid, n_hidden):
             if l < n_hidden:
                 h = np.maximum(h, 0)
         np.testing.assert_allclose(p.mlp_step(x, v), x + (h * mlp["ystd"] + mlp["ymean"]), rtol=1e-12, atol=1e-13)
+
+
+# ======================================================================= SURVEY §8f-4: AUV family, quaternion / 3D-ellipse costs
+# The oracle's restatement of AUVModel / NNAUVModel / StaticQuatCost / ElipseCost3D against the reference's own literals
+# (scripts/test.py TestAUVModel :237-586, TestNNAUVModel :587-684, TestElipse3DCost :1164-1360), fp64 like the Python reference,
+# at tf.test's assertAllClose tolerance (rtol = atol = 1e-6).
+CLOSE = dict(rtol=1e-6, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def auv_golden():
+    return load_golden("model_auv")
+
+
+def test_auv_body_to_inertial_rotation(auv_golden):
+    mdl = orc.AuvModel(auv_golden["params"], dtype=np.float64)
+    for q, R in zip(auv_golden["b2i"]["quat"], auv_golden["b2i"]["rot_from_lib"]):
+        rot, T = mdl.b2i(q)
+        np.testing.assert_allclose(rot, R, **CLOSE)
+        x, y, z, w = q  # auv_model.py:388-396: rows rxt, ryt, rzt, rwt, times 0.5
+        np.testing.assert_allclose(T, 0.5 * np.array([[w, -z, y], [z, w, -x], [-y, x, w], [-x, -y, -z]]), rtol=0, atol=0)
+        # the Jacobian maps body rates to quaternion rates: q . qdot = 0 for any angular velocity
+        assert abs(np.dot(np.array(q)[[0, 1, 2]], T[:3] @ [0.3, -0.2, 0.5]) + q[3] * (T[3] @ [0.3, -0.2, 0.5])) < 1e-15
+
+
+def test_auv_restoring_forces(auv_golden):
+    mdl = orc.AuvModel(auv_golden["params"], dtype=np.float64)
+    g = auv_golden["restoring"]
+    for q, R, exp in zip(g["quat"], g["exp_rot"], g["exp_restoring"]):
+        np.testing.assert_allclose(mdl.b2i(q)[0], R, **CLOSE)
+        np.testing.assert_allclose(mdl.restoring(q), exp, **CLOSE)
+
+
+def test_auv_damping_and_coriolis(auv_golden):
+    mdl = orc.AuvModel(auv_golden["params"], dtype=np.float64)
+    for v, D in zip(auv_golden["damping"]["vel"], auv_golden["damping"]["exp"]):
+        np.testing.assert_allclose(mdl.damping(v), D, **CLOSE)
+    np.testing.assert_allclose(mdl.coriolis(auv_golden["coriolis"]["vel"]), auv_golden["coriolis"]["exp"], **CLOSE)
+
+
+def test_auv_step_properties(auv_golden):
+    """The reference's step tests only print (scripts/test.py:541-586): the step is pinned as the composition of the pinned
+    pieces. Properties: unit quaternion out; at rest with neutral buoyancy and no force nothing moves; rk1 = x + dt f(x);
+    fp32 instantiation within fp32 of fp64."""
+    P = dict(auv_golden["params"])
+    m64, m32 = orc.AuvModel(P, dtype=np.float64), orc.AuvModel(P, dtype=np.float32)
+    for x, u in zip(auv_golden["step_inputs"]["state"], auv_golden["step_inputs"]["action"]):
+        xn = m64.step(x, u)
+        assert abs(np.linalg.norm(xn[3:7]) - 1) < 1e-12
+        k1 = m64.state_dot(x, u)
+        xs = np.asarray(x) + 0.1 * k1
+        heun = np.asarray(x) + 0.05 * (k1 + m64.state_dot(xs, u))
+        heun[3:7] /= np.linalg.norm(heun[3:7])
+        np.testing.assert_allclose(xn, heun, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(m32.step(x, u), xn, rtol=2e-5, atol=2e-5)
+    neutral = dict(P, volume=1.0, cob=[0., 0., 0.], rk=1)  # W = B, no righting moment
+    x0 = [1., 2., 3., 0., 0., 0., 1.] + [0.] * 6
+    np.testing.assert_allclose(orc.AuvModel(neutral).step(x0, [0.] * 6), x0, rtol=0, atol=1e-15)
+    e1 = orc.AuvModel(dict(P, rk=1))
+    x, u = auv_golden["step_inputs"]["state"][1], auv_golden["step_inputs"]["action"][1]
+    eul = np.asarray(x) + 0.1 * e1.state_dot(x, u)
+    eul[3:7] /= np.linalg.norm(eul[3:7])
+    np.testing.assert_allclose(e1.step(x, u), eul, rtol=1e-12, atol=1e-12)
+
+
+def test_nnauv_data_preparation():
+    g = load_golden("model_nnauv")
+    t = g["training_n1"]
+    X, Y = orc.nnauv_prepare_training_data(t["state_t"], t["state_t1"], t["action"])
+    np.testing.assert_allclose(X, t["exp_x"], **CLOSE)
+    np.testing.assert_allclose(Y, t["exp_y"], **CLOSE)
+    for key in ("prepare_n1", "prepare_n6"):
+        np.testing.assert_allclose(orc.nnauv_prepare_data(g[key]["state"], g[key]["action"]), g[key]["exp"], **CLOSE)
+
+
+def test_nnauv_step_is_state_plus_denormalised_network_output():
+    """NNAUVModel.build_step_graph (nn_model.py:215-239): x' = x + nn(norm(concat(x[3:], u)))*Ystd + Ymean, against numpy."""
+    rng = np.random.default_rng(0)
+    dims = [16, 32, 32, 32, 13]
+    mlp = dict(W=[rng.standard_normal((dims[i], dims[i + 1])) / 4 for i in range(4)], b=[rng.standard_normal(dims[i + 1]) / 10 for i in range(4)],
+               xmean=rng.standard_normal(16) / 10, xstd=1 + rng.random(16), ymean=rng.standard_normal(13) / 10, ystd=1 + rng.random(13))
+    p = orc.Problem(tau=4, s=13, a=6, sigma=np.eye(6), goal=np.zeros(13), nnauv=mlp, dtype=np.float64)
+    x, u = rng.standard_normal((5, 13)), rng.standard_normal((5, 6))
+    h = (orc.nnauv_prepare_data(x, u, mlp["xmean"], mlp["xstd"]))
+    for l in range(4):
+        h = h @ mlp["W"][l] + mlp["b"][l]
+        if l < 3:
+            h = np.maximum(h, 0)
+    np.testing.assert_allclose(p.model_next(x, u), x + h * mlp["ystd"] + mlp["ymean"], rtol=1e-12, atol=1e-12)
+
+
+def test_elipse3d_cost_pieces():
+    g = load_golden("cost_elipse3d")
+    b = g["base"]
+    for pc in g["prep_const"]:
+        e = orc.Ellipse3D(pc["normal"], pc["aVec"], b["axis"], b["speed"], b["m_state"], b["m_vel"])
+        np.testing.assert_allclose(e.R, pc["exp_R"], **CLOSE)
+    pl = g["plane"]
+    e = orc.Ellipse3D(pl["normal"], pl["aVec"], b["axis"], b["speed"], b["m_state"], b["m_vel"])
+    np.testing.assert_allclose([e.position_error(p) for p in g["position_error"]["position"]], g["position_error"]["exp"], **CLOSE)
+    np.testing.assert_allclose([e.orientation_error(p) for p in g["orientation_error"]["pose"]], g["orientation_error"]["exp"], **CLOSE)
+    np.testing.assert_allclose([e.velocity_error(v) for v in g["velocity_error"]["velocity"]], g["velocity_error"]["exp"], **CLOSE)
+    t = g["tf_rot"]
+    np.testing.assert_allclose(orc.quat_rotate(t["position"], t["q"]), t["exp_pos"], **CLOSE)
+    np.testing.assert_allclose(orc.quat_multiply(t["q"], t["quat"]), t["exp_quat"], **CLOSE)
+    # state_cost = mS*position + mS*orientation + mV*velocity of the pose taken into the plane frame (no reference expectation)
+    for x in g["state_cost_inputs"]:
+        pose = np.concatenate([orc.quat_rotate(x[:3], e.q), orc.quat_multiply(e.q, x[3:7])])
+        want = b["m_state"] * e.position_error(pose[:3]) + b["m_state"] * e.orientation_error(pose) + b["m_vel"] * e.velocity_error(x[7:])
+        assert abs(e.state_cost(x) - want) < 1e-12
+    # for an ORTHONORMAL plane basis (the reference's test plane has a normal of length sqrt(2): its R is no rotation and
+    # its q no unit quaternion — restated as is) the plane quaternion is a unit quaternion reproducing R
+    e = orc.Ellipse3D([0., np.sin(0.4), np.cos(0.4)], [1., 0., 0.], b["axis"], 1., 1., 1.)
+    assert abs(np.linalg.norm(e.q) - 1) < 1e-12
+    for v in np.eye(3):
+        np.testing.assert_allclose(orc.quat_rotate(v, e.q), e.R @ v, rtol=0, atol=1e-12)
+
+
+def test_static_quat_cost_dist_and_value():
+    """StaticQuatCost (static_cost.py:73-159; no reference test): dist = (dp, 2 acos<q, g_q>, dv) [10], cost = d^T Q d."""
+    goal = [1., 2., -10., 0., 0., 0., 1.] + [0.] * 6
+    s = np.sin(0.3), np.cos(0.3)
+    x = [0., 2.5, -9., 0., 0., s[0], s[1], 1., 0., -1., 0.1, 0.2, 0.3]
+    d = orc.quat_dist(x, goal)
+    np.testing.assert_allclose(d, [-1., .5, 1., 0.6, 1., 0., -1., .1, .2, .3], rtol=1e-12, atol=1e-12)
+    Q = np.diag([1000.] * 3 + [100.] + [1.] * 6)
+    p = orc.Problem(tau=2, s=13, a=6, sigma=np.eye(6), goal=goal, Q=Q, quat_cost=True, dtype=np.float64)
+    np.testing.assert_allclose(p.state_cost([x]), [d @ Q @ d], rtol=1e-12)
+    p32 = orc.Problem(tau=2, s=13, a=6, sigma=np.eye(6), goal=goal, Q=np.diag(Q), quat_cost=True)
+    np.testing.assert_allclose(p32.state_cost([x]), [d @ Q @ d], rtol=2e-6)
+
+
+def test_auv_rollout_through_the_oracle_problem(auv_golden):
+    """The AUV model and the quaternion cost inside the full path (rollout -> update -> shift): finite, deterministic, and the
+    fp32 instantiation tracks fp64."""
+    H, K = 6, 64
+    goal = [1., 2., -3., 0., 0., 0., 1.] + [0.] * 6
+    kw = dict(tau=H, s=13, a=6, lam=1.0, sigma=200. * np.eye(6), goal=goal, Q=[100.] * 3 + [10.] * 4 + [1.] * 6, auv=auv_golden["params"])
+    p64, p32 = orc.Problem(dtype=np.float64, **kw), orc.Problem(**kw)
+    rng = np.random.default_rng(1)
+    eps = (200. * rng.standard_normal((K, H, 6))).astype(np.float32)
+    x0 = np.array([0., 0., 0., 0., 0., 0., 1.] + [0.] * 6, np.float32)
+    U = np.zeros((H, 6), np.float32)
+    u64, U64, c64 = p64.next_with_noise(x0, U, eps)
+    u32, U32, c32 = p32.next_with_noise(x0, U, eps)
+    assert np.isfinite(c64).all() and (np.abs(c32 - c64) / np.abs(c64)).max() < 1e-4
+    assert np.abs(np.asarray(U32, np.float64) - U64).max() < 1e-2 * np.abs(U64).max() + 1e-3
