@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 2 /* 2: mppi_config gained state_cost_kind / ellipse; transition log, tuning, kernel-name entry points */
+#define MPPI_ABI_VERSION 3 /* 3: the 13-state AUV family (MPPI_MODEL_AUV / _NN_AUV, mppi_auv_desc), StaticQuatCost / ElipseCost3D state costs,
+                              mppi_auv_pieces, the learner (mppi_learner_*); 2: state_cost_kind / ellipse, transition log, tuning */
 #define MPPI_MAX_S 32  /* largest state dimension  */
 #define MPPI_MAX_A 16  /* largest action dimension */
 
@@ -50,14 +51,22 @@ typedef enum {
 } mppi_status;
 
 enum { MPPI_MODEL_POINT_MASS = 0, /* x' = A x + (B/m) v, src/model_base.cpp:53-82 */
-       MPPI_MODEL_MLP = 1 };      /* x' = x + denorm(MLP(norm([x;v]))), nn_model.py:215-304 convention */
+       MPPI_MODEL_MLP = 1,        /* x' = x + denorm(MLP(norm([x;v]))), nn_model.py:215-304 convention, point-mass state (s = 2a) */
+       MPPI_MODEL_AUV = 2,        /* Fossen 6-DOF AUVModel, s = 13 (pos, quat xyzw, lin vel, ang vel), a = 6: models/auv_model.py:282-562 */
+       MPPI_MODEL_NN_AUV = 3 };   /* NNAUVModel: x' = x + denorm(nn(norm(concat(x[3:], u)))), s = 13, a = 6, nn input s+a-3 = 16,
+                                     Dense(16|32, relu) x 1..3 + Dense(13): models/nn_model.py:179-304 */
 
 enum { MPPI_ACTION_COST_CPP = 0,  /* λ uᵀΣ⁻¹ε                          src/cost_base.cpp:63-68   */
        MPPI_ACTION_COST_PY = 1 }; /* ½[γ(uᵀΣ⁻¹u+2uᵀΣ⁻¹ε)+λ(1-1/υ)εᵀΣ⁻¹ε]  costs/cost_base.py:114-170 */
 
 enum { MPPI_STATE_COST_QUADRATIC = 0, /* (x-g)ᵀQ(x-g)   src/cost_base.cpp:56-61, costs/static_cost.py:40-63          */
-       MPPI_STATE_COST_ELLIPSE = 1 }; /* 2D elliptic track, state (x, vx, y, vy, ..): m_state·|((x-cx)/a)²+((y-cy)/b)²-1|
+       MPPI_STATE_COST_ELLIPSE = 1,   /* 2D elliptic track, state (x, vx, y, vy, ..): m_state·|((x-cx)/a)²+((y-cy)/b)²-1|
                                          + m_vel·(sqrt(vx²+vy²)-speed)²                 costs/elipse_cost.py:9-85       */
+       MPPI_STATE_COST_QUAT = 2,      /* StaticQuatCost (s = 13): d = (pos-g, 2·acos<quat, g_quat>, vel-g) [10], dᵀ Q d with
+                                         Q = cfg.quat_Q [10*10], goal = cfg.goal [13]      costs/static_cost.py:73-159  */
+       MPPI_STATE_COST_ELLIPSE3D = 3 };/* ElipseCost3D (s = 13): the pose taken into the ellipse's plane frame, then
+                                         mS·|Σ(p_i/axis_i)²-1| + mS·angle(pose, tangent) + mV·||v|²-speed²|
+                                         with cfg.ellipse3d                                costs/elipse_cost.py:101-246 */
 
 /* mppi_config.flags */
 enum { MPPI_FLAG_UPSILON_SCALES_NOISE = 1, /* Py build_noise: eps = (υΣ)·z while the cost keeps Σ⁻¹ of the
@@ -86,6 +95,20 @@ typedef struct {
     const float *ymean, *ystd; /* [s]   output de-normalisation, NULL -> 0 / 1 (nn_model.py:295-297) */
 } mppi_mlp_desc;
 
+/* AUVModel's `parameters` (models/auv_model.py:85-245; config/models/rexrov2.default.yaml). Matrices [6*6] row-major; a
+ * diagonal given in the reference's 6-vector form is expanded by the caller. NULL matrix = zeros. */
+typedef struct {
+    float mass, volume, density;
+    float gravity;             /* 0 -> 9.81 (auv_model.py:236) */
+    float cog[3], cob[3];      /* centre of gravity / buoyancy in the body frame */
+    float inertial[6];         /* ixx, iyy, izz, ixy, ixz, iyz */
+    const float *added_mass;                    /* Ma [36] */
+    const float *linear_damping;                /* [36] */
+    const float *linear_damping_forward_speed;  /* [36] */
+    const float *quad_damping;                  /* [6]  */
+    int32_t rk;                /* 1 Euler, 2 Heun, 4 the reference's rk4 expression (auv_model.py:282-306) */
+} mppi_auv_desc;
+
 /* Everything the reference hard-codes in ControllerBase's constructor
  * (controller_base.cpp:23-71) or reads from its config YAML files, as one POD block. */
 typedef struct {
@@ -111,6 +134,11 @@ typedef struct {
     int32_t state_cost_kind;  /* MPPI_STATE_COST_*; 0 = the quadratic cost (goal, Q)       */
     const float *ellipse;     /* MPPI_STATE_COST_ELLIPSE: [7] a, b, cx, cy, speed, m_state, m_vel (ElipseCost's
                                  constructor arguments, elipse_cost.py:10-46); needs s_dim >= 4 */
+    const mppi_auv_desc *auv; /* MPPI_MODEL_AUV only */
+    const float *quat_Q;      /* MPPI_STATE_COST_QUAT: Q [10*10] row-major (static_cost.py:92-100) */
+    const float *ellipse3d;   /* MPPI_STATE_COST_ELLIPSE3D: [11] normal[3], aVec[3], axis a, b, speed, mState, mVel
+                                 (ElipseCost3D's constructor arguments, elipse_cost.py:102-140; `center` is stored by the
+                                 reference and never used) */
 } mppi_config;
 
 /* ---- library ------------------------------------------------------------------------- */
@@ -185,6 +213,16 @@ mppi_status mppi_debug_get(mppi_handle *h, int what, float *out, size_t n);
  * model_base.hpp:74-75); v is [k,a]. Any output may be NULL. out_free is [kx,s]. */
 mppi_status mppi_model_step(mppi_handle *h, const float *x, int kx, const float *v, int k,
                             float *out_free, float *out_action, float *out_next);
+/* AUVModel's intermediate quantities, as the reference's tests look at them one by one (scripts/test.py:264-539): for k
+ * (state x[13], action u[6]) pairs -> out[k*124] = rotBtoI[9] | TBtoIquat[12] | C(nu)nu[6] | D(nu)nu[6] | g(eta)[6] | state_dot[13] |
+ * D(nu)[36] | C(nu)[36]
+ * (auv_model.py:353-398 body2inertial_transform, :512-545, :482-510, :450-480, :308-351). MPPI_MODEL_AUV handles only. */
+mppi_status mppi_auv_pieces(mppi_handle *h, const float *x, const float *u, int k, float *out);
+/* ElipseCost3D.position_error / orientation_error / velocity_error (costs/elipse_cost.py:169-246) of k states x[k*13] ->
+ * out[k*3]. in_plane_frame = 1: the pose in x is ALREADY in the ellipse's plane frame (what the reference's unit tests pass to
+ * the three methods); 0: the state is taken into the plane frame first, as state_cost does (:124-139).
+ * MPPI_STATE_COST_ELLIPSE3D handles only. */
+mppi_status mppi_ellipse3d_terms(mppi_handle *h, const float *x, int k, int in_plane_frame, float *out);
 /* CostBase::mStateCost / mBuildFinalStepCostGraph (cost_base.cpp:52-61): x[k,s] -> out[k] */
 mppi_status mppi_state_cost(mppi_handle *h, const float *x, int k, float *out);
 /* CostBase::mActionCost (cost_base.cpp:63-68 or the Py form): u[a], eps[k,a] -> out[k] */

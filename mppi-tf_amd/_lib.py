@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MPPI_SO_PATH") or os.path.join(HERE, "libmppi_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_SINGULAR_SIGMA, ERR_ALLOC, ERR_IO, ERR_EXCHANGE = range(9)
-MODEL_POINT_MASS, MODEL_MLP = 0, 1
+MODEL_POINT_MASS, MODEL_MLP, MODEL_AUV, MODEL_NN_AUV = 0, 1, 2, 3
+STATE_COST_QUADRATIC, STATE_COST_ELLIPSE, STATE_COST_QUAT, STATE_COST_ELLIPSE3D = 0, 1, 2, 3
 ACTION_COST_CPP, ACTION_COST_PY = 0, 1
 DBG_COSTS, DBG_BETA, DBG_ETA, DBG_WEIGHTS, DBG_NOISE, DBG_U_UPDATED = range(6)
 CSV_REFERENCE, CSV_ROUNDTRIP = 0, 1
@@ -38,6 +39,13 @@ class MlpDesc(C.Structure):
                 ("xmean", FP), ("xstd", FP), ("ymean", FP), ("ystd", FP)]
 
 
+class AuvDesc(C.Structure):
+    _fields_ = [("mass", C.c_float), ("volume", C.c_float), ("density", C.c_float), ("gravity", C.c_float),
+                ("cog", C.c_float * 3), ("cob", C.c_float * 3), ("inertial", C.c_float * 6),
+                ("added_mass", FP), ("linear_damping", FP), ("linear_damping_forward_speed", FP), ("quad_damping", FP),
+                ("rk", C.c_int32)]
+
+
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("k", C.c_int32), ("tau", C.c_int32),
                 ("s_dim", C.c_int32), ("a_dim", C.c_int32), ("dt", C.c_float), ("mass", C.c_float),
@@ -46,7 +54,8 @@ class Config(C.Structure):
                 ("sigma", FP), ("goal", FP), ("Q", FP), ("q_is_full", C.c_int32),
                 ("seed", C.c_uint64), ("model_kind", C.c_int32), ("mlp", C.POINTER(MlpDesc)),
                 ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
-                ("flags", C.c_int32), ("state_cost_kind", C.c_int32), ("ellipse", FP)]
+                ("flags", C.c_int32), ("state_cost_kind", C.c_int32), ("ellipse", FP),
+                ("auv", C.POINTER(AuvDesc)), ("quat_Q", FP), ("ellipse3d", FP)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol include/mppi_c.h declares
@@ -75,6 +84,8 @@ SIGNATURES = {
     "mppi_set_step_counter": (C.c_int, [_H, C.c_uint64]),
     "mppi_debug_get": (C.c_int, [_H, C.c_int, FP, C.c_size_t]),
     "mppi_model_step": (C.c_int, [_H, FP, C.c_int, FP, C.c_int, FP, FP, FP]),
+    "mppi_auv_pieces": (C.c_int, [_H, FP, FP, C.c_int, FP]),
+    "mppi_ellipse3d_terms": (C.c_int, [_H, FP, C.c_int, C.c_int, FP]),
     "mppi_state_cost": (C.c_int, [_H, FP, C.c_int, FP]),
     "mppi_action_cost": (C.c_int, [_H, FP, FP, C.c_int, FP]),
     "mppi_step_cost": (C.c_int, [_H, FP, FP, FP, C.c_int, FP]),
@@ -118,7 +129,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.mppi_abi_version() != 2:
+    if lib.mppi_abi_version() != 3:
         raise OSError("libmppi_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -139,11 +150,17 @@ class Handle:
     def __init__(self, k, tau, s_dim, a_dim, dt=0.1, mass=1.0, lam=1.0, gamma=1.0, upsilon=1.0,
                  sigma=None, goal=None, Q=None, q_is_full=None, action_cost=ACTION_COST_CPP,
                  normalize_cost=False, seed=1, device=0, shard_rank=0, shard_count=1, mlp=None,
-                 upsilon_scales_noise=False, mlp_bf16x3=False, tuning=None, log_rows=0, ellipse=None):
+                 upsilon_scales_noise=False, mlp_bf16x3=False, tuning=None, log_rows=0, ellipse=None,
+                 auv=None, nnauv=None, quat_cost=False, ellipse3d=None):
         """mlp: dict(W=[W1,W2,W3], b=[b1,b2,b3], xmean=, xstd=, ymean=, ystd=) selects the learned
         model_base (Dense(256,relu) x2 + Dense(s_dim); Keras [in x out] kernels).
         tuning: dict of diagnostic switches (keys of TUNING) applied with mppi_set_tuning right after creation.
-        log_rows: capacity of the transition log (mppi_set_transition_log); 0 = off."""
+        log_rows: capacity of the transition log (mppi_set_transition_log); 0 = off.
+        auv: the reference's AUVModel `parameters` dict (auv_model.py:85-245: mass, volume, density, cog, cob, Ma, linear_damping,
+        quad_damping, linear_damping_forward_speed, inertial{ixx..iyz}, rk) selects the Fossen model (s_dim 13, a_dim 6);
+        nnauv: an mlp dict whose first kernel has s+a-3 = 16 rows selects NNAUVModel (nn_model.py:179-304);
+        quat_cost: StaticQuatCost (static_cost.py:73-159) with goal [13] and Q [10,10] (or its 10 diagonal entries);
+        ellipse3d: dict(normal, aVec, axis, speed, m_state, m_vel) selects ElipseCost3D (elipse_cost.py:101-246)."""
         lib = self.lib = load()
         cfg = Config()
         self._check(lib.mppi_config_init(C.byref(cfg), k, tau, dt, mass, s_dim, a_dim), None)
@@ -156,6 +173,39 @@ class Handle:
             e = [ellipse[k] for k in ("a", "b", "cx", "cy", "speed", "m_state", "m_vel")] if isinstance(ellipse, dict) else ellipse
             keep.append(f32(e, (7,)))
             cfg.state_cost_kind, cfg.ellipse = 1, fp(keep[-1])
+        if auv is not None:
+            d = AuvDesc()
+            d.mass, d.volume, d.density, d.gravity = auv["mass"], auv["volume"], auv["density"], auv.get("gravity", 0.0)
+            d.rk = int(auv.get("rk", 1))  # auv_model.py:111-114: rk defaults to 1 when the parameters do not carry it
+            for i in range(3):
+                d.cog[i], d.cob[i] = auv["cog"][i], auv["cob"][i]
+            for i, key in enumerate(("ixx", "iyy", "izz", "ixy", "ixz", "iyz")):
+                d.inertial[i] = auv["inertial"][key]
+
+            def mat6(key):  # a 6-vector is the diagonal (auv_model.py:186-195)
+                if auv.get(key) is None:
+                    return None
+                m6 = np.asarray(auv[key], np.float32)
+                keep.append(f32(np.diag(m6) if m6.shape == (6,) else m6, (36,)))
+                return fp(keep[-1])
+            d.added_mass, d.linear_damping = mat6("Ma"), mat6("linear_damping")
+            d.linear_damping_forward_speed = mat6("linear_damping_forward_speed")
+            if auv.get("quad_damping") is not None:
+                keep.append(f32(auv["quad_damping"], (6,)))
+                d.quad_damping = fp(keep[-1])
+            keep.append(d)
+            cfg.model_kind, cfg.auv = MODEL_AUV, C.pointer(d)
+        if quat_cost:
+            q = f32(Q if Q is not None else np.ones(10))
+            keep.append(f32(np.diag(q) if q.ndim == 1 else q, (100,)))
+            cfg.state_cost_kind, cfg.quat_Q = STATE_COST_QUAT, fp(keep[-1])
+            Q = None
+        if ellipse3d is not None:
+            e = ellipse3d
+            keep.append(f32(list(np.ravel(e["normal"])) + list(np.ravel(e["aVec"])) + list(np.ravel(e["axis"])) + [e["speed"], e["m_state"], e["m_vel"]], (11,)))
+            cfg.state_cost_kind, cfg.ellipse3d = STATE_COST_ELLIPSE3D, fp(keep[-1])
+        if nnauv is not None:
+            mlp = nnauv
         if sigma is not None:
             keep.append(f32(sigma, (a_dim, a_dim)))
             cfg.sigma = fp(keep[-1])
@@ -178,12 +228,13 @@ class Handle:
             Wp = (FP * len(Ws))(*[fp(w) for w in Ws])
             bp = (FP * len(bs))(*[fp(b) for b in bs])
             desc.widths, desc.W, desc.b = widths, Wp, bp
-            for name, n in (("xmean", s_dim + a_dim), ("xstd", s_dim + a_dim), ("ymean", s_dim), ("ystd", s_dim)):
+            n_in = s_dim + a_dim - (3 if nnauv is not None else 0)
+            for name, n in (("xmean", n_in), ("xstd", n_in), ("ymean", s_dim), ("ystd", s_dim)):
                 if mlp.get(name) is not None:
                     keep.append(f32(mlp[name], (n,)))
                     setattr(desc, name, fp(keep[-1]))
             keep += [desc, widths, Wp, bp]
-            cfg.model_kind, cfg.mlp = MODEL_MLP, C.pointer(desc)
+            cfg.model_kind, cfg.mlp = (MODEL_NN_AUV if nnauv is not None else MODEL_MLP), C.pointer(desc)
         self.h = _H()
         self.k, self.tau, self.s, self.a = k, tau, s_dim, a_dim
         st = lib.mppi_create(C.byref(cfg), C.byref(self.h))
@@ -305,6 +356,22 @@ class Handle:
         fr, ac, nx = np.zeros((kx, self.s), np.float32), np.zeros((k, self.s), np.float32), np.zeros((k, self.s), np.float32)
         self._check(self.lib.mppi_model_step(self.h, fp(x), kx, fp(v), k, fp(fr), fp(ac), fp(nx)))
         return fr, ac, nx
+
+    def auv_pieces(self, x, u):
+        """AUVModel's intermediates for k (state, action) pairs -> dict(rot [k,3,3], T [k,4,3], Cv, Dv, g [k,6], xdot [k,13])"""
+        x, u = f32(x, (-1, 13)), f32(u, (-1, 6))
+        k = x.shape[0]
+        out = np.zeros((k, 124), np.float32)
+        self._check(self.lib.mppi_auv_pieces(self.h, fp(x), fp(u), k, fp(out)))
+        return dict(rot=out[:, :9].reshape(k, 3, 3), T=out[:, 9:21].reshape(k, 4, 3), Cv=out[:, 21:27], Dv=out[:, 27:33], g=out[:, 33:39],
+                    xdot=out[:, 39:52], D=out[:, 52:88].reshape(k, 6, 6), C=out[:, 88:124].reshape(k, 6, 6))
+
+    def ellipse3d_terms(self, x, in_plane_frame=False):
+        """ElipseCost3D's (position, orientation, velocity) errors of k states -> [k,3]"""
+        x = f32(x, (-1, 13))
+        out = np.zeros((x.shape[0], 3), np.float32)
+        self._check(self.lib.mppi_ellipse3d_terms(self.h, fp(x), x.shape[0], int(bool(in_plane_frame)), fp(out)))
+        return out
 
     def state_cost(self, x):
         x = f32(x, (-1, self.s))

@@ -228,8 +228,14 @@ class ControllerBase:
             sigma = np.eye(aDim, dtype=np.float32)
         # build_noise: noises = (upsilon * sigma) @ rng   (controller_base.py:362-368)
         self._sigma = sigma
+        # the model_base slot: the point-mass model (dt, mass), or a 13-state model that brings its own description
+        model_kw = {}
+        if hasattr(model, "handle_parameters"):   # AUVModel (auv.py)
+            model_kw = dict(auv=model.handle_parameters())
+        elif hasattr(model, "mlp"):               # NNAUVModel (auv.py)
+            model_kw = dict(nnauv=model.mlp())
         self._h = Handle(k=self._k, tau=self._tau, s_dim=self._sDim, a_dim=self._aDim,
-                         dt=model._dt, mass=model._mass, lam=self._lam,
+                         dt=model._dt, mass=(1.0 if model_kw else model._mass), lam=self._lam, **model_kw,
                          gamma=getattr(cost, "gamma", 1.0), upsilon=getattr(cost, "upsilon", 1.0),
                          sigma=sigma, **self._state_cost_args(cost),
                          action_cost=cost._action_cost_kind, normalize_cost=self._normalizeCost,
@@ -262,6 +268,8 @@ class ControllerBase:
         """what selects the device state cost: (goal, Q) of a StaticCost or the ellipse of an ElipseCost"""
         if isinstance(cost, ElipseCost):
             return dict(ellipse=cost.ellipse)
+        if hasattr(cost, "handle_args"):  # StaticQuatCost / ElipseCost3D (auv.py)
+            return cost.handle_args()
         return dict(goal=cost.goal.ravel(), Q=cost.Q, q_is_full=True)
 
     # ---- the step ---------------------------------------------------------------------

@@ -148,6 +148,7 @@ extern "C" void mppi_destroy(mppi_handle *h)
     if (h->h_xchg_status) (void)hipHostFree(h->h_xchg_status);
     if (h->d_xchg_dead) (void)hipFree(h->d_xchg_dead);
     if (h->d_probe_got) (void)hipFree(h->d_probe_got);
+    mppi_gen_destroy(h);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -164,10 +165,28 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     if (cfg->shard_count < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_count)
         return fail(nullptr, MPPI_ERR_INVALID_ARG, "bad shard_rank/shard_count");
     if (cfg->model_kind == MPPI_MODEL_POINT_MASS && !(cfg->mass != 0.0f)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "mass must be non-zero");
-    if (cfg->model_kind != MPPI_MODEL_POINT_MASS && cfg->model_kind != MPPI_MODEL_MLP)
+    if (cfg->model_kind < MPPI_MODEL_POINT_MASS || cfg->model_kind > MPPI_MODEL_NN_AUV)
         return fail(nullptr, MPPI_ERR_INVALID_ARG, "unknown model kind");
-    if (cfg->state_cost_kind != MPPI_STATE_COST_QUADRATIC && cfg->state_cost_kind != MPPI_STATE_COST_ELLIPSE)
+    if (cfg->state_cost_kind < MPPI_STATE_COST_QUADRATIC || cfg->state_cost_kind > MPPI_STATE_COST_ELLIPSE3D)
         return fail(nullptr, MPPI_ERR_INVALID_ARG, "unknown state cost kind");
+    // the 13-state AUV family (mppi_gen.hip.h): pose with a quaternion + body velocities, 6 generalised forces
+    const bool gen = cfg->model_kind == MPPI_MODEL_AUV || cfg->model_kind == MPPI_MODEL_NN_AUV;
+    const bool cost13 = cfg->state_cost_kind == MPPI_STATE_COST_QUAT || cfg->state_cost_kind == MPPI_STATE_COST_ELLIPSE3D;
+    if (gen && (s != 13 || a != 6)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "AUVModel / NNAUVModel: s_dim = 13 (pos, quat, lin vel, ang vel), a_dim = 6");
+    if (cost13 && s != 13) return fail(nullptr, MPPI_ERR_INVALID_ARG, "StaticQuatCost / ElipseCost3D read a 13-state (static_cost.py:141-159, elipse_cost.py:124-139)");
+    if (cost13 && !gen && cfg->k * (long long)cfg->tau > 1) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "StaticQuatCost / ElipseCost3D rollouts need a 13-state model (MPPI_MODEL_AUV / MPPI_MODEL_NN_AUV)");
+    if (cfg->model_kind == MPPI_MODEL_NN_AUV) {
+        const mppi_mlp_desc *d = cfg->mlp;
+        if (!d || !d->widths || !d->W || !d->b) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NNAUVModel needs cfg.mlp with widths, W, b");
+        if (d->n_layers < 2 || d->n_layers > kMlpSmallMaxLayers) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "NNAUVModel: 2 to 4 Dense layers (1 to 3 hidden + the output layer)");
+        for (int l = 0; l < d->n_layers; ++l) if (!d->W[l] || !d->b[l]) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NULL MLP weight pointer");
+        if (d->widths[d->n_layers - 1] != 13) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NNAUVModel: the last layer's width must be 13 (nn_model.py:59)");
+        const int hid = d->widths[0];
+        bool same = hid == 16 || hid == 32;
+        for (int l = 0; l + 1 < d->n_layers; ++l) same = same && d->widths[l] == hid;
+        if (!same) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "NNAUVModel kernels exist for 1-3 equal hidden layers of 16 or 32 (nn_model.py:54-60)");
+        if (cfg->flags & MPPI_FLAG_MLP_BF16X3) return fail(nullptr, MPPI_ERR_INVALID_ARG, "MPPI_FLAG_MLP_BF16X3 applies to the 256-wide network only");
+    }
     if (cfg->state_cost_kind == MPPI_STATE_COST_ELLIPSE) {
         if (!cfg->ellipse) return fail(nullptr, MPPI_ERR_INVALID_ARG, "the elliptic cost needs cfg.ellipse[7]");
         if (s < 4) return fail(nullptr, MPPI_ERR_INVALID_ARG, "the elliptic cost reads (x, vx, y, vy): s_dim >= 4");
@@ -260,12 +279,15 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     // CostBase and ModelBase are separate classes in the reference (cost shapes such as s=4,a=3
     // or s=13,a=6 appear in its tests): such a handle serves the cost/model helpers, and the
     // rollout entry points answer MPPI_ERR_UNSUPPORTED with this reason.
-    if (s != 2 * a) h->no_rollout = "point-mass rollouts need s_dim == 2*a_dim (blockDiag of 2x2 / 2x1 blocks, model_base.cpp:59-82)";
+    if (gen) R = 64; // one wave per 64-rollout tile, nothing parked in LDS
+    if (gen) { /* rollouts run k_rollout_gen */ }
+    else if (s != 2 * a) h->no_rollout = "point-mass rollouts need s_dim == 2*a_dim (blockDiag of 2x2 / 2x1 blocks, model_base.cpp:59-82)";
     else if (a > 4) h->no_rollout = "rollout kernels are instantiated for a_dim <= 4";
     else if (tile_lds_floats(h->HA, R) * 4 > lds_cap) h->no_rollout = "tau*a_dim too large: the 16-rollout LDS tile exceeds 160 KiB";
     h->R = R; h->nb = (h->K_local + R - 1) / R; h->tile_lds = tile_lds_floats(h->HA, R) * 4;
     h->mlp_bx3 = (cfg->model_kind == MPPI_MODEL_MLP && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) ? 1 : 0;
-    h->mlp_small = (cfg->model_kind == MPPI_MODEL_MLP && cfg->mlp->widths[0] != kHid) ? cfg->mlp->widths[0] : 0;
+    h->mlp_small = ((cfg->model_kind == MPPI_MODEL_MLP && cfg->mlp->widths[0] != kHid) || cfg->model_kind == MPPI_MODEL_NN_AUV) ? cfg->mlp->widths[0] : 0;
+    h->is_gen = gen ? 1 : 0;
     h->mlp_v2 = (cfg->model_kind == MPPI_MODEL_MLP && !h->mlp_small && !h->mlp_bx3 && a <= 3) ? 1 : 0; // a_dim = 4: two h1 images + the rest exceed 160 KiB of LDS
     h->nb_mlp = cfg->model_kind == MPPI_MODEL_MLP ? (h->mlp_v2 ? (h->K_local + kMlp2R - 1) / kMlp2R : (h->K_local + kMlpR - 1) / kMlpR) : 0;
 
@@ -291,26 +313,38 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         const int nrec2 = (nrec + kGroup - 1) / kGroup, nrec3 = (nrec2 + kGroup - 1) / kGroup;
         HIP_TRY(h, hipMalloc((void **)&h->d_part2, sizeof(float) * (size_t)nrec2 * (2 + h->HA)));
         HIP_TRY(h, hipMalloc((void **)&h->d_part3, sizeof(float) * (size_t)nrec3 * (2 + h->HA)));
-        if (cfg->model_kind == MPPI_MODEL_MLP) {
+        if (cfg->model_kind == MPPI_MODEL_MLP || cfg->model_kind == MPPI_MODEL_NN_AUV) {
             const mppi_mlp_desc *d = cfg->mlp;
-            const int nin = s + a;
+            const bool nnauv = cfg->model_kind == MPPI_MODEL_NN_AUV;
+            const int nin = nnauv ? s + a - 3 : s + a; // NNAUVModel.prepare_data drops the position (nn_model.py:289-293)
             size_t total = 0;
-            for (int l = 0, w_in = nin; l < d->n_layers; w_in = d->widths[l], ++l) total += (size_t)(w_in + 1) * d->widths[l];
+            for (int l = 0, w_in = nin; l < d->n_layers; w_in = d->widths[l], ++l) total += (size_t)(w_in + 1) * (d->widths[l] + 1);
             HIP_TRY(h, hipMalloc((void **)&h->d_mlp_w, sizeof(float) * total));
             HIP_TRY(h, hipMalloc((void **)&h->dM, sizeof(MlpDev)));
             float *p = h->d_mlp_w;
             h->hm.n_layers = d->n_layers;
             h->small_args.n_layers = d->n_layers;
+            std::vector<float> padded; // an odd output layer (NNAUVModel: 13) is stored with one zero column more: outputs stay pairs
             for (int l = 0, w_in = nin; l < d->n_layers; w_in = d->widths[l], ++l) {
-                const size_t nw = (size_t)w_in * d->widths[l], nbias = (size_t)d->widths[l];
-                HIP_TRY(h, hipMemcpyAsync(p, d->W[l], sizeof(float) * nw, hipMemcpyHostToDevice, h->stream));
-                HIP_TRY(h, hipMemcpyAsync(p + nw, d->b[l], sizeof(float) * nbias, hipMemcpyHostToDevice, h->stream));
+                const int ld = (nnauv && (d->widths[l] & 1)) ? d->widths[l] + 1 : d->widths[l];
+                const size_t nw = (size_t)w_in * ld, nbias = (size_t)ld;
+                if (ld != d->widths[l]) {
+                    padded.assign(nw + nbias, 0.0f);
+                    for (int i = 0; i < w_in; ++i) for (int o = 0; o < d->widths[l]; ++o) padded[(size_t)i * ld + o] = d->W[l][(size_t)i * d->widths[l] + o];
+                    for (int o = 0; o < d->widths[l]; ++o) padded[nw + o] = d->b[l][o];
+                    HIP_TRY(h, hipMemcpyAsync(p, padded.data(), sizeof(float) * (nw + nbias), hipMemcpyHostToDevice, h->stream));
+                    HIP_TRY(h, hipStreamSynchronize(h->stream));
+                } else {
+                    HIP_TRY(h, hipMemcpyAsync(p, d->W[l], sizeof(float) * nw, hipMemcpyHostToDevice, h->stream));
+                    HIP_TRY(h, hipMemcpyAsync(p + nw, d->b[l], sizeof(float) * nbias, hipMemcpyHostToDevice, h->stream));
+                }
                 h->hm.widths[l] = d->widths[l];
+                h->hm.ld[l] = ld;
                 h->hm.Wl[l] = h->small_args.W[l] = p;
                 h->hm.bl[l] = h->small_args.b[l] = p + nw;
                 p += nw + nbias;
             }
-            if (!h->mlp_small) {
+            if (!h->mlp_small && !nnauv) {
                 h->hm.W1 = h->hm.Wl[0]; h->hm.b1 = h->hm.bl[0]; h->hm.W2 = h->hm.Wl[1]; h->hm.b2 = h->hm.bl[1];
                 h->hm.W3 = h->hm.Wl[2]; h->hm.b3 = h->hm.bl[2];
             }
@@ -328,6 +362,10 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         HIP_TRY(h, hipMemsetAsync(h->d_step, 0, sizeof(unsigned long long), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_dbg, 0, sizeof(float) * 8, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_cost, 0, sizeof(float) * h->K_local, h->stream));
+        if (gen || cost13) {
+            if (const char *why = mppi_gen_fill(h, cfg)) return fail(h, MPPI_ERR_INVALID_ARG, why);
+            HIP_TRY(h, mppi_gen_upload(h));
+        }
         return upload_consts(h);
     };
     st = body();
@@ -354,7 +392,7 @@ static hipError_t launch_tile(mppi_handle *h, hipStream_t st, int src, int mode,
 // diagonal-Q handles only (a dense Q runs the tile kernel); horizon groups per producer must fit the registers
 static bool pc_eligible(const mppi_handle *h)
 {
-    return h->no_rollout.empty() && h->R == 64 && !h->hc.q_full && !h->force_tile && h->H <= (h->pc_np == 3 ? 132 : 160) &&
+    return !h->is_gen && h->no_rollout.empty() && h->R == 64 && !h->hc.q_full && !h->force_tile && h->H <= (h->pc_np == 3 ? 132 : 160) &&
            h->hc.state_cost_kind == MPPI_STATE_COST_QUADRATIC; // other costs run the general tile kernel
 }
 
@@ -534,16 +572,18 @@ static hipError_t ensure_record_layout(mppi_handle *h, hipStream_t st, int n_til
 static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, const float *x_dev, const float *eps, float *noise_out, int *nrec)
 {
     const bool mlp = h->hc.model_kind == MPPI_MODEL_MLP;
+    const bool gen = h->is_gen != 0;
     *nrec = h->nbp; // every slot: those no tile owns hold neutral records
     HIP_TRY(h, ensure_record_layout(h, st, (mlp && !h->normalize) ? h->nb_mlp : h->nb)); // (normalizeCost: the tile kernel writes the records)
     if (!h->normalize) {
         const bool prof = h->prof_n < h->prof_cap;
         const bool pc = !mlp && src == SRC_PHILOX && noise_out == nullptr && pc_eligible(h);
-        const bool kernel_events = prof && (mlp || pc); // the kernel's own begin/end; other kernels: events around the launch
+        const bool kernel_events = prof && (mlp || pc || gen); // the kernel's own begin/end; other kernels: events around the launch
         if (prof && !kernel_events) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 0], st));
         h->kev0 = kernel_events ? h->ev[4 * h->prof_n + 0] : nullptr;
         h->kev1 = kernel_events ? h->ev[4 * h->prof_n + 1] : nullptr;
-        hipError_t le = mlp ? launch_mlp(h, st, src, MODE_ROLLOUT, x_dev, h->U_cur(), eps, h->d_cost)
+        hipError_t le = gen ? mppi_launch_gen(h, st, src, MODE_ROLLOUT, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out)
+                      : mlp ? launch_mlp(h, st, src, MODE_ROLLOUT, x_dev, h->U_cur(), eps, h->d_cost)
                       : pc  ? launch_pc(h, st, x_dev)
                             : launch_tile(h, st, src, MODE_ROLLOUT, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out);
         h->kev0 = h->kev1 = nullptr;
@@ -556,14 +596,16 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
     // c' = (c-min)/(max-min) with the SAME noise (regenerated from the same Philox counters).
     const bool prof_n = h->prof_n < h->prof_cap; // a profiled step brackets the cost pass (the dominant launch) here
     if (prof_n) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 0], st));
-    if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost));
+    if (gen) HIP_TRY(h, mppi_launch_gen(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out));
+    else if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost));
     else HIP_TRY(h, launch_tile(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out));
     if (prof_n) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 1], st));
     hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(kFinishThreads), 0, st, h->d_cost, h->K_local, h->d_mm);
     HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(k_cost_normalize, dim3((h->K_local + 255) / 256), dim3(256), 0, st, h->d_cost, h->K_local, h->d_mm, h->d_cost2);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, launch_tile(h, st, src, MODE_COSTS_GIVEN, x_dev, h->U_cur(), eps, h->d_cost2, h->d_part, nullptr));
+    if (gen) HIP_TRY(h, mppi_launch_gen(h, st, src, MODE_COSTS_GIVEN, x_dev, h->U_cur(), eps, h->d_cost2, h->d_part, nullptr));
+    else HIP_TRY(h, launch_tile(h, st, src, MODE_COSTS_GIVEN, x_dev, h->U_cur(), eps, h->d_cost2, h->d_part, nullptr));
     *nrec = h->nbp;
     return MPPI_OK;
 }
@@ -593,7 +635,8 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
 {
     if (!h || !buf || n == 0) return MPPI_ERR_INVALID_ARG;
     const int NG = (h->H + 3) / 4;
-    if (h->hc.model_kind == MPPI_MODEL_MLP)
+    if (h->is_gen) std::snprintf(buf, n, "%s", mppi_gen_kernel_name(h));
+    else if (h->hc.model_kind == MPPI_MODEL_MLP)
         if (h->mlp_small == 32 && !h->mlp32_valu) std::snprintf(buf, n, "mppi::k_rollout_mlp32<%d>", h->a);
         else if (h->mlp_small) std::snprintf(buf, n, "mppi::k_rollout_mlp_small<%d, %d>", h->a, h->mlp_small);
         else if (h->mlp_v2 && !h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp2<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
@@ -1039,7 +1082,8 @@ extern "C" mppi_status mppi_debug_get(mppi_handle *h, int what, float *out, size
         unsigned long long prev = cur - 1;
         HIP_TRY(h, hipMemcpyAsync(h->d_step, &prev, sizeof(prev), hipMemcpyHostToDevice, h->stream));
         // noise-only pass of the tile kernel: reads neither x nor any cost buffer and writes nothing but d_eps
-        HIP_TRY(h, launch_tile(h, h->stream, SRC_PHILOX, MODE_NOISE_ONLY, h->d_x, h->U_cur(), nullptr, nullptr, nullptr, h->d_eps));
+        if (h->is_gen) HIP_TRY(h, mppi_launch_gen(h, h->stream, SRC_PHILOX, MODE_NOISE_ONLY, h->d_x, h->U_cur(), nullptr, nullptr, nullptr, h->d_eps));
+        else HIP_TRY(h, launch_tile(h, h->stream, SRC_PHILOX, MODE_NOISE_ONLY, h->d_x, h->U_cur(), nullptr, nullptr, nullptr, h->d_eps));
         HIP_TRY(h, hipMemcpyAsync(h->d_step, &cur, sizeof(cur), hipMemcpyHostToDevice, h->stream));
         src = h->d_eps;
         break;
@@ -1071,6 +1115,16 @@ extern "C" mppi_status mppi_model_step(mppi_handle *h, const float *x, int kx, c
     if (!x || !v || k <= 0 || (kx != k && kx != 1)) return fail(h, MPPI_ERR_INVALID_ARG, "x is [kx,s] with kx in {1,k}; v is [k,a]");
     HIP_TRY(h, hipSetDevice(h->device));
     const int s = h->s, a = h->a;
+    if (h->is_gen) {
+        if (out_free || out_action) return fail(h, MPPI_ERR_UNSUPPORTED, "the free/action split exists for the point-mass model only");
+        DevBuf dx, dv, dn, ds;
+        HIP_TRY(h, dx.alloc((size_t)kx * s)); HIP_TRY(h, dv.alloc((size_t)k * a)); HIP_TRY(h, dn.alloc((size_t)k * s)); HIP_TRY(h, ds.alloc((size_t)k * 128));
+        HIP_TRY(h, dx.up(x, (size_t)kx * s, h->stream)); HIP_TRY(h, dv.up(v, (size_t)k * a, h->stream));
+        HIP_TRY(h, mppi_gen_model_step(h, h->stream, dx.p, kx, dv.p, k, ds.p, dn.p));
+        if (out_next) HIP_TRY(h, dn.down(out_next, (size_t)k * s, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return MPPI_OK;
+    }
     if (h->hc.model_kind == MPPI_MODEL_MLP) {
         if (out_free || out_action) return fail(h, MPPI_ERR_UNSUPPORTED, "the free/action split exists for the point-mass model only");
         DevBuf dx, dv, dn, ds;
@@ -1101,6 +1155,36 @@ extern "C" mppi_status mppi_model_step(mppi_handle *h, const float *x, int kx, c
     return MPPI_OK;
 }
 
+extern "C" mppi_status mppi_auv_pieces(mppi_handle *h, const float *x, const float *u, int k, float *out)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (!x || !u || !out || k <= 0) return fail(h, MPPI_ERR_INVALID_ARG, "x is [k,13], u is [k,6], out is [k,124]");
+    if (h->hc.model_kind != MPPI_MODEL_AUV) return fail(h, MPPI_ERR_INVALID_ARG, "not an AUVModel handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    DevBuf dx, du, dout;
+    HIP_TRY(h, dx.alloc((size_t)k * 13)); HIP_TRY(h, du.alloc((size_t)k * 6)); HIP_TRY(h, dout.alloc((size_t)k * 124));
+    HIP_TRY(h, dx.up(x, (size_t)k * 13, h->stream)); HIP_TRY(h, du.up(u, (size_t)k * 6, h->stream));
+    HIP_TRY(h, mppi_gen_auv_pieces(h, h->stream, dx.p, du.p, k, dout.p));
+    HIP_TRY(h, dout.down(out, (size_t)k * 124, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_ellipse3d_terms(mppi_handle *h, const float *x, int k, int in_plane_frame, float *out)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    if (!x || !out || k <= 0) return fail(h, MPPI_ERR_INVALID_ARG, "x is [k,13], out is [k,3]");
+    if (h->hc.state_cost_kind != MPPI_STATE_COST_ELLIPSE3D) return fail(h, MPPI_ERR_INVALID_ARG, "not an ElipseCost3D handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    DevBuf dx, dout;
+    HIP_TRY(h, dx.alloc((size_t)k * 13)); HIP_TRY(h, dout.alloc((size_t)k * 3));
+    HIP_TRY(h, dx.up(x, (size_t)k * 13, h->stream));
+    HIP_TRY(h, mppi_gen_e3_terms(h, h->stream, dx.p, k, in_plane_frame, dout.p));
+    HIP_TRY(h, dout.down(out, (size_t)k * 3, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
 template <int S, int A>
 static void launch_costs_sa(mppi_handle *h, const float *x, const float *u, const float *eps, int k, float *os, float *oa, float *ot)
 {
@@ -1124,7 +1208,8 @@ static mppi_status costs_host(mppi_handle *h, const float *x, const float *u, co
     if (u) { HIP_TRY(h, du.up(u, a, h->stream)); HIP_TRY(h, de.up(eps, (size_t)k * a, h->stream)); }
     const float *px = x ? dx.p : nullptr, *pu = u ? du.p : nullptr, *pe = u ? de.p : nullptr;
     // shapes of the reference's own tests + the point-mass family run exact instances
-    if (s == 2 && a == 1) launch_costs_sa<2, 1>(h, px, pu, pe, k, ds.p, da.p, dt.p);
+    if (h->gen != nullptr) HIP_TRY(h, mppi_gen_costs(h, h->stream, px, pu, pe, k, ds.p, da.p, dt.p)); // 13-state costs (quadratic, quaternion, 3D ellipse)
+    else if (s == 2 && a == 1) launch_costs_sa<2, 1>(h, px, pu, pe, k, ds.p, da.p, dt.p);
     else if (s == 2 && a == 2) launch_costs_sa<2, 2>(h, px, pu, pe, k, ds.p, da.p, dt.p);
     else if (s == 4 && a == 2) launch_costs_sa<4, 2>(h, px, pu, pe, k, ds.p, da.p, dt.p);
     else if (s == 4 && a == 3) launch_costs_sa<4, 3>(h, px, pu, pe, k, ds.p, da.p, dt.p);
@@ -1168,7 +1253,8 @@ extern "C" mppi_status mppi_rollout_cost(mppi_handle *h, const float *x, const f
     HIP_TRY(h, dx.alloc(h->s)); HIP_TRY(h, dU.alloc(h->HA)); HIP_TRY(h, dc.alloc(h->K_local));
     HIP_TRY(h, dx.up(x, h->s, h->stream)); HIP_TRY(h, dU.up(U, h->HA, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_eps, eps, sizeof(float) * (size_t)h->K_local * h->HA, hipMemcpyHostToDevice, h->stream));
-    if (h->hc.model_kind == MPPI_MODEL_MLP) HIP_TRY(h, launch_mlp(h, h->stream, SRC_HBM, MODE_COST_ONLY, dx.p, dU.p, h->d_eps, dc.p));
+    if (h->is_gen) HIP_TRY(h, mppi_launch_gen(h, h->stream, SRC_HBM, MODE_COST_ONLY, dx.p, dU.p, h->d_eps, dc.p, h->d_part, nullptr));
+    else if (h->hc.model_kind == MPPI_MODEL_MLP) HIP_TRY(h, launch_mlp(h, h->stream, SRC_HBM, MODE_COST_ONLY, dx.p, dU.p, h->d_eps, dc.p));
     else HIP_TRY(h, launch_tile(h, h->stream, SRC_HBM, MODE_COST_ONLY, dx.p, dU.p, h->d_eps, dc.p, h->d_part, nullptr));
     HIP_TRY(h, dc.down(cost_out, h->K_local, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1191,7 +1277,8 @@ extern "C" mppi_status mppi_update(mppi_handle *h, const float *cost, const floa
     HIP_TRY(h, dU.up(U, HA, h->stream)); HIP_TRY(h, dc.up(cost, K, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_eps, eps, sizeof(float) * (size_t)K * HA, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, ensure_record_layout(h, h->stream, h->nb));
-    HIP_TRY(h, launch_tile(h, h->stream, SRC_HBM, MODE_COSTS_GIVEN, h->d_x, dU.p, h->d_eps, dc.p, h->d_part, nullptr));
+    if (h->is_gen) HIP_TRY(h, mppi_launch_gen(h, h->stream, SRC_HBM, MODE_COSTS_GIVEN, h->d_x, dU.p, h->d_eps, dc.p, h->d_part, nullptr));
+    else HIP_TRY(h, launch_tile(h, h->stream, SRC_HBM, MODE_COSTS_GIVEN, h->d_x, dU.p, h->d_eps, dc.p, h->d_part, nullptr));
     // record = (beta, eta, V); then U' on a scratch copy of U (apply shifts it, so read U_updated)
     unsigned long long step_before = 0;
     HIP_TRY(h, hipMemcpyAsync(&step_before, h->d_step, sizeof(step_before), hipMemcpyDeviceToHost, h->stream));

@@ -1,0 +1,557 @@
+// mppi_gen.hip.h — the 13-state AUV family in the model_base slot and the richer costs in the cost_base slot
+// (SURVEY §8f row 4), as lane-per-rollout device code for gfx950:
+//   models  AUVModel   (Fossen 6-DOF rigid body, quaternion attitude, rk1/rk2/"rk4")   models/auv_model.py:282-562
+//           NNAUVModel (x' = x + denorm(nn(norm(concat(x[3:], u)))), Dense(16|32)x1..3)  models/nn_model.py:215-304
+//   costs   StaticCost     (x-g)^T Q (x-g), s = 13                                     costs/static_cost.py:40-63
+//           StaticQuatCost d = (dp, 2 acos<q, g_q>, dv), d^T Q10 d                     costs/static_cost.py:73-159
+//           ElipseCost3D   plane-frame pose, |sum (p/axis)^2 - 1| + tangent angle + | |v|^2 - speed^2 |   costs/elipse_cost.py:101-246
+// State x = (pos[3], quat[x,y,z,w], lin vel[3], ang vel[3]), action = 6 generalised forces; s_dim = 13 and a_dim = 6 are
+// NOT tied by s = 2a as in the point-mass kernels. Arithmetic in the reference's order, every operation rounded on its
+// own (-ffp-contract=off), products with the structural zeros of the reference's dense matrices skipped (exact up to the
+// sign of a zero) — the same contract as mppi_device.hip.h, checked by the parity tests against the CPU restatement.
+//
+// k_rollout_gen: one rollout per LANE, one wave = one 64-rollout tile = one (beta, eta, V) record, everything in
+// registers; the wave-uniform model constants arrive through scalar loads (GenConsts in HBM / the weights through the
+// scalar cache as in k_rollout_mlp_small). The tile record regenerates the noise from its Philox counters
+// (mlp_tile_record): at 400-1500 vector instructions per model step that costs under 10 % and keeps the LDS free.
+#pragma once
+
+namespace mppi {
+
+constexpr int kGenS = 13, kGenA = 6;
+constexpr int kGenNin = kGenS + kGenA - 3; // NNAUVModel's input: the state without the position, then the action
+
+enum GenModel { GEN_MODEL_AUV = 0, GEN_MODEL_NNAUV = 1 };
+
+// Device-resident constants of the 13-state family (beside DevConsts, which keeps lambda, Sigma, goal, Q, seed ...).
+struct GenConsts {
+    // AUVModel (auv_model.py:85-245), matrices row-major [6x6]
+    int rk;                 // 1, 2, 4
+    int damp_diag;          // linear_damping and linear_damping_forward_speed are both diagonal (the config files' form)
+    float dt;
+    float fng_z, fnb_z;     // (-mass)*gravity ; (volume*density)*gravity              :452-456
+    float cog[3], cob[3];
+    float mtot[36];         // rigid body + added mass                                   :247-254
+    float inv_mtot[36];     // its inverse (host, double Gauss-Jordan, rounded once)     :241
+    float lin_damp[36], lin_damp_fwd[36], quad_damp[6];
+    // StaticQuatCost: Q [10x10] (goal comes from DevConsts.goal[13])                    static_cost.py:92-100
+    float q10[100];
+    // ElipseCost3D after prepare_consts                                                  elipse_cost.py:141-167
+    float e3_q[4], e3_axis[3], e3_map[3], e3_gv, e3_mS, e3_mV;
+};
+
+// ---------------------------------------------------------------------------------------- AUVModel
+// auv_model.py:353-398 body2inertial_transform
+__device__ __forceinline__ void auv_b2i(const float (&q)[4], float (&rot)[9], float (&T)[12])
+{
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    rot[0] = 1.0f - 2.0f * (y * y + z * z);
+    rot[1] = 2.0f * (x * y - z * w);
+    rot[2] = 2.0f * (x * z + y * w);
+    rot[3] = 2.0f * (x * y + z * w);
+    rot[4] = 1.0f - 2.0f * (x * x + z * z);
+    rot[5] = 2.0f * (y * z - x * w);
+    rot[6] = 2.0f * (x * z - y * w);
+    rot[7] = 2.0f * (y * z + x * w);
+    rot[8] = 1.0f - 2.0f * (x * x + y * y);
+    const float t[12] = {w, -z, y, z, w, -x, -y, x, w, -x, -y, -z}; // rows rxt, ryt, rzt, rwt (:388-396)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = 0.5f * t[i];
+}
+
+__device__ __forceinline__ void cross3(const float (&a)[3], const float (&b)[3], float (&o)[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// dense row sum  y_i = sum_j M[i][j] x_j  in index order, first add dropped (0 + p = p up to the sign of a zero)
+template <int N>
+__device__ __forceinline__ void matvec_n(const float *__restrict__ M, const float (&x)[N], float (&y)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float acc = M[i * N] * x[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) acc = acc + M[i * N + j] * x[j];
+        y[i] = acc;
+    }
+}
+
+// auv_model.py:308-351 state_dot = (J(eta) nu, invM (tau - C nu - D nu - g)); the zero blocks of the reference's dense products are skipped
+// pieces: NULL, or 18 floats that receive C nu [6], D nu [6], g [6] (what the reference's tests look at one by one)
+__device__ __forceinline__ void auv_state_dot(const GenConsts *__restrict__ G, const float (&x)[kGenS], const float (&u)[kGenA],
+                                              float (&xd)[kGenS], float *pieces = nullptr)
+{
+    const float q[4] = {x[3], x[4], x[5], x[6]};
+    float rot[9], T[12];
+    auv_b2i(q, rot, T);
+    float vel[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vel[i] = x[7 + i];
+    // pose rates: J = [[rot, 0], [0, T]] (:335-351); the zero blocks contribute exact zeros
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xd[i] = (rot[i * 3] * vel[0] + rot[i * 3 + 1] * vel[1]) + rot[i * 3 + 2] * vel[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xd[3 + i] = (T[i * 3] * vel[3] + T[i * 3 + 1] * vel[4]) + T[i * 3 + 2] * vel[5];
+
+    // damping (:482-510): D = (-lin - v0*fwd) + (-(diag(quad) |diag(v)|)); D v as the dense row sum
+    float Dv[6];
+    const float v0 = vel[0];
+    if (G->damp_diag) { // off-diagonal entries: (-0 - v0*0) + (-0) = +-0, times v_j = +-0: dropped
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float d1 = (-1.0f * G->lin_damp[i * 7]) - (v0 * G->lin_damp_fwd[i * 7]);
+            const float dii = d1 + (-1.0f * (G->quad_damp[i] * fabsf(vel[i])));
+            Dv[i] = dii * vel[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d1 = (-1.0f * G->lin_damp[i * 6 + j]) - (v0 * G->lin_damp_fwd[i * 6 + j]);
+                const float dij = i == j ? d1 + (-1.0f * (G->quad_damp[i] * fabsf(vel[i]))) : d1 + (-0.0f);
+                acc = acc + dij * vel[j];
+            }
+            Dv[i] = acc;
+        }
+    }
+    // Coriolis (:512-545): a1 = M11 v1 + M12 v2, a2 = M21 v1 + M22 v2; C = [[0, -S(a1)], [-S(a1), -S(a2)]]
+    float a1[3], a2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float s1 = (G->mtot[i * 6] * vel[0] + G->mtot[i * 6 + 1] * vel[1]) + G->mtot[i * 6 + 2] * vel[2];
+        const float s2 = (G->mtot[i * 6 + 3] * vel[3] + G->mtot[i * 6 + 4] * vel[4]) + G->mtot[i * 6 + 5] * vel[5];
+        a1[i] = s1 + s2;
+        const float r1 = (G->mtot[(3 + i) * 6] * vel[0] + G->mtot[(3 + i) * 6 + 1] * vel[1]) + G->mtot[(3 + i) * 6 + 2] * vel[2];
+        const float r2 = (G->mtot[(3 + i) * 6 + 3] * vel[3] + G->mtot[(3 + i) * 6 + 4] * vel[4]) + G->mtot[(3 + i) * 6 + 5] * vel[5];
+        a2[i] = r1 + r2;
+    }
+    // -S(a) = [[-0, a2, -a1], [-a2, -0, a0], [a1, -a0, -0]]; rows of C v as running sums over j = 0..5 without the zero terms
+    float Cv[6];
+    Cv[0] = a1[2] * vel[4] + (-a1[1]) * vel[5];
+    Cv[1] = (-a1[2]) * vel[3] + a1[0] * vel[5];
+    Cv[2] = a1[1] * vel[3] + (-a1[0]) * vel[4];
+    Cv[3] = ((a1[2] * vel[1] + (-a1[1]) * vel[2]) + a2[2] * vel[4]) + (-a2[1]) * vel[5];
+    Cv[4] = (((-a1[2]) * vel[0] + a1[0] * vel[2]) + (-a2[2]) * vel[3]) + a2[0] * vel[5];
+    Cv[5] = ((a1[1] * vel[0] + (-a1[0]) * vel[1]) + a2[1] * vel[3]) + (-a2[0]) * vel[4];
+    // restoring (:450-480): f_g = R^T (0, 0, fng_z) = R[2][:]*fng_z ; f_b likewise ; moments cog x f_g, cob x f_b
+    float fbg[3], fbb[3], mbg[3], mbb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { fbg[i] = rot[6 + i] * G->fng_z; fbb[i] = rot[6 + i] * G->fnb_z; }
+    const float cog[3] = {G->cog[0], G->cog[1], G->cog[2]}, cob[3] = {G->cob[0], G->cob[1], G->cob[2]};
+    cross3(cog, fbg, mbg);
+    cross3(cob, fbb, mbb);
+    float rhs[6], acc6[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float g_f = -(fbg[i] + fbb[i]), g_m = -(mbg[i] + mbb[i]);
+        rhs[i] = ((u[i] - Cv[i]) - Dv[i]) - g_f;
+        rhs[3 + i] = ((u[3 + i] - Cv[3 + i]) - Dv[3 + i]) - g_m;
+        if (pieces != nullptr) { pieces[12 + i] = g_f; pieces[15 + i] = g_m; }
+    }
+    if (pieces != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { pieces[i] = Cv[i]; pieces[6 + i] = Dv[i]; }
+    }
+    matvec_n<6>(G->inv_mtot, rhs, acc6);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xd[7 + i] = acc6[i];
+}
+
+// tf.math.l2_normalize on the quaternion (auv_model.py:422-448): q * (1 / sqrt(max(sum q^2, 1e-12)))
+__device__ __forceinline__ void normalize_quat(float (&x)[kGenS])
+{
+    float ss = x[3] * x[3];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) ss = ss + x[3 + i] * x[3 + i];
+    ss = ss < 1e-12f ? 1e-12f : ss;
+    const float inv = 1.0f / sqrtf(ss);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[3 + i] = x[3 + i] * inv;
+}
+
+// auv_model.py:279-306 step(rk) + normalize_quat. rk is wave-uniform.
+__device__ __forceinline__ void auv_step(const GenConsts *__restrict__ G, float (&x)[kGenS], const float (&u)[kGenA])
+{
+    const float dt = G->dt;
+    float k1[kGenS], tmp[kGenS];
+    auv_state_dot(G, x, u, k1);
+    if (G->rk == 2) {
+        float xs[kGenS], k2[kGenS];
+#pragma unroll
+        for (int i = 0; i < kGenS; ++i) xs[i] = x[i] + dt * k1[i];
+        auv_state_dot(G, xs, u, k2);
+#pragma unroll
+        for (int i = 0; i < kGenS; ++i) tmp[i] = (dt / 2.0f) * (k1[i] + k2[i]);
+    } else if (G->rk == 4) { // the reference's formula, k4*dt inside the sum (:299-300)
+        float xs[kGenS], k2[kGenS], k3[kGenS], k4[kGenS];
+#pragma unroll
+        for (int i = 0; i < kGenS; ++i) xs[i] = x[i] + (dt * k1[i]) / 2.0f;
+        auv_state_dot(G, xs, u, k2);
+#pragma unroll
+        for (int i = 0; i < kGenS; ++i) xs[i] = x[i] + (dt * k2[i]) / 2.0f;
+        auv_state_dot(G, xs, u, k3);
+#pragma unroll
+        for (int i = 0; i < kGenS; ++i) xs[i] = x[i] + dt * k3[i];
+        auv_state_dot(G, xs, u, k4);
+        const float sixth = (float)(1.0 / 6.0);
+#pragma unroll
+        for (int i = 0; i < kGenS; ++i) tmp[i] = (sixth * ((k1[i] + 2.0f * k2[i]) + (2.0f * k3[i] + k4[i] * dt))) * dt;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kGenS; ++i) tmp[i] = k1[i] * dt;
+    }
+#pragma unroll
+    for (int i = 0; i < kGenS; ++i) x[i] = x[i] + tmp[i];
+    normalize_quat(x);
+}
+
+// ---------------------------------------------------------------------------------------- costs
+// static_cost.py:141-159 dist + :114-139 state_cost
+__device__ __forceinline__ float state_cost_quat(const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const float (&x)[kGenS])
+{
+    float d[10], left[10];
+    float dot = x[3] * C->goal[3];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) dot = dot + x[3 + i] * C->goal[3 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = x[i] - C->goal[i];
+    d[3] = 2.0f * acosf(dot);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[4 + i] = x[7 + i] - C->goal[7 + i];
+    matvec_n<10>(G->q10, d, left);
+    float acc = d[0] * left[0];
+#pragma unroll
+    for (int i = 1; i < 10; ++i) acc = acc + d[i] * left[i];
+    return acc;
+}
+
+// tensorflow_graphics quaternion.multiply (x, y, z, w)
+__device__ __forceinline__ void quat_mul(const float (&p)[4], const float (&q)[4], float (&o)[4])
+{
+    const float x1 = p[0], y1 = p[1], z1 = p[2], w1 = p[3], x2 = q[0], y2 = q[1], z2 = q[2], w2 = q[3];
+    o[0] = ((x1 * w2 + y1 * z2) - z1 * y2) + w1 * x2;
+    o[1] = ((-x1 * z2 + y1 * w2) + z1 * x2) + w1 * y2;
+    o[2] = ((x1 * y2 - y1 * x2) + z1 * w2) + w1 * z2;
+    o[3] = ((-x1 * x2 - y1 * y2) - z1 * z2) + w1 * w2;
+}
+
+__device__ __forceinline__ void l2_normalize3(float (&v)[3])
+{
+    float ss = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    ss = ss < 1e-12f ? 1e-12f : ss;
+    const float inv = 1.0f / sqrtf(ss);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = v[i] * inv;
+}
+
+// elipse_cost.py:124-246 ElipseCost3D: the three terms position_error, orientation_error, velocity_error of a state.
+// in_plane: the pose is ALREADY expressed in the plane frame (what the reference's unit tests feed the three methods with).
+__device__ __forceinline__ void e3_terms(const GenConsts *__restrict__ G, const float (&x)[kGenS], const bool in_plane,
+                                         float &pc, float &oc, float &vc)
+{
+    const float q[4] = {G->e3_q[0], G->e3_q[1], G->e3_q[2], G->e3_q[3]};
+    const float qc[4] = {-q[0], -q[1], -q[2], q[3]};
+    // the pose in the plane frame: rotate(position, q) = (q (p, 0)) conj(q) ; multiply(q, quat)
+    const float pq[4] = {x[0], x[1], x[2], 0.0f};
+    float t4[4], r4[4], qpf[4];
+    quat_mul(q, pq, t4);
+    quat_mul(t4, qc, r4);
+    const float xq[4] = {x[3], x[4], x[5], x[6]};
+    quat_mul(q, xq, qpf);
+    if (in_plane) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r4[i] = x[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qpf[i] = x[3 + i];
+    }
+    // position error: |sum_i (p_i/axis_i)^2 - 1|
+    float pd = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float r = r4[i] / G->e3_axis[i]; pd = i == 0 ? r * r : pd + r * r; }
+    pc = fabsf(pd - 1.0f);
+    // orientation error: tangent (p1*(-a/b), p0*(b/a), p2*0) normalised; q_t = between_two_vectors_3d(e_x, tangent); relative_angle
+    float tg[3] = {r4[1] * G->e3_map[0], r4[0] * G->e3_map[1], r4[2] * G->e3_map[2]};
+    const float nrm = sqrtf((tg[0] * tg[0] + tg[1] * tg[1]) + tg[2] * tg[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tg[i] = tg[i] / nrm;
+    float v1[3] = {1.0f, 0.0f, 0.0f};
+    l2_normalize3(v1);
+    l2_normalize3(tg);
+    const float cos_theta = (v1[0] * tg[0] + v1[1] * tg[1]) + v1[2] * tg[2];
+    float real_part = 1.0f + cos_theta;
+    float axis[3];
+    cross3(v1, tg, axis);
+    if (real_part < 1e-6f) { // antiparallel: an arbitrary axis orthogonal to v1 = e_x: |x| largest -> rotate around z: (-y, x, 0)
+        axis[0] = -v1[1]; axis[1] = v1[0]; axis[2] = 0.0f;
+        real_part = 0.0f;
+    }
+    float qt[4] = {axis[0], axis[1], axis[2], real_part};
+    {
+        float ss = ((qt[0] * qt[0] + qt[1] * qt[1]) + qt[2] * qt[2]) + qt[3] * qt[3];
+        ss = ss < 1e-12f ? 1e-12f : ss;
+        const float inv = 1.0f / sqrtf(ss);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qt[i] = qt[i] * inv;
+    }
+    float dot = ((qt[0] * qpf[0] + qt[1] * qpf[1]) + qt[2] * qpf[2]) + qt[3] * qpf[3];
+    dot = dot * (1.0f - 4.0f * (2.0f * 1.1920928955078125e-07f)); // safe_shrink by 4 eps_addition(float32)
+    oc = 2.0f * acosf(fabsf(dot));
+    // velocity error: | |v|^2 - speed^2 |, |v| = sqrt of the sum of squares, squared again
+    const float v = sqrtf((x[7] * x[7] + x[8] * x[8]) + x[9] * x[9]);
+    vc = fabsf(v * v - G->e3_gv * G->e3_gv);
+}
+
+// elipse_cost.py:124-139 state_cost = mS*position + mS*orientation + mV*velocity
+__device__ __forceinline__ float state_cost_e3(const GenConsts *__restrict__ G, const float (&x)[kGenS])
+{
+    float pc, oc, vc;
+    e3_terms(G, x, false, pc, oc, vc);
+    return (G->e3_mS * pc + G->e3_mS * oc) + G->e3_mV * vc;
+}
+
+// the cost_base slot of the 13-state kernels: wave-uniform branch on the cost the controller was built with
+__device__ __forceinline__ float gen_state_cost(const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const float (&x)[kGenS])
+{
+    if (C->state_cost_kind == MPPI_STATE_COST_QUAT) return state_cost_quat(C, G, x);
+    if (C->state_cost_kind == MPPI_STATE_COST_ELLIPSE3D) return state_cost_e3(G, x);
+    if (C->q_full) return state_cost<kGenS, true>(C, x);
+    return state_cost<kGenS, false>(C, x);
+}
+
+// ---------------------------------------------------------------------------------------- NNAUVModel on the vector ALU
+// (nn_model.py:215-239, 289-304) the Dense stack through the scalar cache, as k_rollout_mlp_small. The output layer is
+// padded to 14 columns (W3 [HID x 14], b3 [14], column 13 zero) on the host so that outputs stay pairs.
+template <int HID>
+__device__ __forceinline__ void nnauv_step(const MlpDev *__restrict__ M, const float *const (&Wp)[kMlpSmallMaxLayers],
+                                           const float *const (&bp)[kMlpSmallMaxLayers], int n_hidden,
+                                           const float (&xm)[kGenNin], const float (&xr)[kGenNin], float (&x)[kGenS], const float (&v)[kGenA])
+{
+    constexpr int H2 = HID / 2, S2 = (kGenS + 1) / 2;
+    float in[kGenNin];
+#pragma unroll
+    for (int i = 0; i < kGenS - 3; ++i) in[i] = (x[3 + i] - xm[i]) * xr[i];
+#pragma unroll
+    for (int i = 0; i < kGenA; ++i) in[kGenS - 3 + i] = (v[i] - xm[kGenS - 3 + i]) * xr[kGenS - 3 + i];
+    f32x2s ha[H2], hb[H2];
+    float hin[HID];
+    dense_pairs<kGenNin, H2, true>(Wp[0], bp[0], in, ha);
+    for (int l = 1; l < n_hidden; ++l) {
+#pragma unroll
+        for (int o2 = 0; o2 < H2; ++o2) { hin[2 * o2] = ha[o2].x; hin[2 * o2 + 1] = ha[o2].y; }
+        const float *Wl = l == 1 ? Wp[1] : Wp[2], *bl = l == 1 ? bp[1] : bp[2];
+        dense_pairs<HID, H2, true>(Wl, bl, hin, hb);
+#pragma unroll
+        for (int o2 = 0; o2 < H2; ++o2) ha[o2] = hb[o2];
+    }
+#pragma unroll
+    for (int o2 = 0; o2 < H2; ++o2) { hin[2 * o2] = ha[o2].x; hin[2 * o2 + 1] = ha[o2].y; }
+    f32x2s y[S2];
+    const float *Wo = n_hidden == 1 ? Wp[1] : (n_hidden == 2 ? Wp[2] : Wp[3]);
+    const float *bo = n_hidden == 1 ? bp[1] : (n_hidden == 2 ? bp[2] : bp[3]);
+    dense_pairs<HID, S2, false>(Wo, bo, hin, y);
+#pragma unroll
+    for (int i = 0; i < kGenS; ++i) {
+        const float yi = (i & 1) ? y[i / 2].y : y[i / 2].x;
+        x[i] = x[i] + (yi * M->ystd[i] + M->ymean[i]); // next_state = state + delta (nn_model.py:303-304)
+    }
+}
+
+// ---------------------------------------------------------------------------------------- the rollout kernel
+// MODEL: GEN_MODEL_AUV | GEN_MODEL_NNAUV ; HID: hidden width of the NNAUV network (16 | 32; ignored for the AUV model).
+// mode: MODE_ROLLOUT (costs + record) | MODE_COST_ONLY | MODE_COSTS_GIVEN (record from given costs) ; noise_out != NULL
+// additionally exports the noise the step used ([K, H, A], MPPI_DBG_NOISE) — and with MODE_NOISE_ONLY does nothing else.
+template <int MODEL, int HID>
+__global__ __launch_bounds__(64) void k_rollout_gen(
+    const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const MlpDev *__restrict__ M, const MlpSmallArgs P,
+    const float *__restrict__ x_dev, const float *__restrict__ U_dev, const float *__restrict__ eps_hbm,
+    const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
+    float *__restrict__ noise_out, const int SRC, const int MODE, const int rsb, const int rsc)
+{
+    constexpr int S = kGenS, A = kGenA;
+    constexpr bool DIAG = false;
+    const int H = C->H, HA = H * A, K = C->K_local;
+    const int NG = (H + 3) / 4;
+    const int lane = threadIdx.x;
+    const int k0 = blockIdx.x * 64;
+    const bool valid = (k0 + lane) < K;
+    const int kk = valid ? k0 + lane : K - 1; // lanes past K recompute the last sample, outside every sum
+    const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
+    const unsigned long long seed = C->seed;
+    const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)kk;
+    float c = 0.0f;
+    if (MODE == MODE_COSTS_GIVEN) {
+        c = cost[kk];
+    } else {
+        float xm[kGenNin], xr[kGenNin];
+        if (MODEL == GEN_MODEL_NNAUV) {
+#pragma unroll
+            for (int i = 0; i < kGenNin; ++i) { xm[i] = M->xmean[i]; xr[i] = 1.0f / M->xstd[i]; }
+        }
+        float x[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+        float z[4 * A];
+        for (int t = 0; t < H; ++t) {
+            if (SRC == SRC_PHILOX && (t & 3) == 0) normals_group<A>(seed, gk, base + (unsigned long long)(t >> 2), z);
+            float u[A], e[A], v[A];
+            if (SRC == SRC_PHILOX) {
+                float z1[A];
+#pragma unroll
+                for (int i = 0; i < A; ++i) { // z[(t & 3) * A + i] without a dynamically indexed register array
+                    float zi = z[i];
+#pragma unroll
+                    for (int tl = 1; tl < 4; ++tl) zi = (t & 3) == tl ? z[tl * A + i] : zi;
+                    z1[i] = zi;
+                }
+                scale_noise<A, DIAG>(C, z1, e);
+            } else {
+#pragma unroll
+                for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
+            }
+            if (noise_out != nullptr && valid) {
+#pragma unroll
+                for (int i = 0; i < A; ++i) noise_out[(size_t)kk * HA + t * A + i] = e[i];
+            }
+            if (MODE == MODE_NOISE_ONLY) continue;
+#pragma unroll
+            for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; } // to_apply, controller_base.cpp:258
+            const float ac = action_cost<A, DIAG>(C, u, e);
+            if (MODEL == GEN_MODEL_AUV) {
+                auv_step(G, x, v);
+            } else {
+                int zoff; // opaque zero offset: keeps the weight loads inside the horizon loop (see k_rollout_mlp_small)
+                asm("s_mov_b32 %0, 0" : "=s"(zoff) : "s"(t));
+                const float *Wp[kMlpSmallMaxLayers], *bp[kMlpSmallMaxLayers];
+#pragma unroll
+                for (int l = 0; l < kMlpSmallMaxLayers; ++l) { Wp[l] = P.W[l] + zoff; bp[l] = P.b[l] + zoff; }
+                nnauv_step<HID>(M, Wp, bp, P.n_layers - 1, xm, xr, x, v);
+            }
+            const float sc = gen_state_cost(C, G, x); // cost on the POST-step state
+            const float tmp = sc + ac;                // Step_cost_result cost_base.cpp:49
+            c = c + tmp;                              // path_cost        controller_base.cpp:268
+        }
+        if (MODE == MODE_NOISE_ONLY) return;
+        c = c + gen_state_cost(C, G, x); // terminal cost, controller_base.cpp:271-272
+        if (valid) cost[k0 + lane] = c;
+        if (MODE == MODE_COST_ONLY) return;
+    }
+    mlp_tile_record<A, DIAG, 1>(C, c, valid, 0, lane, kk, H, NG, SRC, eps_hbm, seed, gk, base,
+                                partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc);
+}
+
+// state / action / step cost of k samples on a 13-state handle (mppi_state_cost, mppi_action_cost, mppi_step_cost)
+__global__ void k_gen_costs(const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const float *__restrict__ x,
+                            const float *__restrict__ u, const float *__restrict__ eps, int k,
+                            float *__restrict__ out_state, float *__restrict__ out_action, float *__restrict__ out_step)
+{
+    const int a = C->a; // any action dimension (zero-padded instance: adding exact zeros changes no sum)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    float sc = 0.0f, ac = 0.0f;
+    if (x != nullptr) {
+        float xs[kGenS];
+#pragma unroll
+        for (int j = 0; j < kGenS; ++j) xs[j] = x[(size_t)i * kGenS + j];
+        sc = gen_state_cost(C, G, xs);
+    }
+    if (u != nullptr) {
+        float us[kMaxA], es[kMaxA];
+#pragma unroll
+        for (int j = 0; j < kMaxA; ++j) { us[j] = j < a ? u[j] : 0.0f; es[j] = j < a ? eps[(size_t)i * a + j] : 0.0f; }
+        ac = action_cost<kMaxA>(C, us, es);
+    }
+    if (out_state) out_state[i] = sc;
+    if (out_action) out_action[i] = ac;
+    if (out_step) out_step[i] = sc + ac;
+}
+
+// ElipseCost3D's three terms for k states -> out [k, 3] (position, orientation, velocity error)
+__global__ void k_e3_terms(const GenConsts *__restrict__ G, const float *__restrict__ x, int k, int in_plane, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    float xs[kGenS], pc, oc, vc;
+#pragma unroll
+    for (int j = 0; j < kGenS; ++j) xs[j] = x[(size_t)i * kGenS + j];
+    e3_terms(G, xs, in_plane != 0, pc, oc, vc);
+    out[(size_t)i * 3] = pc; out[(size_t)i * 3 + 1] = oc; out[(size_t)i * 3 + 2] = vc;
+}
+
+// D(nu) and C(nu) as the 6x6 MATRICES the reference builds (auv_model.py:482-545) — the rollout never materialises them
+// (auv_state_dot forms D nu and C nu directly); used by k_auv_pieces so that the reference's matrix expectations can be
+// checked on the device and the fast forms against the matrices.
+__device__ __forceinline__ void auv_damping_matrix(const GenConsts *__restrict__ G, const float (&vel)[6], float (&D)[36])
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float d1 = (-1.0f * G->lin_damp[i * 6 + j]) - (vel[0] * G->lin_damp_fwd[i * 6 + j]);
+            D[i * 6 + j] = i == j ? d1 + (-1.0f * (G->quad_damp[i] * fabsf(vel[i]))) : d1 + (-0.0f);
+        }
+}
+
+__device__ __forceinline__ void auv_coriolis_matrix(const GenConsts *__restrict__ G, const float (&vel)[6], float (&Cm)[36])
+{
+    float a[2][3];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float *m = G->mtot + (3 * blk + i) * 6;
+            a[blk][i] = ((m[0] * vel[0] + m[1] * vel[1]) + m[2] * vel[2]) + ((m[3] * vel[3] + m[4] * vel[4]) + m[5] * vel[5]);
+        }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) Cm[i] = 0.0f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const float *v = a[blk];
+        const float ns[9] = {-0.0f, v[2], -v[1], -v[2], -0.0f, v[0], v[1], -v[0], -0.0f}; // -skew(v)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (blk == 0) { Cm[i * 6 + 3 + j] = ns[i * 3 + j]; Cm[(3 + i) * 6 + j] = ns[i * 3 + j]; }
+                else Cm[(3 + i) * 6 + 3 + j] = ns[i * 3 + j];
+            }
+    }
+}
+
+// the pieces of AUVModel the reference's tests call one by one (scripts/test.py:264-539), per (state, action) pair:
+// out [k, 124] = rotBtoI [9] | TBtoIquat [12] | C nu [6] | D nu [6] | g [6] | state_dot [13] | D [36] | C [36]
+constexpr int kAuvPieces = 124;
+__global__ void k_auv_pieces(const GenConsts *__restrict__ G, const float *__restrict__ x, const float *__restrict__ u, int k,
+                             float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    float xs[kGenS], us[kGenA], xd[kGenS], rot[9], T[12], pc[18], D[36], Cm[36];
+#pragma unroll
+    for (int j = 0; j < kGenS; ++j) xs[j] = x[(size_t)i * kGenS + j];
+#pragma unroll
+    for (int j = 0; j < kGenA; ++j) us[j] = u[(size_t)i * kGenA + j];
+    const float q[4] = {xs[3], xs[4], xs[5], xs[6]};
+    const float vel[6] = {xs[7], xs[8], xs[9], xs[10], xs[11], xs[12]};
+    auv_b2i(q, rot, T);
+    auv_state_dot(G, xs, us, xd, pc);
+    auv_damping_matrix(G, vel, D);
+    auv_coriolis_matrix(G, vel, Cm);
+    float *o = out + (size_t)i * kAuvPieces;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) o[j] = rot[j];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) o[9 + j] = T[j];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) o[21 + j] = pc[j];
+#pragma unroll
+    for (int j = 0; j < kGenS; ++j) o[39 + j] = xd[j];
+#pragma unroll
+    for (int j = 0; j < 36; ++j) { o[52 + j] = D[j]; o[88 + j] = Cm[j]; }
+}
+
+} // namespace mppi

@@ -74,6 +74,8 @@ struct mppi_handle {
     // carry the dispatch's own begin/end timestamps (what rocprofv3 reports), not the stream-level gaps around it
     hipEvent_t kev0 = nullptr, kev1 = nullptr;
     std::string no_rollout; // non-empty: why this handle cannot run rollouts (helpers still work)
+    int is_gen = 0;         // model_base is AUVModel / NNAUVModel: rollouts run k_rollout_gen
+    void *gen = nullptr;    // 13-state AUV family (model AUV / NN_AUV; mppi_launch_gen.hip owns it): constants + device copy
     // transition log (m_db of the reference: addX/addU/addNext/toCSV, data_base.cpp:29-71): off until
     // mppi_set_transition_log gives it a capacity; a ring of rows (x | u | x_next | has_next), allocated once there
     std::vector<float> log_rows;
@@ -111,5 +113,16 @@ MPPI_DECL_A(mppi_launch_tile_a, MPPI_TILE_PARAMS)
 MPPI_DECL_A(mppi_launch_pc_a, MPPI_PC_PARAMS)
 MPPI_DECL_A(mppi_launch_mlp_a, MPPI_MLP_PARAMS)
 #undef MPPI_DECL_A
+// the 13-state AUV family (mppi_launch_gen.hip)
+const char *mppi_gen_fill(mppi_handle *h, const mppi_config *cfg); // NULL = ok, else why the config is invalid
+hipError_t mppi_gen_upload(mppi_handle *h);
+void mppi_gen_destroy(mppi_handle *h);
+hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, const float *x_dev, const float *U_dev, const float *eps,
+                           float *cost, float *part, float *noise_out);
+const char *mppi_gen_kernel_name(const mppi_handle *h);
+hipError_t mppi_gen_model_step(mppi_handle *h, hipStream_t st, const float *x, int kx, const float *v, int k, float *scratch, float *out_next);
+hipError_t mppi_gen_costs(mppi_handle *h, hipStream_t st, const float *x, const float *u, const float *eps, int k, float *os, float *oa, float *ot);
+hipError_t mppi_gen_auv_pieces(mppi_handle *h, hipStream_t st, const float *x, const float *u, int k, float *out);
+hipError_t mppi_gen_e3_terms(mppi_handle *h, hipStream_t st, const float *x, int k, int in_plane, float *out);
 #define MPPI_CAT_(a, b) a##b
 #define MPPI_CAT(a, b) MPPI_CAT_(a, b)

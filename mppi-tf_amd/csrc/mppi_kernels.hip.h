@@ -733,6 +733,7 @@ struct MlpDev {
     float xmean[kMaxS + kMaxA], xstd[kMaxS + kMaxA], ymean[kMaxS], ystd[kMaxS];
     int n_layers, widths[4];                  // every network: Dense layers l = 0 .. n_layers-1, [in x out] row-major
     const float *Wl[4], *bl[4];
+    int ld[4];                                // row stride of Wl[l]: widths[l], except an output layer padded to an even width (NNAUVModel: 13 -> 14)
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

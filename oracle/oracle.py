@@ -445,7 +445,8 @@ def auv_matrices(params):
     def mat(key):
         d = np.asarray(params.get(key, np.zeros(6)), np.float64)
         return np.diag(d) if d.shape == (6,) else d
-    return dict(mtot=mtot, inv_mtot=np.linalg.inv(mtot), lin_damp=mat("linear_damping"), lin_damp_fwd=mat("linear_damping_forward_speed"),
+    # the inverse through orc_mat_inverse (Gauss-Jordan, partial pivoting, double): deterministic, no LAPACK in the loop
+    return dict(mtot=mtot, inv_mtot=mat_inverse(mtot, np.float64), lin_damp=mat("linear_damping"), lin_damp_fwd=mat("linear_damping_forward_speed"),
                 quad_damp=np.asarray(params.get("quad_damping", np.zeros(6)), np.float64))
 
 

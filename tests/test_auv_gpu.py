@@ -1,0 +1,399 @@
+"""SURVEY §8f row 4 on the GPU: the 13-state AUV family in the model_base slot (AUVModel, NNAUVModel) and StaticQuatCost /
+ElipseCost3D in the cost_base slot, through the C-ABI, against the CPU oracle and the reference's own literals
+(scripts/test.py TestAUVModel :237-586, TestNNAUVModel :587-684, TestElipse3DCost :1164-1360).
+
+Bars: AUVModel pieces, steps and rollout costs BIT-IDENTICAL to the fp32 oracle (same operation order on both sides, both
+compiled without FMA contraction; the host constants come from the same double Gauss-Jordan inverse); the quaternion /
+3D-ellipse costs within 2e-6 relative (device acosf vs libm); learned-model rollouts as the other MLP kernels (costs within
+4x the fp32 CPU's own error against fp64). Control updates: |dU'| <= 1e-5 x the noise scale (north_star's 1e-5 for unit noise).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+CLOSE = dict(rtol=1e-6, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def m():
+    import __graft_entry__ as g
+    g.build()
+    import mppi_tf_amd as mod
+    return mod
+
+
+@pytest.fixture(scope="module")
+def G():
+    return load_golden("model_auv")
+
+
+def rand_states(k, seed=0, vel=1.0):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((k, 13))
+    x[:, 3:7] /= np.linalg.norm(x[:, 3:7], axis=1, keepdims=True)
+    x[:, 7:] *= vel
+    return x.astype(F32), (200.0 * rng.standard_normal((k, 6))).astype(F32)
+
+
+REXROV = None
+
+
+def rexrov(m):
+    from mppi_tf_amd.auv import auv_task
+    return auv_task(8)["auv"]
+
+
+# ------------------------------------------------------------------------------------------------ AUVModel
+def test_golden_auv_rotation_restoring_damping_coriolis_on_device(m, G):
+    """The reference's TestAUVModel through the device code, with the reference's method names."""
+    mdl = m.AUVModel(actionDim=6, dt=0.1, parameters=G["params"])
+    k = 3
+    mdl.set_k(k)
+    quat = np.zeros((k, 13, 1))
+    quat[:, 3:7, 0] = G["b2i"]["quat"]
+    pose, _ = mdl.prepare_data(quat)
+    mdl.body2inertial_transform(pose)
+    np.testing.assert_allclose(mdl._rotBtoI, G["b2i"]["rot_from_lib"], **CLOSE)
+    for i, (x, y, z, w) in enumerate(G["b2i"]["quat"]):
+        np.testing.assert_allclose(mdl._TBtoIquat[i], 0.5 * np.array([[w, -z, y], [z, w, -x], [-y, x, w], [-x, -y, -z]]), rtol=1e-7, atol=0)
+    jac = mdl.get_jacobian()
+    assert jac.shape == (k, 7, 6) and not jac[:, :3, 3:].any() and not jac[:, 3:, :3].any()
+    # test_restoring
+    r = G["restoring"]
+    pose = np.zeros((2, 7, 1))
+    pose[:, 3:7, 0] = r["quat"]
+    mdl.body2inertial_transform(pose)
+    np.testing.assert_allclose(mdl._rotBtoI, r["exp_rot"], rtol=1e-6, atol=2e-6)  # the test's quaternions carry 7 digits
+    np.testing.assert_allclose(mdl.restoring_forces("rest")[..., 0], r["exp_restoring"], rtol=2e-6, atol=5e-3)
+    # test_damping / test_corrolis: the 6x6 matrices
+    d = mdl.damping_matrix("damp", np.array(G["damping"]["vel"])[..., None])
+    np.testing.assert_allclose(d, G["damping"]["exp"], **CLOSE)
+    c = mdl.coriolis_matrix("coriolis", np.array([G["coriolis"]["vel"]])[..., None])
+    np.testing.assert_allclose(c[0], G["coriolis"]["exp"], **CLOSE)
+
+
+@pytest.mark.parametrize("params", ["test", "rexrov2"])
+def test_auv_pieces_bit_exact_and_fast_forms_equal_matrix_forms(m, G, params):
+    """Every intermediate of state_dot for 256 random (state, action) pairs: bit-identical to the fp32 oracle; and the rollout's
+    direct forms of D nu / C nu equal the 6x6 matrices (the reference's formulation) applied to nu."""
+    P = G["params"] if params == "test" else rexrov(m)
+    h = m.Handle(k=1, tau=1, s_dim=13, a_dim=6, sigma=np.eye(6), goal=np.zeros(13), auv=P)
+    o = orc.AuvModel(P, dtype=F32)
+    x, u = rand_states(256, 1, vel=2.0)
+    pc = h.auv_pieces(x, u)
+    for i in range(x.shape[0]):
+        rot, T = o.b2i(x[i, 3:7])
+        np.testing.assert_array_equal(pc["rot"][i], rot)
+        np.testing.assert_array_equal(pc["T"][i], T)
+        np.testing.assert_array_equal(pc["g"][i], o.restoring(x[i, 3:7]))
+        np.testing.assert_array_equal(pc["D"][i], o.damping(x[i, 7:]))
+        np.testing.assert_array_equal(pc["C"][i] + 0.0, o.coriolis(x[i, 7:]) + 0.0)  # (+0.0: -0 and +0 compare equal anyway)
+        np.testing.assert_array_equal(pc["xdot"][i], o.state_dot(x[i], u[i]))
+        Dv = np.array([np.add.reduce((pc["D"][i][r] * x[i, 7:]).astype(F32), dtype=F32) for r in range(6)])  # row sums in index order
+        np.testing.assert_allclose(pc["Dv"][i], Dv, rtol=3e-7, atol=0)
+        np.testing.assert_allclose(pc["Cv"][i], (pc["C"][i].astype(np.float64) @ x[i, 7:]), rtol=2e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize("rk", [1, 2, 4])
+def test_auv_step_bit_exact(m, G, rk):
+    """AUVModel.build_step_graph (Euler / Heun / the reference's rk4 expression + quaternion normalisation): device == fp32 oracle,
+    bit for bit, and within fp32 of the fp64 oracle. Includes the reference's own step inputs (scripts/test.py:541-586)."""
+    P = dict(G["params"], rk=rk)
+    mdl = m.AUVModel(actionDim=6, dt=0.1, parameters=P)
+    o32, o64 = orc.AuvModel(P, dtype=F32), orc.AuvModel(P, dtype=np.float64)
+    x, u = rand_states(200, 2)
+    x = np.vstack([x, np.array(G["step_inputs"]["state"], F32)])
+    u = np.vstack([u, np.array(G["step_inputs"]["action"], F32)])
+    got = mdl.build_step_graph("step", x[..., None], u[..., None])[..., 0]
+    ref = np.stack([o32.step(x[i], u[i]) for i in range(x.shape[0])])
+    np.testing.assert_array_equal(got, ref)
+    truth = np.stack([o64.step(x[i], u[i]) for i in range(x.shape[0])])
+    np.testing.assert_allclose(got, truth, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(np.linalg.norm(got[:, 3:7], axis=1), 1.0, atol=3e-7)
+
+
+# ------------------------------------------------------------------------------------------------ NNAUVModel
+def make_nnauv(seed=0, hid=32, n_hidden=3):
+    rng = np.random.default_rng(seed)
+    dims = [16] + [hid] * n_hidden + [13]
+    W = [(rng.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(F32) for i in range(n_hidden + 1)]
+    b = [(rng.uniform(-1, 1, dims[i + 1]) / np.sqrt(dims[i])).astype(F32) for i in range(n_hidden + 1)]
+    W[-1] *= 0.1
+    b[-1] *= 0.1
+    return dict(W=W, b=b, xmean=rng.uniform(-0.1, 0.1, 16).astype(F32), xstd=rng.uniform(0.8, 1.2, 16).astype(F32),
+                ymean=rng.uniform(-0.01, 0.01, 13).astype(F32), ystd=rng.uniform(0.8, 1.2, 13).astype(F32))
+
+
+def test_golden_nnauv_data_preparation(m):
+    """TestNNAUVModel's literals through the mirror class (host bookkeeping around the path)."""
+    g = load_golden("model_nnauv")
+    nn = m.NNAUVModel()
+    t = g["training_n1"]
+    X, Y = nn.prepare_training_data(np.array(t["state_t"])[..., None], np.array(t["state_t1"])[..., None], np.array(t["action"])[..., None])
+    np.testing.assert_allclose(X, t["exp_x"], **CLOSE)
+    np.testing.assert_allclose(Y, t["exp_y"], **CLOSE)
+    for key in ("prepare_n1", "prepare_n6"):
+        np.testing.assert_allclose(nn.prepare_data(np.array(g[key]["state"])[..., None], np.array(g[key]["action"])[..., None]), g[key]["exp"], **CLOSE)
+
+
+@pytest.mark.parametrize("hid,n_hidden", [(32, 3), (16, 3), (32, 1), (16, 2)])
+def test_nnauv_single_step_reference_order_is_bit_exact(m, hid, n_hidden):
+    mlp = make_nnauv(3, hid, n_hidden)
+    nn = m.NNAUVModel(weights=mlp)
+    nn.set_Xmean_Xstd(mlp["xmean"], mlp["xstd"])
+    nn.set_Ymean_Ystd(mlp["ymean"], mlp["ystd"])
+    p32 = orc.Problem(tau=2, s=13, a=6, sigma=np.eye(6), goal=np.zeros(13), nnauv=mlp)
+    x, u = rand_states(64, 4)
+    u = (u / 200).astype(F32)
+    got = nn.build_step_graph("nn", x[..., None], u[..., None])[..., 0]
+    np.testing.assert_array_equal(got, p32.model_next(x, u))
+
+
+# ------------------------------------------------------------------------------------------------ costs
+GOAL13 = [1.0, 2.0, -3.0, 0.0, 0.0, np.sin(0.2), np.cos(0.2)] + [0.0] * 6
+Q10 = np.diag([100.0] * 3 + [10.0] + [1.0] * 6) + 0.01
+
+
+def test_static_quat_cost_on_device(m):
+    x, _ = rand_states(300, 5)
+    cost = m.StaticQuatCost(1.0, 1.0, 1.0, np.eye(6), np.array(GOAL13)[:, None], Q10)
+    got = cost.state_cost("c", x[..., None]).ravel()
+    p64 = orc.Problem(tau=2, s=13, a=6, sigma=np.eye(6), goal=GOAL13, Q=Q10, quat_cost=True, dtype=np.float64)
+    np.testing.assert_allclose(got, p64.state_cost(x), rtol=3e-6)
+    d = np.stack([orc.quat_dist(x[i], GOAL13) for i in range(5)])
+    np.testing.assert_allclose(cost.dist(x[:5, :, None])[..., 0], d, rtol=1e-6, atol=1e-6)
+    with pytest.raises(AssertionError):
+        m.StaticQuatCost(1.0, 1.0, 1.0, np.eye(6), np.array(GOAL13)[:, None], np.eye(13))
+    # the step cost adds the Python action cost (cost_base.py:114-170)
+    u, eps = np.linspace(0.1, 0.6, 6), np.random.default_rng(0).standard_normal((300, 6))
+    step = cost.build_step_cost_graph("s", x[..., None], u[:, None], eps[..., None]).ravel()
+    pq = orc.Problem(tau=2, s=13, a=6, sigma=np.eye(6), goal=GOAL13, Q=Q10, quat_cost=True, action_cost=orc.ACTION_COST_PY, dtype=np.float64)
+    np.testing.assert_allclose(step, pq.step_cost(x, u, eps), rtol=3e-6)
+
+
+def test_golden_elipse3d_cost_on_device(m):
+    """TestElipse3DCost's literals through the device code with the reference's constructor and method names."""
+    g = load_golden("cost_elipse3d")
+    b, pl = g["base"], g["plane"]
+    col = lambda v: np.array(v, np.float64)[:, None]
+    mk = lambda normal, aVec, center: m.ElipseCost3D(1.0, 1.0, 1.0, np.eye(6), col(normal), col(aVec), col(b["axis"]), col(center),
+                                                     b["speed"], 1.0, b["m_state"], b["m_vel"])
+    for pc in g["prep_const"]:
+        c = mk(pc["normal"], pc["aVec"], pc["center"])
+        np.testing.assert_allclose(c.R, pc["exp_R"], **CLOSE)
+        np.testing.assert_allclose(c.t, col(pc["center"]), **CLOSE)
+    cost = mk(pl["normal"], pl["aVec"], pl["center"])
+    np.testing.assert_allclose(cost.position_error(np.array(g["position_error"]["position"])[..., None]).ravel(), g["position_error"]["exp"], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(cost.orientation_error(np.array(g["orientation_error"]["pose"])[..., None]), g["orientation_error"]["exp"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(cost.velocity_error(np.array(g["velocity_error"]["velocity"])[..., None]).ravel(), g["velocity_error"]["exp"], rtol=2e-6, atol=1e-6)
+    # state_cost (no expectation in the reference): against the oracle, the reference's three states + random ones
+    x = np.vstack([np.array(g["state_cost_inputs"], F32), rand_states(200, 6)[0]])
+    e3 = dict(normal=pl["normal"], aVec=pl["aVec"], axis=b["axis"], speed=b["speed"], m_state=b["m_state"], m_vel=b["m_vel"])
+    p64 = orc.Problem(tau=2, s=13, a=6, sigma=np.eye(6), goal=np.zeros(13), ellipse3d=e3, dtype=np.float64)
+    got = cost.state_cost("c", x[..., None]).ravel()
+    np.testing.assert_allclose(got, p64.state_cost(x), rtol=5e-6, atol=5e-6)
+
+
+# ------------------------------------------------------------------------------------------------ rollouts and control steps
+def auv_case(m, G, K, H, cost="quadratic", seed=0, **kw):
+    P = dict(G["params"])
+    sigma = 200.0 * np.eye(6)
+    if cost == "quadratic":
+        ck = dict(goal=GOAL13, Q=np.array([100.0] * 3 + [10.0] * 4 + [1.0] * 6))
+        ok = dict(ck)
+    elif cost == "dense":
+        Qd = np.diag([100.0] * 3 + [10.0] * 4 + [1.0] * 6) + 0.05
+        ck, ok = dict(goal=GOAL13, Q=Qd, q_is_full=True), dict(goal=GOAL13, Q=Qd)
+    elif cost == "quat":
+        ck = dict(goal=GOAL13, Q=Q10, quat_cost=True)
+        ok = dict(ck)
+    else:
+        e3 = dict(normal=[0.0, np.sin(0.3), np.cos(0.3)], aVec=[1.0, 0.0, 0.0], axis=[2.0, 1.5], speed=1.0, m_state=50.0, m_vel=5.0)
+        ck, ok = dict(ellipse3d=e3), dict(ellipse3d=e3, goal=np.zeros(13))
+    h = m.Handle(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, auv=P, seed=seed + 1, **ck, **kw)
+    mk = lambda dt: orc.Problem(tau=H, s=13, a=6, dt=0.1, lam=1.0, sigma=sigma, auv=P, threads=0, dtype=dt, **ok)
+    rng = np.random.default_rng(seed)
+    x0 = np.array([0.5, -0.5, 0.2, 0.0, 0.0, 0.0, 1.0, 0.3, 0.0, -0.1, 0.0, 0.05, 0.0], F32)
+    U = (50.0 * rng.standard_normal((H, 6))).astype(F32)
+    eps = (200.0 * rng.standard_normal((K, H, 6))).astype(F32)
+    return h, mk(F32), mk(np.float64), x0, U, eps
+
+
+@pytest.mark.parametrize("cost", ["quadratic", "dense", "quat", "ellipse3d"])
+@pytest.mark.parametrize("K,H", [(1024, 16), (100, 7)])
+def test_auv_rollout_costs_against_oracle(m, G, K, H, cost):
+    """mBuildModelGraph with the Fossen model: sample costs bit-identical to the fp32 oracle for the quadratic costs (diagonal and
+    dense Q), within 3e-6 relative for the quaternion / 3D-ellipse costs (acos); ragged K and a horizon that is no multiple of 4."""
+    h, p32, p64, x0, U, eps = auv_case(m, G, K, H, cost)
+    assert h.rollout_kernel_name() == "mppi::k_rollout_gen<0, 32>"
+    got = h.rollout_cost(x0, U, eps)
+    ref = p32.rollout_cost(x0, U, eps)
+    if cost in ("quadratic", "dense"):
+        np.testing.assert_array_equal(got, ref)
+    else:
+        np.testing.assert_allclose(got, ref, rtol=3e-6)
+    truth = p64.rollout_cost(x0, U, eps)
+    assert (np.abs(got - truth) / np.abs(truth)).max() < 4 * max((np.abs(ref - truth) / np.abs(truth)).max(), 1e-6)
+
+
+@pytest.mark.parametrize("cost", ["quadratic", "quat", "ellipse3d"])
+def test_auv_control_step_against_oracle(m, G, cost):
+    """One control step with injected noise, then the fused Philox step on its own exported noise: U' within 1e-5 x the noise
+    scale of the fp64 oracle; device noise = the oracle's Philox stream for a = 6; weights sum to 1."""
+    K, H = 2048, 12
+    h, p32, p64, x0, U, eps = auv_case(m, G, K, H, cost, seed=3)
+    h.set_action_sequence(U)
+    u = h.next_with_noise(x0, eps)
+    u64, U64, c64 = p64.next_with_noise(x0, U, eps)
+    u32, U32, c32 = p32.next_with_noise(x0, U, eps)
+    c = h.debug_get(m.DBG_COSTS)
+    if cost == "quadratic":
+        np.testing.assert_array_equal(c, c32)
+    eu, eu_cpu = np.abs(h.get_action_sequence() - U64).max() / 200.0, np.abs(np.asarray(U32, np.float64) - U64).max() / 200.0
+    print("AUV %s: max|dU'|/sigma GPU %.3g, fp32 CPU %.3g" % (cost, eu, eu_cpu))
+    assert eu <= max(1e-5, 4 * eu_cpu) and np.abs(u - u64).max() / 200.0 <= max(1e-5, 4 * eu_cpu)
+    assert abs(h.debug_get(m.DBG_WEIGHTS).astype(np.float64).sum() - 1) < 1e-5
+    # fused path
+    U_in = h.get_action_sequence()
+    x1 = p64.model_next([x0], [u64])[0].astype(F32)
+    u2 = h.next(x1)
+    noise = h.debug_get(m.DBG_NOISE)
+    np.testing.assert_allclose(noise / 200.0, orc.noise(h_seed(h), 1, 0, K, H, 6, 200.0 * np.eye(6)) / 200.0, rtol=0, atol=5e-6)
+    u64b, U64b, _ = p64.next_with_noise(x1, U_in, noise)
+    assert np.abs(h.get_action_sequence() - U64b).max() / 200.0 <= max(1e-5, 4 * eu_cpu)
+    assert np.abs(u2 - u64b).max() / 200.0 <= max(1e-5, 4 * eu_cpu)
+
+
+def h_seed(h):
+    return 4  # auv_case(seed=3) builds the handle with seed + 1
+
+
+def test_auv_sharded_equals_unsharded_and_normalize(m, G):
+    import torch
+    K, H, shards = 4096, 8, 4
+    full, p32, p64, x0, U, eps = auv_case(m, G, K, H, "quat", seed=5)
+    hs = [auv_case(m, G, K, H, "quat", seed=5, shard_rank=g, shard_count=shards)[0] for g in range(shards)]
+    full.set_action_sequence(U)
+    u_full = full.next(x0)
+    xd = torch.tensor(x0, device="cuda")
+    n = hs[0].record_size
+    recs = torch.zeros(shards * n, device="cuda")
+    us = [torch.zeros(6, device="cuda") for _ in range(shards)]
+    for g, hg in enumerate(hs):
+        hg.set_action_sequence(U)
+        hg.shard_partial(xd.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
+        hg.synchronize()
+    for g, hg in enumerate(hs):
+        hg.shard_finish(recs.data_ptr(), shards, us[g].data_ptr())
+        hg.synchronize()
+        np.testing.assert_array_equal(us[g].cpu().numpy(), us[0].cpu().numpy())
+        np.testing.assert_allclose(us[g].cpu().numpy() / 200.0, u_full / 200.0, rtol=0, atol=2e-6)
+        np.testing.assert_array_equal(hg.debug_get(m.DBG_COSTS), full.debug_get(m.DBG_COSTS)[hg.k_offset:hg.k_offset + hg.k_local])
+    # Py normalizeCost on a 13-state handle: cost pass, min/max, record pass on the normalised costs
+    hn = auv_case(m, G, 512, 6, "quadratic", seed=6, normalize_cost=True)[0]
+    _, p32n, p64n, x0n, Un, epsn = auv_case(m, G, 512, 6, "quadratic", seed=6)
+    hn.set_action_sequence(Un)
+    un = hn.next_with_noise(x0n, epsn)
+    u_ref, _, _ = p64n.next_with_noise(x0n, Un, epsn, normalize=True)
+    assert np.abs(un - u_ref).max() / 200.0 < 1e-5
+
+
+@pytest.mark.parametrize("hid,n_hidden", [(32, 3), (16, 2)])
+@pytest.mark.parametrize("cost", ["quadratic", "quat"])
+def test_nnauv_control_step_against_oracle(m, hid, n_hidden, cost):
+    """The learned 13-state model in the full path: NNAUVModel (input 16, output 13) with the quadratic or the quaternion cost —
+    the combination the point-mass MLP kernels fence off (s = 2a, diagonal Q, quadratic cost). Costs as close to fp64 as an fp32
+    CPU evaluation is (4x); U' at 1e-5 on unit noise; fused Philox step; 4-way sharding."""
+    import torch
+    K, H = 2048, 10
+    mlp = make_nnauv(7, hid, n_hidden)
+    sigma = 0.25 * np.eye(6)
+    ck = dict(goal=GOAL13, Q=np.array([10.0] * 3 + [5.0] * 4 + [1.0] * 6)) if cost == "quadratic" else dict(goal=GOAL13, Q=Q10 / 10, quat_cost=True)
+    cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv=mlp, seed=9, **ck)
+    h = m.Handle(**cfg)
+    assert h.rollout_kernel_name() == "mppi::k_rollout_gen<1, %d>" % hid
+    mk = lambda dt: orc.Problem(tau=H, s=13, a=6, lam=1.0, sigma=sigma, nnauv=mlp, threads=0, dtype=dt, **ck)
+    p32, p64 = mk(F32), mk(np.float64)
+    rng = np.random.default_rng(1)
+    x0 = np.array([0.5, -0.5, 0.2, 0.0, 0.0, 0.0, 1.0, 0.3, 0.0, -0.1, 0.0, 0.05, 0.0], F32)
+    U = (0.1 * rng.standard_normal((H, 6))).astype(F32)
+    eps = (0.25 * rng.standard_normal((K, H, 6))).astype(F32)
+    h.set_action_sequence(U)
+    u = h.next_with_noise(x0, eps)
+    u64, U64, c64 = p64.next_with_noise(x0, U, eps)
+    u32, U32, c32 = p32.next_with_noise(x0, U, eps)
+    c = h.debug_get(m.DBG_COSTS).astype(np.float64)
+    rel = lambda a: float((np.abs(a - c64) / np.abs(c64)).max())
+    eu, eu_cpu = float(np.abs(h.get_action_sequence() - U64).max()), float(np.abs(np.asarray(U32, np.float64) - U64).max())
+    print("NNAUV %dx%d %s: rel cost err GPU %.3g / CPU %.3g; max|dU'| GPU %.3g / CPU %.3g" % (hid, n_hidden, cost, rel(c), rel(c32.astype(np.float64)), eu, eu_cpu))
+    assert rel(c) < 2e-5 and rel(c) < 4 * max(rel(c32.astype(np.float64)), 1e-6)
+    assert eu <= max(1e-5, 4 * eu_cpu)
+    # fused Philox step on the exported noise + sharding
+    U_in = h.get_action_sequence()
+    u2 = h.next(x0)
+    noise = h.debug_get(m.DBG_NOISE)
+    np.testing.assert_allclose(noise, orc.noise(9, 1, 0, K, H, 6, sigma), rtol=0, atol=5e-6)
+    _, U64b, _ = p64.next_with_noise(x0, U_in, noise)
+    assert np.abs(h.get_action_sequence() - U64b).max() <= 1e-5
+    shards = 4
+    hs = [m.Handle(shard_rank=g, shard_count=shards, **cfg) for g in range(shards)]
+    xd = torch.tensor(x0, device="cuda")
+    n = hs[0].record_size
+    recs = torch.zeros(shards * n, device="cuda")
+    ud = torch.zeros(6, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for g, hg in enumerate(hs):
+        hg.set_action_sequence(U)
+        hg.set_step_counter(0)
+        hg.shard_partial(xd.data_ptr(), recs[g * n:(g + 1) * n].data_ptr(), st)
+    hs[0].shard_finish(recs.data_ptr(), shards, ud.data_ptr(), st)
+    torch.cuda.synchronize()
+    full = m.Handle(**cfg)
+    full.set_action_sequence(U)
+    np.testing.assert_allclose(ud.cpu().numpy(), full.next(x0), rtol=0, atol=2e-6)
+
+
+def test_python_controller_with_the_auv_model_and_quaternion_cost(m, G):
+    """ControllerBase(model=AUVModel, cost=StaticQuatCost) as scripts/main.py builds it for the AUV task: a few closed-loop steps
+    against the oracle stepping the same plant."""
+    K, H = 1024, 8
+    model = m.AUVModel(actionDim=6, dt=0.1, parameters=G["params"])
+    sigma = 200.0 * np.eye(6)
+    cost = m.StaticQuatCost(1.0, 1.0, 1.0, sigma, np.array(GOAL13)[:, None], Q10)
+    ctl = m.ControllerBase(model=model, cost=cost, k=K, tau=H, sDim=13, aDim=6, lam=1.0, sigma=sigma, seed=11)
+    p64 = orc.Problem(tau=H, s=13, a=6, lam=1.0, sigma=sigma, auv=G["params"], goal=GOAL13, Q=Q10, quat_cost=True, action_cost=orc.ACTION_COST_PY,
+                      threads=0, dtype=np.float64)
+    x = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0] + [0.0] * 6)
+    U = np.zeros((H, 6))
+    for step in range(3):
+        u = ctl.next(x[:, None])
+        noise = ctl._h.debug_get(m.DBG_NOISE)
+        u64, U, _ = p64.next_with_noise(x, U, noise)
+        assert np.abs(u - u64).max() / 200.0 < 1e-5, step
+        x = p64.model_next([x], [u64])[0]
+    assert np.isfinite(x).all()
+
+
+def test_auv_family_argument_errors(m, G):
+    with pytest.raises(m.MppiError) as e:
+        m.Handle(k=64, tau=4, s_dim=12, a_dim=6, sigma=np.eye(6), goal=np.zeros(12), auv=G["params"])
+    assert e.value.status == 1 and "13" in str(e.value)
+    with pytest.raises(m.MppiError) as e:
+        m.Handle(k=64, tau=4, s_dim=13, a_dim=6, sigma=np.eye(6), goal=np.zeros(13), auv=dict(G["params"], rk=3))
+    assert e.value.status == 1 and "rk" in str(e.value)
+    with pytest.raises(m.MppiError) as e:
+        m.Handle(k=64, tau=4, s_dim=13, a_dim=6, sigma=np.eye(6), goal=np.zeros(13), auv=dict(G["params"], mass=-1.0))
+    assert e.value.status == 1
+    bad = make_nnauv(0, 64, 2)
+    with pytest.raises(m.MppiError) as e:
+        m.Handle(k=64, tau=4, s_dim=13, a_dim=6, sigma=np.eye(6), goal=np.zeros(13), nnauv=bad)
+    assert e.value.status == 4 and "16 or 32" in str(e.value)
+    with pytest.raises(m.MppiError) as e:  # the quaternion cost needs a 13-state model to roll out
+        m.Handle(k=64, tau=4, s_dim=13, a_dim=6, sigma=np.eye(6), goal=GOAL13, Q=Q10, quat_cost=True)
+    assert e.value.status == 4
+    with pytest.raises(m.MppiError):
+        m.Handle(k=1, tau=1, s_dim=13, a_dim=6, sigma=np.eye(6), goal=np.zeros(13)).auv_pieces(np.zeros((1, 13)), np.zeros((1, 6)))
