@@ -324,6 +324,34 @@ mppi_status mppi_profile_end(mppi_handle *h, float *rollout_ms_avg, float *finis
  * (e.g. "mppi::k_rollout_pc<3, 3, 6, true>"): what a roofline figure of this handle refers to. */
 mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf, size_t n);
 
+/* ---- the learner of the learned model_base (replaces LearnerBase.train / _train_step, learners/learner_base.py:324-358,
+ * 469-496; train_all :146-153) --------------------------------------------------------------------------------------------
+ * Full-batch Adam on the mean squared error of the network's prediction against the (normalised) targets, for the
+ * reference's Dense networks (nn_model.py:54-60; widths <= 32, 1-4 layers, relu on the hidden layers). The data preparation
+ * (prepare_training_data, normalisation statistics, augmentation) is host bookkeeping in the caller; what runs on the
+ * device is forward, loss, backward (the weight-gradient GEMMs over the batch on the matrix cores, exact fp32) and the Adam
+ * update — a train loop of many steps needs no host round trip. Its weights are what mppi_config.mlp of an
+ * MPPI_MODEL_NN_AUV / MPPI_MODEL_MLP controller takes. Deterministic (no float atomics). Not thread-safe per learner. */
+typedef struct mppi_learner mppi_learner;
+/* widths[n_layers + 1] = inputs, hidden widths..., outputs; W[l] is [widths[l] x widths[l+1]] row-major (Keras kernel), b[l] [widths[l+1]] */
+mppi_status mppi_learner_create(int n_layers, const int32_t *widths, const float *const *W, const float *const *b, int device,
+                                mppi_learner **out);
+void mppi_learner_destroy(mppi_learner *l);
+const char *mppi_learner_last_error(const mppi_learner *l);
+/* the training set: X [n, inputs], Y [n, outputs] (copied to the device) */
+mppi_status mppi_learner_set_data(mppi_learner *l, const float *X, const float *Y, int n);
+/* `steps` Adam steps (tf.optimizers.Adam's update: m, v, lr*sqrt(1-b2^t)/(1-b1^t), eps outside the root; Keras defaults
+ * beta1 0.9, beta2 0.999, eps 1e-7). loss_first / loss_last (may be NULL): the loss of the first / last step's forward pass. */
+mppi_status mppi_learner_train(mppi_learner *l, int steps, float lr, float beta1, float beta2, float eps, float *loss_first, float *loss_last);
+/* loss of the CURRENT weights on the training set, no update; grads_out (NULL or [n_layers*33*32]: per layer rows 0..31 = dLoss/dW
+ * padded to 32 x 32, row 32 = dLoss/db) ; pred_out (NULL or [n, outputs]) */
+mppi_status mppi_learner_evaluate(mppi_learner *l, float *loss_out, float *grads_out, float *pred_out);
+mppi_status mppi_learner_get_weights(mppi_learner *l, float *const *W, float *const *b);
+mppi_status mppi_learner_set_weights(mppi_learner *l, const float *const *W, const float *const *b);
+/* forget the Adam moments and the step count (a new tf.optimizers.Adam, learner_base.py:149) */
+mppi_status mppi_learner_reset_optimizer(mppi_learner *l);
+mppi_status mppi_learner_get_step(mppi_learner *l, int *step);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,17 @@ SIGNATURES = {
     "mppi_profile_begin": (C.c_int, [_H, C.c_int]),
     "mppi_profile_end": (C.c_int, [_H, FP, FP, C.POINTER(C.c_int)]),
     "mppi_rollout_kernel_name": (C.c_int, [_H, C.c_char_p, C.c_size_t]),
+    # the learner (LearnerBase.train / _train_step)
+    "mppi_learner_create": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(FP), C.POINTER(FP), C.c_int, C.POINTER(_H)]),
+    "mppi_learner_destroy": (None, [_H]),
+    "mppi_learner_last_error": (C.c_char_p, [_H]),
+    "mppi_learner_set_data": (C.c_int, [_H, FP, FP, C.c_int]),
+    "mppi_learner_train": (C.c_int, [_H, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, FP, FP]),
+    "mppi_learner_evaluate": (C.c_int, [_H, FP, FP, FP]),
+    "mppi_learner_get_weights": (C.c_int, [_H, C.POINTER(FP), C.POINTER(FP)]),
+    "mppi_learner_set_weights": (C.c_int, [_H, C.POINTER(FP), C.POINTER(FP)]),
+    "mppi_learner_reset_optimizer": (C.c_int, [_H]),
+    "mppi_learner_get_step": (C.c_int, [_H, C.POINTER(C.c_int)]),
 }
 
 _lib = None
@@ -503,3 +514,84 @@ def shift(U, init, nb):
     if st != OK:
         raise MppiError(st, "mppi_shift")
     return out
+
+
+class Learner:
+    """RAII wrapper of one mppi_learner: full-batch Adam on the MSE of a small Dense network, on the GPU (mppi_learner.hip).
+    weights: dict(W=[...], b=[...]) (Keras [in x out] kernels); widths <= 32, 1-4 layers."""
+
+    def __init__(self, weights, device=0):
+        lib = self.lib = load()
+        self.Ws = [f32(w) for w in weights["W"]]
+        self.bs = [f32(b).ravel() for b in weights["b"]]
+        self.widths = [self.Ws[0].shape[0]] + [w.shape[1] for w in self.Ws]
+        wd = (C.c_int32 * len(self.widths))(*self.widths)
+        self.h = _H()
+        st = lib.mppi_learner_create(len(self.Ws), wd, self._ptrs(self.Ws), self._ptrs(self.bs), device, C.byref(self.h))
+        if st != OK:
+            self.h = _H()
+            raise MppiError(st, (lib.mppi_learner_last_error(None) or b"").decode())
+        self.n = 0
+
+    @staticmethod
+    def _ptrs(arrs):
+        return (FP * len(arrs))(*[fp(a) for a in arrs])
+
+    def _check(self, st):
+        if st != OK:
+            raise MppiError(st, (self.lib.mppi_learner_last_error(self.h) or b"").decode())
+
+    def close(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self.lib.mppi_learner_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_data(self, X, Y):
+        X, Y = f32(X, (-1, self.widths[0])), f32(Y, (-1, self.widths[-1]))
+        assert X.shape[0] == Y.shape[0]
+        self.n = X.shape[0]
+        self._check(self.lib.mppi_learner_set_data(self.h, fp(X), fp(Y), self.n))
+
+    def train(self, steps, lr, beta1=0.9, beta2=0.999, eps=1e-7):
+        """`steps` Adam steps (Keras defaults) -> (loss of the first step's forward pass, loss of the last step's)"""
+        first, last = np.zeros(1, np.float32), np.zeros(1, np.float32)
+        self._check(self.lib.mppi_learner_train(self.h, int(steps), lr, beta1, beta2, eps, fp(first), fp(last)))
+        return float(first[0]), float(last[0])
+
+    def evaluate(self, grads=False, pred=False):
+        """loss of the current weights on the training set [, gradients as dict(W=[...], b=[...])] [, predictions]"""
+        loss = np.zeros(1, np.float32)
+        g = np.zeros((len(self.Ws), 33, 32), np.float32) if grads else None
+        p = np.zeros((self.n, self.widths[-1]), np.float32) if pred else None
+        self._check(self.lib.mppi_learner_evaluate(self.h, fp(loss), fp(g), fp(p)))
+        out = [float(loss[0])]
+        if grads:
+            out.append(dict(W=[g[l, :self.widths[l], :self.widths[l + 1]].copy() for l in range(len(self.Ws))],
+                            b=[g[l, 32, :self.widths[l + 1]].copy() for l in range(len(self.Ws))]))
+        if pred:
+            out.append(p)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def get_weights(self):
+        Ws = [np.zeros_like(w) for w in self.Ws]
+        bs = [np.zeros_like(b) for b in self.bs]
+        self._check(self.lib.mppi_learner_get_weights(self.h, self._ptrs(Ws), self._ptrs(bs)))
+        return dict(W=Ws, b=bs)
+
+    def set_weights(self, weights):
+        Ws, bs = [f32(w) for w in weights["W"]], [f32(b).ravel() for b in weights["b"]]
+        self._check(self.lib.mppi_learner_set_weights(self.h, self._ptrs(Ws), self._ptrs(bs)))
+
+    def reset_optimizer(self):
+        self._check(self.lib.mppi_learner_reset_optimizer(self.h))
+
+    def step_count(self):
+        v = C.c_int(0)
+        self._check(self.lib.mppi_learner_get_step(self.h, C.byref(v)))
+        return int(v.value)

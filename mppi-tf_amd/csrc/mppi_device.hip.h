@@ -161,6 +161,65 @@ __device__ __forceinline__ uint4 philox4x32_10_block(unsigned long long seed, un
     return uint4{c0, c1, c2, c3};
 }
 
+// The same block function for the rollout kernels' counters, where the BLOCK index (and the key) is wave-uniform and the
+// subsequence is a per-lane sample index below 2^32 (k_offset and K are ints): in the first three rounds half of the state
+// is then uniform, so those products run on the scalar unit and the three-input xors become a scalar xor + ONE v_xor_b32 with
+// an SGPR operand — instead of a v_bitop3_b32 (1.7x the issue cost of v_xor) that needs two v_mov to bring its two scalar
+// operands into VGPRs (VOP3 reads one SGPR). Bit-identical to philox4x32_10_block(seed, subsequence, block) by construction
+// (same integer arithmetic, regrouped xors); checked against rocRAND's engine by the noise parity tests.
+__device__ __forceinline__ uint4 philox4x32_10_block_ub(unsigned long long seed, unsigned int subsequence_lo, unsigned long long block_uniform)
+{
+    const unsigned int c0s = (unsigned int)block_uniform, c1s = (unsigned int)(block_uniform >> 32);
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+    // round 0: c0, c1 uniform; c2 = the lane's sample; c3 = 0
+    const unsigned long long m0s = (unsigned long long)ROCRAND_PHILOX_M4x32_0 * c0s; // scalar
+    unsigned long long m1 = (unsigned long long)ROCRAND_PHILOX_M4x32_1 * subsequence_lo;
+    const unsigned int a0 = (unsigned int)(m1 >> 32) ^ (c1s ^ k0), a1 = (unsigned int)m1;
+    const unsigned int a2s = (unsigned int)(m0s >> 32) ^ k1, a3s = (unsigned int)m0s;      // uniform
+    k0 += ROCRAND_PHILOX_W32_0; k1 += ROCRAND_PHILOX_W32_1;
+    // round 1: c0 = a0, c1 = a1 per lane; c2 = a2s, c3 = a3s uniform
+    unsigned long long m0 = (unsigned long long)ROCRAND_PHILOX_M4x32_0 * a0;
+    const unsigned long long m1s = (unsigned long long)ROCRAND_PHILOX_M4x32_1 * a2s;        // scalar
+    const unsigned int b0 = a1 ^ ((unsigned int)(m1s >> 32) ^ k0), b1s = (unsigned int)m1s;
+    const unsigned int b2 = (unsigned int)(m0 >> 32) ^ (a3s ^ k1), b3 = (unsigned int)m0;
+    k0 += ROCRAND_PHILOX_W32_0; k1 += ROCRAND_PHILOX_W32_1;
+    // round 2: c1 = b1s uniform, the rest per lane
+    m0 = (unsigned long long)ROCRAND_PHILOX_M4x32_0 * b0;
+    m1 = (unsigned long long)ROCRAND_PHILOX_M4x32_1 * b2;
+    unsigned int c0 = (unsigned int)(m1 >> 32) ^ (b1s ^ k0), c1 = (unsigned int)m1;
+    unsigned int c2 = __builtin_amdgcn_bitop3_b32((unsigned int)(m0 >> 32), b3, k1, 0x96), c3 = (unsigned int)m0;
+    k0 += ROCRAND_PHILOX_W32_0; k1 += ROCRAND_PHILOX_W32_1;
+#pragma unroll
+    for (int r = 3; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)ROCRAND_PHILOX_M4x32_0 * c0;
+        const unsigned long long p1 = (unsigned long long)ROCRAND_PHILOX_M4x32_1 * c2;
+        const unsigned int n0 = __builtin_amdgcn_bitop3_b32((unsigned int)(p1 >> 32), c1, k0, 0x96);
+        const unsigned int n2 = __builtin_amdgcn_bitop3_b32((unsigned int)(p0 >> 32), c3, k1, 0x96);
+        c0 = n0; c1 = (unsigned int)p1; c2 = n2; c3 = (unsigned int)p0;
+        k0 += ROCRAND_PHILOX_W32_0; k1 += ROCRAND_PHILOX_W32_1;
+    }
+    return uint4{c0, c1, c2, c3};
+}
+
+// normals_group for a wave-uniform group index and a sample index below 2^32 (the rollout kernels' case)
+template <int A>
+__device__ __forceinline__ void normals_group_ub(unsigned long long seed, unsigned int gk_lo, unsigned long long group_index_uniform,
+                                                 float (&z)[4 * A])
+{
+#pragma unroll
+    for (int q = 0; q < A; ++q) {
+#if defined(MPPI_ROCRAND_NORMALS)
+        PhiloxAt eng(seed, (unsigned long long)gk_lo, 4ull * (group_index_uniform * A + q));
+        const float4 n = rocrand_device::detail::normal_distribution4(eng.block());
+        z[4 * q + 0] = n.x; z[4 * q + 1] = n.y; z[4 * q + 2] = n.z; z[4 * q + 3] = n.w;
+#else
+        const uint4 r = philox4x32_10_block_ub(seed, gk_lo, group_index_uniform * A + q);
+        const float2 n0 = box_muller_hw(r.x, r.y), n1 = box_muller_hw(r.z, r.w);
+        z[4 * q + 0] = n0.x; z[4 * q + 1] = n0.y; z[4 * q + 2] = n1.x; z[4 * q + 3] = n1.y;
+#endif
+    }
+}
+
 template <int A>
 __device__ __forceinline__ void normals_group(unsigned long long seed, unsigned long long gk,
                                               unsigned long long group_index, float (&z)[4 * A])
@@ -337,7 +396,7 @@ __device__ __forceinline__ float action_cost(const CT *__restrict__ C, const flo
 
 // ----------------------------------------------------------------------------------------
 // wavefront (64-lane) butterflies: fixed order, deterministic.
-__device__ __forceinline__ float wave_min(float v)
+__device__ __forceinline__ float wave_min_bpermute(float v) // the LDS-crossbar form (ds_bpermute_b32: 24 issue cycles + its latency per level)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
@@ -349,7 +408,7 @@ __device__ __forceinline__ float wave_max(float v)
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
-__device__ __forceinline__ float wave_sum(float v)
+__device__ __forceinline__ float wave_sum_bpermute(float v)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = v + __shfl_xor(v, off, 64);
@@ -381,6 +440,25 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
     const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
     return (s0 + s1) + (s2 + s3);
 }
+
+// min over the 64 lanes, every lane gets it: the same DPP ladder (min is exact in any order)
+__device__ __forceinline__ float wave_min_dpp(float v)
+{
+    v = fminf(v, dpp_mov<0xB1>(v));
+    v = fminf(v, dpp_mov<0x4E>(v));
+    v = fminf(v, dpp_mov<0x141>(v));
+    v = fminf(v, dpp_mov<0x140>(v));
+    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return fminf(fminf(s0, s1), fminf(s2, s3));
+}
+// The tile soft-min of every rollout kernel (beta_b = min, eta_b = sum over a tile's 64 lanes) runs on these: no LDS
+// crossbar on the critical tail of a tile (12 dependent ds_bpermute round trips before, ~0.5 us per tile). One fixed
+// association for every kernel, so kernels that must agree on a record (k_rollout_pc / k_rollout_tile) still do.
+__device__ __forceinline__ float wave_min(float v) { return wave_min_dpp(v); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
 // ----------------------------------------------------------------------------------------
 // Transposing butterfly: sums N per-lane values ACROSS the 64 lanes for N independent columns at once. Each level

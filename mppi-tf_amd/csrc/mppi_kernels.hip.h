@@ -233,7 +233,11 @@ __device__ __forceinline__ void pc_set_prio(int i, int n, int gen)
 
 // NP producers + 1 consumer = NP+1 wavefronts per workgroup; a chunk = one horizon group (4 steps)
 // from every producer = 4·NP steps; two chunk buffers of (A+1) floats per (step, lane).
-__host__ __device__ inline size_t pc_lds_floats(int A, int NP) { return (size_t)2 * 4 * NP * (A + 1) * 64; }
+// floats per (step, lane) slot of a chunk: the A perturbed actions + the action cost, padded so that ONE LDS instruction moves
+// a slot (ds_write_b64 / _b128 by the producer, ds_read_b64 / _b128 by the consumer: a quarter of the LDS instructions and
+// waits of the dword layout [step][value][lane]); a_dim = 4 (5 values) keeps the dword layout
+__host__ __device__ constexpr int pc_slot_floats(int A) { return A == 1 ? 2 : (A == 2 || A == 3) ? 4 : A + 1; }
+__host__ __device__ inline size_t pc_lds_floats(int A, int NP) { return (size_t)2 * 4 * NP * pc_slot_floats(A) * 64; }
 
 template <int A, int NP, int NSLOT, bool DIAG>
 __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) void k_rollout_pc(
@@ -245,7 +249,10 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
     constexpr int S = 2 * A;
     constexpr int NW = NP + 1;
     constexpr int CS = 4 * NP;                // steps per chunk
-    constexpr int CH = CS * (A + 1) * 64;     // floats per chunk buffer: [CS][(A+1)][64 lanes]
+    constexpr int SLOT = pc_slot_floats(A);   // floats per (step, lane)
+    constexpr bool PACKED = SLOT != A + 1 || A == 3; // [CS][64 lanes][SLOT], one LDS instruction per slot; else [CS][(A+1)][64 lanes] dwords
+    constexpr int CH = CS * SLOT * 64;        // floats per chunk buffer
+    typedef float slot_t __attribute__((ext_vector_type(SLOT == 2 ? 2 : 4)));
     constexpr int NREG = NSLOT * 4 * A;       // noise values a producer lane keeps
     const int H = C->H;
     const int K = C->K_local;
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
     if (wave != 0) {
         // ------------------------------------------------------------------ producers
         const int p = wave - 1;
-        const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)(k0 + lane);
+        const unsigned int gk = (unsigned int)C->k_offset + (unsigned int)(k0 + lane); // the global sample index: below 2^31 + 64
         const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
         const unsigned long long seed = C->seed;
         float eps_r[NREG];
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
             const int g = NP * i + p;
             if (balance) pc_set_prio(i, nch, gen);
             if (i < nch) { // chunk i exists (wave-uniform)
-                float *cb = buf + (i & 1) * CH + (size_t)(4 * p) * (A + 1) * 64;
+                float *cb = buf + (i & 1) * CH + (size_t)(4 * p) * SLOT * 64;
                 if (g < NG) {
                     // the nominal actions of the group's 4 steps: scalar loads issued ahead of the Philox rounds that
                     // hide them (mPrepareAction controller_base.cpp:205-208); steps past the horizon are never consumed
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
 #pragma unroll
                     for (int j = 0; j < 4 * A; ++j) z[j] = (float)((int)((gk * 2654435761ull + (base + g) * 40503ull + j) & 1023) - 512) * (1.0f / 512.0f);
 #else
-                    normals_group<A>(seed, gk, base + (unsigned long long)g, z);
+                    normals_group_ub<A>(seed, gk, base + (unsigned long long)g, z);
 #endif
 #pragma unroll
                     for (int tl = 0; tl < 4; ++tl) {
@@ -336,13 +343,25 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
                         // 19 cycles per instruction on this part against 2.3 for the multiply (tools/micro/valu_issue.hip).
                         // (Copying e into eps_r through an operation also keeps hipcc at 94 live VGPRs instead of 114.)
                         const float keep = t < H ? 1.0f : 0.0f;
+                        float slot[SLOT];
+#pragma unroll
+                        for (int j = 0; j < SLOT; ++j) slot[j] = 0.0f;
 #pragma unroll
                         for (int j = 0; j < A; ++j) {
                             u[j] = ug[tl][j];
                             eps_r[(i * 4 + tl) * A + j] = e[j] * keep;
-                            cb[(tl * (A + 1) + j) * 64 + lane] = u[j] + e[j]; // to_apply, :258
+                            slot[j] = u[j] + e[j]; // to_apply, :258
                         }
-                        cb[(tl * (A + 1) + A) * 64 + lane] = action_cost<A, DIAG>(PC, u, e);
+                        slot[A] = action_cost<A, DIAG>(PC, u, e);
+                        if constexpr (PACKED) {
+                            slot_t sv;
+#pragma unroll
+                            for (int j = 0; j < SLOT; ++j) sv[j] = slot[j];
+                            *static_cast<slot_t *>(__builtin_assume_aligned(cb + (tl * 64 + lane) * SLOT, SLOT * 4)) = sv;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j <= A; ++j) cb[(tl * (A + 1) + j) * 64 + lane] = slot[j];
+                        }
                     }
                 }
                 MPPI_STAMP(16 + 10 * p + (i < 7 ? i : 6));
@@ -398,10 +417,17 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
 #else
             for (int tl = 0; tl < tend; ++tl) {
 #endif
-                float v[A];
+                float v[A], ac;
+                if constexpr (PACKED) {
+                    const slot_t sv = *static_cast<const slot_t *>(__builtin_assume_aligned(cb + (tl * 64 + lane) * SLOT, SLOT * 4));
 #pragma unroll
-                for (int j = 0; j < A; ++j) v[j] = cb[(tl * (A + 1) + j) * 64 + lane];
-                const float ac = cb[(tl * (A + 1) + A) * 64 + lane];
+                    for (int j = 0; j < A; ++j) v[j] = sv[j];
+                    ac = sv[A];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < A; ++j) v[j] = cb[(tl * (A + 1) + j) * 64 + lane];
+                    ac = cb[(tl * (A + 1) + A) * 64 + lane];
+                }
                 pm_step<A>(CC, x, v);
                 const float sc = state_cost<S, false>(CC, x); // cost on the POST-step state
                 const float tmp = sc + ac;                    // Step_cost_result cost_base.cpp:49

@@ -434,28 +434,30 @@ def skew(v):
 def auv_matrices(params):
     """auv_model.py:186-262 in fp64 (the reference's dtype): -> dict(mtot, inv_mtot, lin_damp, lin_damp_fwd, quad_damp), matrices [6,6].
     rigid-body mass = [[m I, -m S(cog)], [m S(cog), inertial]] (:247-251), total = rigid body + added mass (:253-254)."""
-    m = float(params["mass"])
-    cog = np.asarray(params["cog"], np.float64)
+    r32 = lambda v: np.asarray(v, np.float32).astype(np.float64)  # the parameters ARE fp32 numbers (the C-ABI's mppi_auv_desc carries floats)
+    m = float(r32(params["mass"]))
+    cog = r32(params["cog"])
     i = params["inertial"]
-    inertial = np.array([[i["ixx"], i["ixy"], i["ixz"]], [i["ixy"], i["iyy"], i["iyz"]], [i["ixz"], i["iyz"], i["izz"]]], np.float64)
+    inertial = r32([[i["ixx"], i["ixy"], i["ixz"]], [i["ixy"], i["iyy"], i["iyz"]], [i["ixz"], i["iyz"], i["izz"]]])
     lower = m * skew(cog)
     rb = np.block([[m * np.eye(3), -lower], [lower, inertial]])
-    mtot = rb + np.asarray(params.get("Ma", np.zeros((6, 6))), np.float64)
+    mtot = rb + r32(params.get("Ma", np.zeros((6, 6))))
 
     def mat(key):
-        d = np.asarray(params.get(key, np.zeros(6)), np.float64)
+        d = r32(params.get(key, np.zeros(6)))
         return np.diag(d) if d.shape == (6,) else d
     # the inverse through orc_mat_inverse (Gauss-Jordan, partial pivoting, double): deterministic, no LAPACK in the loop
     return dict(mtot=mtot, inv_mtot=mat_inverse(mtot, np.float64), lin_damp=mat("linear_damping"), lin_damp_fwd=mat("linear_damping_forward_speed"),
-                quad_damp=np.asarray(params.get("quad_damping", np.zeros(6)), np.float64))
+                quad_damp=r32(params.get("quad_damping", np.zeros(6))))
 
 
 def fill_auv(I, c, params, dt):
     mats = auv_matrices(params)
-    c.mass, c.volume, c.density = params["mass"], params["volume"], params["density"]
-    c.gravity, c.dt, c.rk = 9.81, params.get("dt", dt), int(params.get("rk", 1))  # auv_model.py:236, :111-114
+    r32 = lambda v: float(np.float32(v))
+    c.mass, c.volume, c.density = r32(params["mass"]), r32(params["volume"]), r32(params["density"])
+    c.gravity, c.dt, c.rk = r32(9.81), r32(params.get("dt", dt)), int(params.get("rk", 1))  # auv_model.py:236, :111-114
     for i in range(3):
-        c.cog[i], c.cob[i] = params["cog"][i], params["cob"][i]
+        c.cog[i], c.cob[i] = r32(params["cog"][i]), r32(params["cob"][i])
     for key in ("mtot", "inv_mtot", "lin_damp", "lin_damp_fwd"):
         flat = mats[key].ravel()
         arr = getattr(c, key)

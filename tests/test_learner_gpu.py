@@ -1,0 +1,161 @@
+"""The learner of the learned model_base on the GPU (csrc/mppi_learner.hip; LearnerBase.train / _train_step,
+scripts/src/learners/learner_base.py:324-358, 469-496) against a torch-CPU fp32 reference of the same update: autograd for the
+gradients of mean((nn(X) - Y)^2), tf.keras.optimizers.Adam's update written out in numpy for the step. Then the loop the
+reference closes: transitions of the (device) Fossen AUVModel -> LearnerBase(NNAUVModel) -> trained weights -> the NNAUVModel
+controller rolls them out."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def m():
+    import __graft_entry__ as g
+    g.build()
+    import mppi_tf_amd as mod
+    return mod
+
+
+def make_net(dims, seed=0):
+    rng = np.random.default_rng(seed)
+    return dict(W=[(rng.uniform(-1, 1, (dims[i], dims[i + 1])) * np.sqrt(6.0 / (dims[i] + dims[i + 1]))).astype(F32) for i in range(len(dims) - 1)],
+                b=[(0.1 * rng.standard_normal(dims[i + 1])).astype(F32) for i in range(len(dims) - 1)])
+
+
+def torch_loss_and_grads(net, X, Y):
+    import torch
+    Ws = [torch.tensor(w, requires_grad=True) for w in net["W"]]
+    bs = [torch.tensor(b, requires_grad=True) for b in net["b"]]
+    h = torch.tensor(X)
+    for l, (W, b) in enumerate(zip(Ws, bs)):
+        h = h @ W + b
+        if l + 1 < len(Ws):
+            h = torch.relu(h)
+    loss = torch.mean((h - torch.tensor(Y)) ** 2)
+    loss.backward()
+    return float(loss), [w.grad.numpy() for w in Ws], [b.grad.numpy() for b in bs]
+
+
+def keras_adam(net, state, gW, gb, t, lr, b1=0.9, b2=0.999, eps=1e-7):
+    """tf.keras.optimizers.Adam: m, v, lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), w -= lr_t m / (sqrt(v) + eps); fp32"""
+    lr_t = F32(lr) * np.sqrt(F32(1) - F32(b2) ** F32(t)) / (F32(1) - F32(b1) ** F32(t))
+    for key, grads in (("W", gW), ("b", gb)):
+        for l, g in enumerate(grads):
+            mm, vv = state[key][l]
+            mm[:] = F32(b1) * mm + F32(1 - b1) * g
+            vv[:] = F32(b2) * vv + F32(1 - b2) * g * g
+            net[key][l] = (net[key][l] - lr_t * mm / (np.sqrt(vv) + F32(eps))).astype(F32)
+
+
+@pytest.mark.parametrize("dims,n", [([16, 32, 32, 32, 13], 1000), ([9, 16, 6], 333), ([16, 32, 13], 9001), ([4, 8, 8, 8, 2], 64)])
+def test_gradients_match_torch_autograd(m, dims, n):
+    """loss and dLoss/dW, dLoss/db of the reference's network shapes (ragged n: partial last block, odd sample count, more than one
+    4096-sample chunk of the batch GEMM) against torch CPU fp32 autograd."""
+    net = make_net(dims, 1)
+    rng = np.random.default_rng(2)
+    X, Y = rng.standard_normal((n, dims[0])).astype(F32), rng.standard_normal((n, dims[-1])).astype(F32)
+    lr = m.Learner(net)
+    lr.set_data(X, Y)
+    loss, g, pred = lr.evaluate(grads=True, pred=True)
+    tl, tW, tb = torch_loss_and_grads(net, X, Y)
+    assert abs(loss - tl) <= 2e-6 * abs(tl)
+    for l in range(len(dims) - 1):
+        scale = max(np.abs(tW[l]).max(), 1e-12)
+        np.testing.assert_allclose(g["W"][l], tW[l], rtol=2e-5, atol=2e-6 * scale)
+        np.testing.assert_allclose(g["b"][l], tb[l], rtol=2e-5, atol=2e-6 * max(np.abs(tb[l]).max(), 1e-12))
+    assert pred.shape == (n, dims[-1]) and abs(np.mean((pred - Y) ** 2) - tl) <= 1e-5 * tl
+
+
+def test_adam_steps_match_the_keras_update(m):
+    """40 full-batch Adam steps on the device against the same 40 steps done with torch autograd + the Keras update in numpy:
+    weights agree to 2e-5 absolute (they move by ~0.04 in total), the loss falls, two learners give identical bits."""
+    dims, n, steps, lr_rate = [16, 32, 32, 32, 13], 2000, 40, 1e-3
+    net = make_net(dims, 3)
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((n, 16)).astype(F32)
+    Y = (np.tanh(X @ rng.standard_normal((16, 13)) * 0.3)).astype(F32)
+    a, b = m.Learner(net), m.Learner(net)
+    a.set_data(X, Y)
+    b.set_data(X, Y)
+    first, last = a.train(steps, lr_rate)
+    b.train(steps // 2, lr_rate)
+    b.train(steps - steps // 2, lr_rate)  # the optimiser state persists across calls
+    wa, wb = a.get_weights(), b.get_weights()
+    for l in range(4):
+        np.testing.assert_array_equal(wa["W"][l], wb["W"][l])
+        np.testing.assert_array_equal(wa["b"][l], wb["b"][l])
+    assert a.step_count() == steps and last < first
+    ref = dict(W=[w.copy() for w in net["W"]], b=[v.copy() for v in net["b"]])
+    state = dict(W=[(np.zeros_like(w), np.zeros_like(w)) for w in ref["W"]], b=[(np.zeros_like(v), np.zeros_like(v)) for v in ref["b"]])
+    losses = []
+    for t in range(1, steps + 1):
+        tl, gW, gb = torch_loss_and_grads(ref, X, Y)
+        losses.append(tl)
+        keras_adam(ref, state, gW, gb, t, lr_rate)
+    assert abs(first - losses[0]) <= 2e-6 * losses[0] and abs(last - losses[-1]) <= 2e-4 * losses[-1]
+    for l in range(4):
+        np.testing.assert_allclose(wa["W"][l], ref["W"][l], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(wa["b"][l], ref["b"][l], rtol=0, atol=2e-5)
+    moved = max(np.abs(wa["W"][l] - net["W"][l]).max() for l in range(4))
+    print("Adam: loss %.5f -> %.5f; weights moved by up to %.3g, device vs reference differ by up to %.3g"
+          % (first, last, moved, max(np.abs(wa["W"][l] - ref["W"][l]).max() for l in range(4))))
+    assert moved > 1e-2
+    a.reset_optimizer()
+    assert a.step_count() == 0
+
+
+def test_learner_argument_errors(m):
+    with pytest.raises(m.MppiError) as e:
+        m.Learner(make_net([16, 64, 13]))
+    assert e.value.status == 4
+    lr = m.Learner(make_net([4, 8, 2]))
+    with pytest.raises(m.MppiError):
+        lr.train(5, 1e-3)  # no data
+    lr.set_data(np.zeros((10, 4), F32), np.zeros((10, 2), F32))
+    with pytest.raises(m.MppiError):
+        lr.train(0, 1e-3)
+
+
+def test_train_the_auv_network_on_the_fossen_model_and_control_with_it(m):
+    """The loop the reference closes (main.py with a learnable model): transitions of the Fossen AUVModel (rolled on the device) fill
+    the replay buffer, LearnerBase computes the normalisation statistics and trains NNAUVModel's Dense(32)x3 network with Adam on
+    the device; the trained model predicts the plant's next state far better than the untrained one, and the NNAUVModel controller
+    built from the trained weights produces the control the fp64 oracle computes from the same weights."""
+    from conftest import load_golden
+    P = load_golden("model_auv")["params"]
+    plant = m.AUVModel(actionDim=6, dt=0.1, parameters=P)
+    rng = np.random.default_rng(0)
+    n = 6000
+    x = rng.standard_normal((n, 13)) * np.array([1, 1, 1, 0, 0, 0, 0, .5, .5, .5, .2, .2, .2])
+    q = rng.standard_normal((n, 4)) * 0.3 + np.array([0, 0, 0, 1.0])
+    x[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    u = 300.0 * rng.standard_normal((n, 6))
+    xn = plant.build_step_graph("plant", x[..., None], u[..., None])
+    model = m.NNAUVModel()
+    learner = m.LearnerBase(model, bufferSize=n)
+    learner.add_rb(x[..., None], u[..., None], xn)
+    assert learner.rb_trans()["obs"].shape == (n, 13, 1)
+    learner.stats()
+    assert np.all(model.Xstd > 0) and model.Xstd.shape == (16,) and model.Ystd.shape == (13,)
+    before = np.mean((model.build_step_graph("nn", x[:500, :, None], u[:500, :, None]) - xn[:500]) ** 2)
+    first, last = learner.train_all(learningRate=3e-3, epoch=400)
+    after = np.mean((model.build_step_graph("nn", x[:500, :, None], u[:500, :, None]) - xn[:500]) ** 2)
+    print("NNAUVModel trained on %d Fossen transitions: normalised loss %.4f -> %.4f, one-step MSE %.3g -> %.3g" % (n, first, last, before, after))
+    assert last < 0.25 * first and after < 0.25 * before
+    # the controller on the trained weights against the oracle on the same weights
+    K, H = 1024, 8
+    sigma = 100.0 * np.eye(6)
+    goal = [1.0, 0.5, -0.5, 0, 0, 0, 1.0] + [0.0] * 6
+    Q = np.array([50.0] * 3 + [5.0] * 4 + [1.0] * 6)
+    h = m.Handle(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, goal=goal, Q=Q, nnauv=model.mlp(), seed=2)
+    p64 = orc.Problem(tau=H, s=13, a=6, lam=1.0, sigma=sigma, goal=goal, Q=Q, nnauv=model.mlp(), threads=0, dtype=np.float64)
+    x0 = np.array([0, 0, 0, 0, 0, 0, 1.0] + [0.0] * 6, F32)
+    un = h.next(x0)
+    noise = h.debug_get(m.DBG_NOISE)
+    u64, U64, c64 = p64.next_with_noise(x0, np.zeros((H, 6)), noise)
+    assert np.isfinite(c64).all()
+    assert np.abs(un - u64).max() / 100.0 <= 2e-5

@@ -306,12 +306,13 @@ def test_auv_step_properties(auv_golden):
     fp32 instantiation within fp32 of fp64."""
     P = dict(auv_golden["params"])
     m64, m32 = orc.AuvModel(P, dtype=np.float64), orc.AuvModel(P, dtype=np.float32)
+    dt = float(np.float32(0.1))  # the model parameters are fp32 numbers in both instantiations (what the C-ABI carries)
     for x, u in zip(auv_golden["step_inputs"]["state"], auv_golden["step_inputs"]["action"]):
         xn = m64.step(x, u)
         assert abs(np.linalg.norm(xn[3:7]) - 1) < 1e-12
         k1 = m64.state_dot(x, u)
-        xs = np.asarray(x) + 0.1 * k1
-        heun = np.asarray(x) + 0.05 * (k1 + m64.state_dot(xs, u))
+        xs = np.asarray(x) + dt * k1
+        heun = np.asarray(x) + (dt / 2) * (k1 + m64.state_dot(xs, u))
         heun[3:7] /= np.linalg.norm(heun[3:7])
         np.testing.assert_allclose(xn, heun, rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(m32.step(x, u), xn, rtol=2e-5, atol=2e-5)
@@ -320,7 +321,7 @@ def test_auv_step_properties(auv_golden):
     np.testing.assert_allclose(orc.AuvModel(neutral).step(x0, [0.] * 6), x0, rtol=0, atol=1e-15)
     e1 = orc.AuvModel(dict(P, rk=1))
     x, u = auv_golden["step_inputs"]["state"][1], auv_golden["step_inputs"]["action"][1]
-    eul = np.asarray(x) + 0.1 * e1.state_dot(x, u)
+    eul = np.asarray(x) + dt * e1.state_dot(x, u)
     eul[3:7] /= np.linalg.norm(eul[3:7])
     np.testing.assert_allclose(e1.step(x, u), eul, rtol=1e-12, atol=1e-12)
 

@@ -713,12 +713,13 @@ def test_small_mlp_fused_philox_step_and_sharding(m):
     shards = [m.Handle(shard_rank=r, shard_count=4, **cfg) for r in range(4)]
     xd = torch.tensor(x, device="cuda")
     recs = torch.empty((4, 2 + H * a), dtype=torch.float32, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream  # ONE stream for all shards (each handle's own stream would race)
-    for r, sh in enumerate(shards):
-        sh.shard_partial(xd.data_ptr(), recs[r].data_ptr(), st)
-    ud = torch.empty(a, dtype=torch.float32, device="cuda")
-    shards[0].shard_finish(recs.data_ptr(), 4, ud.data_ptr(), st)
+    one = torch.cuda.Stream()  # ONE explicit stream for all shards (stream 0 means "the handle's own stream": those would race)
     torch.cuda.synchronize()
+    for r, sh in enumerate(shards):
+        sh.shard_partial(xd.data_ptr(), recs[r].data_ptr(), one.cuda_stream)
+    ud = torch.empty(a, dtype=torch.float32, device="cuda")
+    shards[0].shard_finish(recs.data_ptr(), 4, ud.data_ptr(), one.cuda_stream)
+    one.synchronize()
     assert np.abs(ud.cpu().numpy() - u).max() <= 2e-6
 
 
