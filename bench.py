@@ -109,12 +109,40 @@ def synthetic_mlp(n_in, n_out, seed=0, hid=HID, n_hidden=2):
     return dict(W=W, b=b)
 
 
+_trained = {}
+
+
+def trained_nnauv():
+    """NNAUVModel's Dense(32)x3 network TRAINED here, on the device: 8192 transitions of the rexrov2 Fossen AUVModel (rolled by the
+    device model), LearnerBase's normalisation statistics, 300 full-batch Adam steps (mppi_learner_*). The one learned-model number
+    that is not on synthetic weights. -> (mlp dict for Handle(nnauv=...), description)"""
+    if "nnauv" not in _trained:
+        import numpy as np
+        import mppi_tf_amd as m
+        from mppi_tf_amd.auv import auv_task
+        plant = m.AUVModel(actionDim=6, dt=0.1, parameters=auv_task(8)["auv"])
+        rng = np.random.default_rng(0)
+        n = 8192
+        x = rng.standard_normal((n, 13)) * np.array([1, 1, 1, 0, 0, 0, 0, .5, .5, .5, .2, .2, .2])
+        q = rng.standard_normal((n, 4)) * 0.3 + np.array([0, 0, 0, 1.0])
+        x[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+        u = 1500.0 * rng.standard_normal((n, 6))
+        xn = plant.build_step_graph("plant", x[..., None], u[..., None])
+        model = m.NNAUVModel()
+        learner = m.LearnerBase(model, bufferSize=n)
+        learner.add_rb(x[..., None], u[..., None], xn)
+        learner.stats()
+        first, last = learner.train_all(learningRate=3e-3, epoch=300)
+        _trained["nnauv"] = (model.mlp(), "trained on the device: %d Fossen (rexrov2) transitions, 300 Adam steps, normalised MSE %.3g -> %.3g" % (n, first, last))
+    return _trained["nnauv"]
+
+
 def mlp_of(workload):
     a, net = WORKLOADS[workload]
     if net is None:
         return None
     if workload == "nnauv":  # NNAUVModel: input = state without the position + action (nn_model.py:289-293), output = 13
-        return synthetic_mlp(13 + 6 - 3, 13, 0, *net)
+        return trained_nnauv()[0]
     return synthetic_mlp(3 * a, 2 * a, 0, *net)
 
 
@@ -241,8 +269,9 @@ class Runner:
         x = torch.zeros(cfg["s_dim"], dtype=torch.float32, device=self.dev)
         if "x0" in cfg:
             x = torch.tensor(cfg.pop("x0"), dtype=torch.float32, device=self.dev)
-        ctl = ShardedController(device_index=self.local_rank, k=K * self.world, mlp=mlp, exchange=os.environ.get("MPPI_EXCHANGE", "auto"),
-                                p2p_timeout_ms=1000, **cfg, **handle_kw)
+        model_kw = dict(nnauv=mlp) if workload == "nnauv" else dict(mlp=mlp)
+        ctl = ShardedController(device_index=self.local_rank, k=K * self.world, exchange=os.environ.get("MPPI_EXCHANGE", "auto"),
+                                p2p_timeout_ms=1000, **model_kw, **cfg, **handle_kw)
         assert ctl.backend.h.k_local == K
         rank_el = [0.0]
 
@@ -311,6 +340,12 @@ def roofline_of(r):
     kus = 1e3 * r["kernel_ms_avg"]
     base = {"kernel": r["kernel"].replace("mppi::", ""), "kernel_us": r4(kus), "finish_kernel_us": r4(1e3 * r["finish_kernel_ms_avg"]),
             "launches_timed": r["launches_timed"]}
+    if "k_rollout_gen" in r["kernel"]:  # lane-per-rollout kernels of the 13-state family: packed-fp32 vector issue is their ceiling
+        flop = r["algorithmic_flop_per_launch"]
+        tf = flop / (kus * 1e-6) / 1e12 if kus > 0 else 0.0
+        base.update({"bound": "valu_issue", "achieved": r4(tf), "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r4(tf / VALU_F32_PEAK_TFLOPS),
+                     "traffic": None, "algorithmic_flop_per_launch": flop})
+        return base
     if r["mlp"] is not None:
         flop = r["algorithmic_flop_per_launch"]
         bx3 = "bx3" in r["kernel"]
@@ -354,9 +389,12 @@ def sub_record(s):
     rf = roofline_of(s)
     keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "kernel_us", "finish_kernel_us", "floor_us", "valu_busy_us",
             "mfma_busy_frac", "algorithmic_TFLOP_per_s", "traffic")
-    return {"config": name, "workload": s["workload"], "K": s["K_per_gpu"], "H": s["H"], "value": r4(s["rollouts_per_s"]), "unit": "rollouts/s",
-            "ms_per_step": r4(s["ms_per_step"]), "steps": s["steps"], "batches": len(s["batches_s"]),
-            "roofline": {k: rf[k] for k in keep if rf.get(k) is not None}}
+    d = {"config": name, "workload": s["workload"], "K": s["K_per_gpu"], "H": s["H"], "value": r4(s["rollouts_per_s"]), "unit": "rollouts/s",
+         "ms_per_step": r4(s["ms_per_step"]), "steps": s["steps"], "batches": len(s["batches_s"]),
+         "roofline": {k: rf[k] for k in keep if rf.get(k) is not None}}
+    if s["workload"] == "nnauv":
+        d["weights"] = trained_nnauv()[1]
+    return d
 
 
 def main():

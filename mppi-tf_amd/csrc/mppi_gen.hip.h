@@ -470,6 +470,166 @@ __global__ void k_gen_costs(const DevConsts *__restrict__ C, const GenConsts *__
     if (out_step) out_step[i] = sc + ac;
 }
 
+// ---------------------------------------------------------------------------------------- NNAUVModel on the matrix cores
+// k_rollout_nnauv32: NNAUVModel with the reference's Dense(32, relu) x 1..3 + Dense(13) network (nn_model.py:54-60, 215-304) as
+// k_rollout_mlp32 runs the point-mass networks (mppi_mlp32.hip.h): a 32-wide layer is one v_mfma_f32_32x32x2_f32 tile, the
+// accumulator layout of one layer IS the B-operand layout of the next (units renumbered u(r, hh) = 8 (r >> 2) + 4 hh + (r & 3)),
+// weights and biases stationary in registers, no LDS and no barrier between layers. What changes for the 13-state family:
+// 16 inputs = concat(x[3:], v) (8 k pairs in layer 1 instead of 5), 13 outputs (the output layer on the vector ALU as 7 pairs,
+// W3 rows padded to 16 in LDS), 6 Philox blocks per horizon group, and the cost_base slot is gen_state_cost (quadratic with any Q,
+// StaticQuatCost, ElipseCost3D). One wave = 32 rollouts (both lane halves carry rollout j's state), a workgroup = 2 waves = one
+// 64-rollout tile record.
+constexpr int kNnauv32Threads = 128;
+
+__global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnauv32(
+    const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
+    const float *__restrict__ U_dev, const float *__restrict__ eps_hbm, const unsigned long long *__restrict__ step_ctr,
+    float *__restrict__ cost, float *__restrict__ partials, const int SRC, const int MODE, const int rsb, const int rsc)
+{
+    constexpr int S = kGenS, A = kGenA, NIN = kGenNin, XOFF = 3, SP = (S + 1) / 2, HID = 32, K1H = NIN / 2, W3LD = 16;
+    constexpr bool DIAG = false;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float w3_s[HID * W3LD];   // output-layer rows, padded to 16
+    __shared__ float z_s[2][4 * A][32];                                // per wave: the normals of one horizon group
+    __shared__ float cost_s[64];
+    const int H = C->H, HA = H * A, K = C->K_local;
+    const int NG = (H + 3) / 4;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
+    const int k0 = blockIdx.x * 64;
+    const int kk = min(k0 + 32 * w + j, K - 1); // rollouts past K recompute the last sample, outside every sum
+    const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
+    const unsigned long long seed = C->seed;
+    const unsigned int gk = (unsigned int)C->k_offset + (unsigned int)kk;
+    const int n_hidden = M->n_layers - 1;
+    auto unit_of = [](int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); };
+
+    // ---- stationary operands
+    float a1[K1H];
+#pragma unroll
+    for (int s1 = 0; s1 < K1H; ++s1) a1[s1] = M->Wl[0][(2 * s1 + hh) * HID + j];
+    f32x16 b1t, bht[2];
+    float ah[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b1t[r] = M->bl[0][unit_of(r, hh)];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const bool have = l + 2 <= n_hidden; // hidden-to-hidden layer l exists
+        const float *Wl = have ? M->Wl[l + 1] : M->Wl[0], *bl = have ? M->bl[l + 1] : M->bl[0];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) ah[l][s] = have ? Wl[unit_of(s, hh) * HID + j] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bht[l][r] = have ? bl[unit_of(r, hh)] : 0.0f;
+    }
+    const float *W3g = M->Wl[n_hidden], *b3g = M->bl[n_hidden];
+    const int ld3 = M->ld[n_hidden]; // 14: the host pads the 13-wide output layer to an even width
+    for (int i = tid; i < HID * W3LD; i += kNnauv32Threads) w3_s[i] = (i & 15) < S ? W3g[(i >> 4) * ld3 + (i & 15)] : 0.0f;
+    float xm[NIN], xr[NIN], b3v[S], ysd[S], ymn[S];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) { xm[i] = M->xmean[i]; xr[i] = 1.0f / M->xstd[i]; }
+#pragma unroll
+    for (int i = 0; i < S; ++i) { b3v[i] = b3g[i]; ysd[i] = M->ystd[i]; ymn[i] = M->ymean[i]; }
+    float x[S], c = 0.0f;
+#pragma unroll
+    for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+    __syncthreads();
+
+    // the layers are single asm statements on fixed accumulator registers (mppi_mfma32.hip.h): MFMAs, wait states and relu together
+    // output layer + next_state (state + de-normalised delta) + step cost, from the (relu'd) accumulators of the last hidden layer
+    auto finish = [&](const f32x16 &hacc, float ac) {
+        f32x2 py[SP];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 8 * (r >> 2) + (r & 3); // + 4 hh through the lane's base
+            const float *wp = w3_s + (4 * hh + row) * W3LD;
+            float wv[W3LD];
+#pragma unroll
+            for (int q4 = 0; q4 < W3LD / 4; ++q4) {
+                const f32x4 t4 = *static_cast<const f32x4 *>(__builtin_assume_aligned(wp + 4 * q4, 16));
+                wv[4 * q4] = t4.x; wv[4 * q4 + 1] = t4.y; wv[4 * q4 + 2] = t4.z; wv[4 * q4 + 3] = t4.w;
+            }
+            const f32x2 h2 = {hacc[r], hacc[r]};
+#pragma unroll
+            for (int p2 = 0; p2 < SP; ++p2) {
+                const f32x2 w2 = {wv[2 * p2], wv[2 * p2 + 1]};
+                py[p2] = r == 0 ? h2 * w2 : __builtin_elementwise_fma(h2, w2, py[p2]);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < S; ++n) { // the other half's rows: lower + upper, in every lane
+            float a = (n & 1) ? py[n / 2].y : py[n / 2].x, b = a;
+            permlane32_swap(a, b); // a = the lower half's partial in all lanes, b = the upper half's
+            const float y = (a + b) + b3v[n];
+            x[n] = x[n] + (y * ysd[n] + ymn[n]);
+        }
+        const float sc = gen_state_cost(C, G, x); // cost on the POST-step state
+        const float tmp = sc + ac;
+        c = c + tmp;
+    };
+
+    for (int t = 0; t < H; ++t) {
+        if (SRC == SRC_PHILOX && (t & 3) == 0) { // this wave's normals of the group: block q by the half with q & 1 == hh
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < A; ++q) {
+                if ((q & 1) == hh) {
+                    const uint4 r = philox4x32_10_block_ub(seed, gk, (base + (unsigned long long)(t >> 2)) * A + q);
+                    const float2 n0 = box_muller_hw(r.x, r.y), n1 = box_muller_hw(r.z, r.w);
+                    z_s[w][4 * q + 0][j] = n0.x; z_s[w][4 * q + 1][j] = n0.y; z_s[w][4 * q + 2][j] = n1.x; z_s[w][4 * q + 3][j] = n1.y;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): one wave's LDS accesses complete in order
+            __builtin_amdgcn_wave_barrier();
+        }
+        float u[A], e[A], v[A];
+        if (SRC == SRC_PHILOX) {
+            float z1[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) z1[i] = z_s[w][(t & 3) * A + i][j];
+            scale_noise<A, DIAG>(C, z1, e);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
+        }
+#pragma unroll
+        for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
+        const float ac = action_cost<A, DIAG>(C, u, e);
+        // layer 1: the B operand of lane (j, hh), k pair s1, is input 2 s1 + hh of rollout j; input i = x[3 + i] for i < 10, else v[i - 10]
+        float bv[K1H];
+#pragma unroll
+        for (int s1 = 0; s1 < K1H; ++s1) {
+            const int i0 = 2 * s1, i1 = 2 * s1 + 1;
+            const float r0 = i0 < S - XOFF ? x[XOFF + i0] : v[i0 - (S - XOFF)], r1 = i1 < S - XOFF ? x[XOFF + i1] : v[i1 - (S - XOFF)];
+            bv[s1] = hh ? (r1 - xm[i1]) * xr[i1] : (r0 - xm[i0]) * xr[i0];
+        }
+        f32x16 acc0;
+        mfma32_layer1<K1H>(acc0, a1, bv, b1t);
+        if (n_hidden >= 2) {
+            f32x16 acc1;
+            mfma32_hidden_64_80(acc1, acc0, ah[0], bht[0]);
+            if (n_hidden >= 3) {
+                mfma32_hidden_80_64(acc0, acc1, ah[1], bht[1]);
+                finish(acc0, ac);
+            } else {
+                finish(acc1, ac);
+            }
+        } else {
+            finish(acc0, ac);
+        }
+    }
+    c = c + gen_state_cost(C, G, x); // terminal cost, controller_base.cpp:271-272
+    // lane l of BOTH waves now stands for rollout k0 + l of the tile
+    if (hh == 0) cost_s[32 * w + j] = c;
+    __syncthreads();
+    const float ct = cost_s[lane];
+    const bool valid = (k0 + lane) < K;
+    const int kt = valid ? k0 + lane : K - 1;
+    if (w == 0 && valid) cost[k0 + lane] = ct;
+    if (MODE == MODE_COST_ONLY) return;
+    mlp_tile_record<A, DIAG, 2>(C, ct, valid, w, lane, kt, H, NG, SRC, eps_hbm, seed, (unsigned long long)C->k_offset + (unsigned long long)kt,
+                                base, partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc);
+}
+
 // ElipseCost3D's three terms for k states -> out [k, 3] (position, orientation, velocity error)
 __global__ void k_e3_terms(const GenConsts *__restrict__ G, const float *__restrict__ x, int k, int in_plane, float *__restrict__ out)
 {

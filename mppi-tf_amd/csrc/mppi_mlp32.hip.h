@@ -19,6 +19,8 @@
 // last): within the same tolerance class as the other MLP kernels, held to the same tests.
 #pragma once
 
+#include "mppi_mfma32.hip.h"
+
 namespace mppi {
 
 constexpr int kMlp32Threads = 128;
@@ -79,31 +81,7 @@ __global__ __launch_bounds__(kMlp32Threads) void k_rollout_mlp32(
     for (int i = 0; i < S; ++i) x[i] = x_dev[i];
     __syncthreads();
 
-    // MFMAs and the relu that reads their result as inline asm with "v" operands: through the intrinsic hipcc keeps the
-    // accumulators in AGPRs and the relu becomes v_accvgpr_read + a canonicalising v_max + v_max per register. Hazards
-    // are ours then: s_nop 1 in front of an MFMA (its B operand may just have been written by the relu), 18 wait states
-    // between a layer's last MFMA and the first read of its result (16 passes + 2; the other wave of the SIMD runs meanwhile).
-    auto mfma_first = [&](f32x16 &acc, float a, float b, const f32x16 &cin) {
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(cin));
-    };
-    auto mfma_more = [&](f32x16 &acc, float a, float b) {
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-    };
-    auto relu16 = [&](f32x16 &acc) {
-        asm volatile("s_nop 15\n\ts_nop 1\n\t"
-                     "v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3\n\t"
-                     "v_max_f32 %4, 0, %4\n\tv_max_f32 %5, 0, %5\n\tv_max_f32 %6, 0, %6\n\tv_max_f32 %7, 0, %7\n\t"
-                     "v_max_f32 %8, 0, %8\n\tv_max_f32 %9, 0, %9\n\tv_max_f32 %10, 0, %10\n\tv_max_f32 %11, 0, %11\n\t"
-                     "v_max_f32 %12, 0, %12\n\tv_max_f32 %13, 0, %13\n\tv_max_f32 %14, 0, %14\n\tv_max_f32 %15, 0, %15"
-                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
-                       "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
-    };
-    auto hidden = [&](f32x16 &acc, const f32x16 &in, const float (&a)[16], const f32x16 &bias) {
-        mfma_first(acc, a[0], in[0], bias);
-#pragma unroll
-        for (int s = 1; s < 16; ++s) mfma_more(acc, a[s], in[s]);
-        relu16(acc);
-    };
+    // the layers are single asm statements on fixed accumulator registers (mppi_mfma32.hip.h): MFMAs, wait states and relu together
     // output layer + state update + step cost, from the (relu'd) accumulators of the last hidden layer
     auto finish = [&](const f32x16 &hacc, float ac) {
         f32x2 py[SP];
@@ -161,22 +139,21 @@ __global__ __launch_bounds__(kMlp32Threads) void k_rollout_mlp32(
         for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
         const float ac = action_cost<A, DIAG>(C, u, e);
         // layer 1: the B operand of lane (j, hh), k pair s1, is input 2 s1 + hh of rollout j — the lane's own value
-        f32x16 acc0;
+        float bv[K1H];
 #pragma unroll
         for (int s1 = 0; s1 < K1H; ++s1) {
             const int i0 = 2 * s1, i1 = 2 * s1 + 1;
             const float r0 = i0 < S ? x[i0] : v[i0 - S], m0 = xm[i0], q0 = xr[i0];
             const float r1 = i1 < NIN ? (i1 < S ? x[i1] : v[i1 - S]) : 0.0f, m1 = i1 < NIN ? xm[i1] : 0.0f, q1 = i1 < NIN ? xr[i1] : 0.0f;
-            const float b = hh ? (r1 - m1) * q1 : (r0 - m0) * q0;
-            if (s1 == 0) mfma_first(acc0, a1[s1], b, b1t);
-            else mfma_more(acc0, a1[s1], b);
+            bv[s1] = hh ? (r1 - m1) * q1 : (r0 - m0) * q0;
         }
-        relu16(acc0);
+        f32x16 acc0;
+        mfma32_layer1<K1H>(acc0, a1, bv, b1t);
         if (n_hidden >= 2) {
             f32x16 acc1;
-            hidden(acc1, acc0, ah[0], bht[0]);
+            mfma32_hidden_64_80(acc1, acc0, ah[0], bht[0]);
             if (n_hidden >= 3) {
-                hidden(acc0, acc1, ah[1], bht[1]);
+                mfma32_hidden_80_64(acc0, acc1, ah[1], bht[1]);
                 finish(acc0, ac);
             } else {
                 finish(acc1, ac);

@@ -302,9 +302,10 @@ def test_auv_sharded_equals_unsharded_and_normalize(m, G):
     assert np.abs(un - u_ref).max() / 200.0 < 1e-5
 
 
-@pytest.mark.parametrize("hid,n_hidden", [(32, 3), (16, 2)])
+@pytest.mark.parametrize("hid,n_hidden,tuning", [(32, 3, None), (32, 3, {"mlp32_valu": 1}), (16, 2, None), (32, 1, None), (32, 2, None)],
+                         ids=["32x3-mfma", "32x3-valu", "16x2", "32x1-mfma", "32x2-mfma"])
 @pytest.mark.parametrize("cost", ["quadratic", "quat"])
-def test_nnauv_control_step_against_oracle(m, hid, n_hidden, cost):
+def test_nnauv_control_step_against_oracle(m, hid, n_hidden, tuning, cost):
     """The learned 13-state model in the full path: NNAUVModel (input 16, output 13) with the quadratic or the quaternion cost —
     the combination the point-mass MLP kernels fence off (s = 2a, diagonal Q, quadratic cost). Costs as close to fp64 as an fp32
     CPU evaluation is (4x); U' at 1e-5 on unit noise; fused Philox step; 4-way sharding."""
@@ -320,9 +321,10 @@ def test_nnauv_control_step_against_oracle(m, hid, n_hidden, cost):
         mlp["W"][-1] = (0.2 * mlp["W"][-1]).astype(F32)
         mlp["b"][-1] = (0.2 * mlp["b"][-1]).astype(F32)
     ck = dict(goal=GOAL13, Q=np.array([10.0] * 3 + [5.0] * 4 + [1.0] * 6)) if cost == "quadratic" else dict(goal=goal_q, Q=Q10 / 10, quat_cost=True)
-    cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv=mlp, seed=9, **ck)
+    cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv=mlp, seed=9, tuning=tuning, **ck)
     h = m.Handle(**cfg)
-    assert h.rollout_kernel_name() == "mppi::k_rollout_gen<1, %d>" % hid
+    # Dense(32): the matrix cores (k_rollout_nnauv32, the accumulators of one layer are the next layer's B operands) unless tuned onto the vector ALU
+    assert h.rollout_kernel_name() == ("mppi::k_rollout_nnauv32" if hid == 32 and not tuning else "mppi::k_rollout_gen<1, %d>" % hid)
     mk = lambda dt: orc.Problem(tau=H, s=13, a=6, lam=1.0, sigma=sigma, nnauv=mlp, threads=0, dtype=dt, **ck)
     p32, p64 = mk(F32), mk(np.float64)
     rng = np.random.default_rng(1)

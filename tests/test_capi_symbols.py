@@ -80,3 +80,14 @@ def test_host_side_slices_need_no_gpu(pkg):
         np.testing.assert_array_equal(_lib.get_new(g["action"], int(nb)), np.asarray(exp, np.float32).reshape(int(nb), 2))
     for case in g["shift"]:
         np.testing.assert_array_equal(_lib.shift(g["action"], case["init"], case["nb"]), np.asarray(case["expected"], np.float32))
+
+
+def test_no_mfma_hazard_in_the_built_code_objects():
+    """hipcc does not look inside inline-asm strings: a register copy it places between an asm MFMA and the reader of its result
+    is a silent stale read (it happened to k_rollout_mlp32 after an unrelated header change: costs off by 1e-4). tools/
+    check_mfma_hazards.py scans every kernel of the built library for a vector / LDS / memory instruction touching an MFMA
+    destination before the result has landed; the layers now are single asm statements on fixed registers (mppi_mfma32.hip.h)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazards.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 hazards" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
