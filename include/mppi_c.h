@@ -176,6 +176,10 @@ mppi_status mppi_next_with_noise(mppi_handle *h, const float *x, int n_x, const 
  * constructors): 0 = off (default, nothing is recorded and mppi_next allocates nothing). Clears the log. When full
  * the oldest row is overwritten. */
 mppi_status mppi_set_transition_log(mppi_handle *h, int max_rows);
+/* What mppi_to_csv will NOT write, so that a truncated file never goes unnoticed (the reference's m_db grows without bound and
+ * writes every transition, data_base.cpp:52-71): rows_overwritten = transitions lost because the ring was full since the log
+ * was sized; rows_without_successor = rows held whose saveNext was skipped (left out of the CSV). Any output may be NULL. */
+mppi_status mppi_transition_log_stats(mppi_handle *h, uint64_t *rows_held, uint64_t *rows_overwritten, uint64_t *rows_without_successor);
 /* replaces ControllerBase::saveNext (controller_base.cpp:155-163): x_next is the successor of the LAST logged (x, u);
  * a row whose saveNext was skipped is left out of the CSV instead of shifting the later rows. */
 mppi_status mppi_save_next(mppi_handle *h, const float *x_next, int n);

@@ -77,6 +77,7 @@ SIGNATURES = {
     "mppi_to_csv": (C.c_int, [_H, C.c_char_p]),
     "mppi_to_csv_format": (C.c_int, [_H, C.c_char_p, C.c_int]),
     "mppi_set_transition_log": (C.c_int, [_H, C.c_int]),
+    "mppi_transition_log_stats": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mppi_set_tuning": (C.c_int, [_H, C.c_int, C.c_int]),
     "mppi_get_action_sequence": (C.c_int, [_H, FP, C.c_int]),
     "mppi_set_action_sequence": (C.c_int, [_H, FP, C.c_int]),
@@ -318,6 +319,12 @@ class Handle:
     def save_next(self, x_next):
         x = f32(x_next).ravel()
         self._check(self.lib.mppi_save_next(self.h, fp(x), x.size))
+
+    def transition_log_stats(self):
+        """-> dict(held, overwritten, without_successor): what to_csv will and will not write"""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.mppi_transition_log_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(held=int(a.value), overwritten=int(b.value), without_successor=int(c.value))
 
     def to_csv(self, filename, fmt=CSV_REFERENCE):
         """DataBase::toCSV; fmt = CSV_REFERENCE (the reference's bytes) or CSV_ROUNDTRIP (%.9g, no trailing commas)"""

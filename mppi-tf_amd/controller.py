@@ -373,3 +373,8 @@ class ControllerBaseCpp:
 
     def toCSV(self, filename):
         self._h.to_csv(filename)  # DataBase::toCSV's bytes (data_base.cpp:36-71)
+        st = self._h.transition_log_stats()
+        if st["overwritten"] or st["without_successor"]:  # the reference's m_db is unbounded: say what the bounded log left out
+            import warnings
+            warnings.warn("toCSV: %d transitions were overwritten (log capacity %d rows) and %d rows had no saveNext; they are not in %s"
+                          % (st["overwritten"], LOG_ROWS, st["without_successor"], filename))

@@ -888,7 +888,7 @@ static mppi_status step_host(mppi_handle *h, const float *x, int n_x, const floa
     if (h->log_cap) {
         size_t r;
         if (h->log_count < h->log_cap) r = (h->log_head + h->log_count++) % h->log_cap;
-        else { r = h->log_head; h->log_head = (h->log_head + 1) % h->log_cap; } // full: the oldest row is overwritten
+        else { r = h->log_head; h->log_head = (h->log_head + 1) % h->log_cap; h->log_dropped++; } // full: the oldest row is overwritten (counted)
         float *row = h->log_rows.data() + r * h->log_stride();
         std::memcpy(row, x, sizeof(float) * h->s);
         std::memcpy(row + h->s, u_out, sizeof(float) * h->a);
@@ -918,7 +918,19 @@ extern "C" mppi_status mppi_set_transition_log(mppi_handle *h, int max_rows)
     } catch (const std::bad_alloc &) {
         return fail(h, MPPI_ERR_ALLOC, "transition log: out of host memory");
     }
-    h->log_cap = (size_t)max_rows; h->log_count = 0; h->log_head = 0;
+    h->log_cap = (size_t)max_rows; h->log_count = 0; h->log_head = 0; h->log_dropped = 0;
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_transition_log_stats(mppi_handle *h, uint64_t *rows_held, uint64_t *rows_overwritten, uint64_t *rows_without_successor)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    size_t open_rows = 0;
+    for (size_t q = 0; q < h->log_count; ++q)
+        if (h->log_rows[((h->log_head + q) % h->log_cap) * h->log_stride() + 2 * h->s + h->a] == 0.0f) ++open_rows;
+    if (rows_held) *rows_held = h->log_count;
+    if (rows_overwritten) *rows_overwritten = h->log_dropped;
+    if (rows_without_successor) *rows_without_successor = open_rows;
     return MPPI_OK;
 }
 

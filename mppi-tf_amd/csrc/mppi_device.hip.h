@@ -201,6 +201,21 @@ __device__ __forceinline__ uint4 philox4x32_10_block_ub(unsigned long long seed,
     return uint4{c0, c1, c2, c3};
 }
 
+// The 4 standard normals of ONE Philox block of a sample (block uniform or not): the single place every rollout kernel that
+// draws block by block (k_rollout_mlp2, k_rollout_mlp32, k_rollout_nnauv32) gets them from, so that the rollout and the tile
+// record (mlp_tile_record -> normals_group) always agree — also in the -DMPPI_ROCRAND_NORMALS variant build.
+__device__ __forceinline__ float4 normals_of_block(unsigned long long seed, unsigned long long gk, unsigned long long block)
+{
+#if defined(MPPI_ROCRAND_NORMALS)
+    PhiloxAt eng(seed, gk, 4ull * block);
+    return rocrand_device::detail::normal_distribution4(eng.block());
+#else
+    const uint4 r = philox4x32_10_block(seed, gk, block);
+    const float2 n0 = box_muller_hw(r.x, r.y), n1 = box_muller_hw(r.z, r.w);
+    return float4{n0.x, n0.y, n1.x, n1.y};
+#endif
+}
+
 // normals_group for a wave-uniform group index and a sample index below 2^32 (the rollout kernels' case)
 template <int A>
 __device__ __forceinline__ void normals_group_ub(unsigned long long seed, unsigned int gk_lo, unsigned long long group_index_uniform,

@@ -80,6 +80,7 @@ struct mppi_handle {
     // mppi_set_transition_log gives it a capacity; a ring of rows (x | u | x_next | has_next), allocated once there
     std::vector<float> log_rows;
     size_t log_cap = 0, log_count = 0, log_head = 0; // capacity in rows, rows held, index of the oldest row
+    unsigned long long log_dropped = 0;               // rows overwritten since the log was (re)sized: the ring was full
     size_t log_stride() const { return (size_t)2 * s + a + 1; }
     // direct record exchange (mppi_shard_p2p_*): own inbox, the peers' mapped inboxes, call sequence number
     unsigned long long *xchg_inbox = nullptr;

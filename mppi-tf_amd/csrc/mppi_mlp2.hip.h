@@ -405,10 +405,9 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
         if (2 * w < 2 * A) { // wave-uniform
             const int set = unit / A, q = unit - set * A;
             if (unit < 2 * A) {
-                const uint4 r = philox4x32_10_block(seed, koff + (unsigned long long)kk_of(set), (base + (unsigned long long)gn) * A + q);
-                const float2 n0 = box_muller_hw(r.x, r.y), n1 = box_muller_hw(r.z, r.w);
+                const float4 n = normals_of_block(seed, koff + (unsigned long long)kk_of(set), (base + (unsigned long long)gn) * A + q);
                 float *zd = z_s + ((set * 2 + (gn & 1)) * 4 * A + 4 * q) * R + j; // normals 4 q .. 4 q + 3 of normals_group<A>
-                zd[0 * R] = n0.x; zd[1 * R] = n0.y; zd[2 * R] = n1.x; zd[3 * R] = n1.y;
+                zd[0 * R] = n.x; zd[1 * R] = n.y; zd[2 * R] = n.z; zd[3 * R] = n.w;
             }
         }
     };

@@ -117,9 +117,8 @@ __global__ __launch_bounds__(kMlp32Threads) void k_rollout_mlp32(
 #pragma unroll
             for (int q = 0; q < A; ++q) {
                 if ((q & 1) == hh) {
-                    const uint4 r = philox4x32_10_block(seed, gk, (base + (unsigned long long)(t >> 2)) * A + q);
-                    const float2 n0 = box_muller_hw(r.x, r.y), n1 = box_muller_hw(r.z, r.w);
-                    z_s[w][4 * q + 0][j] = n0.x; z_s[w][4 * q + 1][j] = n0.y; z_s[w][4 * q + 2][j] = n1.x; z_s[w][4 * q + 3][j] = n1.y;
+                    const float4 n = normals_of_block(seed, gk, (base + (unsigned long long)(t >> 2)) * A + q);
+                    z_s[w][4 * q + 0][j] = n.x; z_s[w][4 * q + 1][j] = n.y; z_s[w][4 * q + 2][j] = n.z; z_s[w][4 * q + 3][j] = n.w;
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): one wave's LDS accesses complete in order

@@ -1081,6 +1081,8 @@ def test_transition_log_ring_pairing_and_formats(m, tmp_path):
     got = np.array([[float(v) for v in r.split(",")] for r in rows[1:]], F32)
     want = np.array([[0.25 + i, -0.5 + i, us[i], 0.375 + i, -0.375 + i] for i in (2, 4)], F32)  # ring of 3 = steps 2,3,4; 3 unpaired
     np.testing.assert_array_equal(got, want)
+    # what the bounded log left out is reported, never silent (the reference's m_db is unbounded): 5 steps into 3 rows = 2 overwritten
+    assert h.transition_log_stats() == dict(held=3, overwritten=2, without_successor=1)
     h.to_csv(str(f))                                 # reference bytes
     rows = f.read_text().splitlines()
     assert rows[0] == "x0,x1,u0,x_next0,x_next1," and rows[1] == "2.250000,1.500000,%f,2.375000,1.625000," % us[2]
@@ -1109,6 +1111,39 @@ def test_written_out_philox_equals_rocrand_engine(m):
         os.remove(f)
     np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=5e-6)
     assert np.abs(outs[0]).max() > 1.0  # not degenerate
+
+
+def test_mlp_kernels_in_the_rocrand_variant_weight_the_noise_they_roll_out():
+    """in the -DMPPI_ROCRAND_NORMALS build the MLP kernels drew their rollout noise with the hardware Box-Muller while the
+    tile record regenerated it with rocRAND's normal_distribution4. Both now come from normals_of_block: on the variant library a fused
+    learned-model step must equal the injected-noise step fed with the noise it exported (costs bitwise, U' to rounding)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    var = os.path.join(ROOT, "build", "variants", "libmppi_hip_rocrand_normals.so")
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import mppi_tf_amd as m
+rng = np.random.default_rng(0)
+def net(dims):
+    return dict(W=[(rng.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) * (0.1 if i == len(dims) - 2 else 1) for i in range(len(dims) - 1)],
+                b=[np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 1)])
+for dims in ([9, 256, 256, 6], [9, 32, 32, 32, 6]):
+    mlp = net(dims)
+    cfg = dict(k=2048, tau=12, s_dim=6, a_dim=3, sigma=0.25 * np.eye(3), goal=[1, 0, .5, 0, .75, 0], mlp=mlp, seed=3)
+    a, b = m.Handle(**cfg), m.Handle(**cfg)
+    x = np.array([0.1, 0, -0.2, 0, 0.3, 0], np.float32)
+    ua = a.next(x)
+    eps = a.debug_get(m.DBG_NOISE)
+    ub = b.next_with_noise(x, eps)
+    assert np.array_equal(a.debug_get(m.DBG_COSTS), b.debug_get(m.DBG_COSTS)), a.rollout_kernel_name()
+    assert np.abs(ua - ub).max() <= 2e-6, (a.rollout_kernel_name(), ua, ub)
+print("VARIANT_MLP_OK")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, MPPI_SO_PATH=var), cwd=ROOT)
+    assert r.returncode == 0 and "VARIANT_MLP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_native_cpp_sharded_host_with_rccl(m):
