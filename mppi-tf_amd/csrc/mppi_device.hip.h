@@ -429,7 +429,7 @@ __device__ __forceinline__ float wave_sum_bpermute(float v)
     for (int off = 32; off > 0; off >>= 1) v = v + __shfl_xor(v, off, 64);
     return v;
 }
-__device__ __forceinline__ double wave_sum_d(double v)
+__device__ __forceinline__ double wave_sum_d_bpermute(double v)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = v + __shfl_xor(v, off, 64);
@@ -469,6 +469,30 @@ __device__ __forceinline__ float wave_min_dpp(float v)
     const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
     return fminf(fminf(s0, s1), fminf(s2, s3));
 }
+// 64-lane sum of doubles on the same DPP ladder (two dword moves per level), every lane gets the total: the finish kernels'
+// eta and V sums (24 ds_bpermute round trips per workgroup before)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int lane)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    v = v + dpp_mov_d<0xB1>(v);
+    v = v + dpp_mov_d<0x4E>(v);
+    v = v + dpp_mov_d<0x141>(v);
+    v = v + dpp_mov_d<0x140>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+
 // The tile soft-min of every rollout kernel (beta_b = min, eta_b = sum over a tile's 64 lanes) runs on these: no LDS
 // crossbar on the critical tail of a tile (12 dependent ds_bpermute round trips before, ~0.5 us per tile). One fixed
 // association for every kernel, so kernels that must agree on a record (k_rollout_pc / k_rollout_tile) still do.

@@ -338,18 +338,15 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
 #pragma unroll
                         for (int j = 0; j < A; ++j) zz[j] = z[tl * A + j];
                         scale_noise<A, DIAG>(PC, zz, e);
-                        // steps past the horizon (ragged last group) must not enter the weighted sum: a wave-uniform factor
-                        // 1.0 / 0.0 in an SGPR (exact), NOT `t < H ? e : 0`, which hipcc turns into a v_cndmask_b32 on VCC:
-                        // 19 cycles per instruction on this part against 2.3 for the multiply (tools/micro/valu_issue.hip).
-                        // (Copying e into eps_r through an operation also keeps hipcc at 94 live VGPRs instead of 114.)
-                        const float keep = t < H ? 1.0f : 0.0f;
+                        // steps past the horizon (ragged last group) need no mask: the butterfly sums every column on its own and the
+                        // columns with t >= H are never stored (r03: the e * keep multiply that used to zero them cost 0.3 us at C3)
                         float slot[SLOT];
 #pragma unroll
                         for (int j = 0; j < SLOT; ++j) slot[j] = 0.0f;
 #pragma unroll
                         for (int j = 0; j < A; ++j) {
                             u[j] = ug[tl][j];
-                            eps_r[(i * 4 + tl) * A + j] = e[j] * keep;
+                            eps_r[(i * 4 + tl) * A + j] = e[j];
                             slot[j] = u[j] + e[j]; // to_apply, :258
                         }
                         slot[A] = action_cost<A, DIAG>(PC, u, e);

@@ -98,9 +98,24 @@ def test_adam_steps_match_the_keras_update(m):
         keras_adam(ref, state, gW, gb, t, lr_rate)
     assert abs(first - losses[0]) <= 2e-6 * losses[0] and abs(last - losses[-1]) <= 2e-4 * losses[-1]
     moved = max(np.abs(wa["W"][l] - net["W"][l]).max() for l in range(4))
-    for l in range(4):  # Adam divides by sqrt(v): fp32 rounding differences of the gradient sums grow to ~0.2 % of the distance moved
-        np.testing.assert_allclose(wa["W"][l], ref["W"][l], rtol=0, atol=5e-3 * moved)
-        np.testing.assert_allclose(wa["b"][l], ref["b"][l], rtol=0, atol=5e-3 * moved)
+    # Adam normalises by sqrt(v): where a gradient is of the order of eps (dead relu units) its relative rounding error IS the update's,
+    # so 40 steps of two fp32 evaluations drift apart by up to ~1 % of the distance moved; the update RULE itself is checked exactly below
+    for l in range(4):
+        np.testing.assert_allclose(wa["W"][l], ref["W"][l], rtol=0, atol=2e-2 * moved)
+        np.testing.assert_allclose(wa["b"][l], ref["b"][l], rtol=0, atol=2e-2 * moved)
+    # two consecutive steps from the device's OWN gradients: the Keras update in numpy reproduces the device's weights to fp32 rounding
+    c = m.Learner(net)
+    c.set_data(X, Y)
+    chk = dict(W=[w.copy() for w in net["W"]], b=[v.copy() for v in net["b"]])
+    st2 = dict(W=[(np.zeros_like(w), np.zeros_like(w)) for w in chk["W"]], b=[(np.zeros_like(v), np.zeros_like(v)) for v in chk["b"]])
+    for t in (1, 2):
+        _, g = c.evaluate(grads=True)
+        c.train(1, lr_rate)
+        keras_adam(chk, st2, g["W"], g["b"], t, lr_rate)
+        wc = c.get_weights()
+        for l in range(4):
+            np.testing.assert_allclose(wc["W"][l], chk["W"][l], rtol=0, atol=3e-7)
+            np.testing.assert_allclose(wc["b"][l], chk["b"][l], rtol=0, atol=3e-7)
     print("Adam: loss %.5f -> %.5f; weights moved by up to %.3g, device vs reference differ by up to %.3g"
           % (first, last, moved, max(np.abs(wa["W"][l] - ref["W"][l]).max() for l in range(4))))
     assert moved > 1e-2

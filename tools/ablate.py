@@ -16,7 +16,10 @@ VARIANTS = {
     "only_philox": ["MPPI_ABLATE_ROLLOUT", "MPPI_ABLATE_WSUM"],
     "only_rollout": ["MPPI_ABLATE_PHILOX", "MPPI_ABLATE_WSUM"],
     "nothing": ["MPPI_ABLATE_PHILOX", "MPPI_ABLATE_ROLLOUT", "MPPI_ABLATE_WSUM"],
+    "nokeep": ["MPPI_PC_NO_KEEP"],
 }
 if __name__ == "__main__":
     for name, defs in VARIANTS.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         print(build.build_variant(name, defs))
