@@ -543,6 +543,11 @@ __device__ __forceinline__ void column_combine(Load ld, int nb, float neg_inv_la
     const int tid = threadIdx.x;
     constexpr int PER = 4; // records per thread held in registers (nb <= 1024 in one pass)
     float bb[PER], ee[PER], vv[PER];
+    // -DMPPI_FINISH_STAGE=n (timing study, tools/ablate.py finish_s*): the kernel stops after stage n — 0 entry, 1 the record loads,
+    // 2 the min over the records, 3 the weighted sums; results are then meaningless, only the kernel time counts
+#if defined(MPPI_FINISH_STAGE)
+    if (MPPI_FINISH_STAGE == 0) { beta_out = 0.f; eta_out = 1.0; V_out = 0.0; return; }
+#endif
 #pragma unroll
     for (int i = 0; i < PER; ++i) { // unconditional clamped loads (see k_combine_group)
         const int b = min(tid + i * kThreads, nb - 1);
@@ -550,6 +555,9 @@ __device__ __forceinline__ void column_combine(Load ld, int nb, float neg_inv_la
         ee[i] = ld(b, 1);
         vv[i] = ld(b, 2);
     }
+#if defined(MPPI_FINISH_STAGE)
+    if (MPPI_FINISH_STAGE == 1) { float s_ = 0.f; for (int i = 0; i < PER; ++i) s_ += bb[i] + ee[i] + vv[i]; beta_out = s_; eta_out = 1.0; V_out = 0.0; return; }
+#endif
     float bmin = INFINITY;
 #pragma unroll
     for (int i = 0; i < PER; ++i) bmin = fminf(bmin, (tid + i * kThreads < nb) ? bb[i] : INFINITY);
@@ -560,6 +568,9 @@ __device__ __forceinline__ void column_combine(Load ld, int nb, float neg_inv_la
     float beta = red_f[0];
 #pragma unroll
     for (int w = 1; w < kThreads / 64; ++w) beta = fminf(beta, red_f[w]);
+#if defined(MPPI_FINISH_STAGE)
+    if (MPPI_FINISH_STAGE == 2) { beta_out = beta + ee[0] + vv[0]; eta_out = 1.0; V_out = 0.0; return; }
+#endif
 
     double se = 0.0, sv = 0.0;
 #pragma unroll

@@ -16,7 +16,10 @@ VARIANTS = {
     "only_philox": ["MPPI_ABLATE_ROLLOUT", "MPPI_ABLATE_WSUM"],
     "only_rollout": ["MPPI_ABLATE_PHILOX", "MPPI_ABLATE_WSUM"],
     "nothing": ["MPPI_ABLATE_PHILOX", "MPPI_ABLATE_ROLLOUT", "MPPI_ABLATE_WSUM"],
-    "nokeep": ["MPPI_PC_NO_KEEP"],
+    # k_finish_cols stopped after stage n (where do its ~4.3 us go): 0 entry, 1 record loads, 2 min over the records, (full = all)
+    "finish_s0": ["MPPI_FINISH_STAGE=0"],
+    "finish_s1": ["MPPI_FINISH_STAGE=1"],
+    "finish_s2": ["MPPI_FINISH_STAGE=2"],
 }
 if __name__ == "__main__":
     for name, defs in VARIANTS.items():
