@@ -190,10 +190,12 @@ def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20):
     loop, main.cpp:37-43). Median / p95 ms per control step."""
     import numpy as np
     a = WORKLOADS[workload][0]
-    h = m.Handle(k=K, mlp=mlp, **cfg_of(workload, H))
-    if mlp is not None:
+    cfg = cfg_of(workload, H)
+    gen = workload in ("auv", "nnauv")  # 13-state family: the state is held at the task's x0 (no host plant for the Fossen model here)
+    x = np.asarray(cfg.pop("x0"), np.float32) if gen else np.zeros(2 * a, np.float32)
+    h = m.Handle(k=K, **(dict(nnauv=mlp) if workload == "nnauv" else dict(mlp=mlp)), **cfg)
+    if mlp is not None or gen:
         steps, warmup = 20, 3
-    x = np.zeros(2 * a, np.float32)
     dt, ts = 0.1, []
     for i in range(warmup + steps):
         t0 = time.perf_counter()
@@ -201,7 +203,7 @@ def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20):
         t1 = time.perf_counter()
         if i >= warmup:
             ts.append(t1 - t0)
-        for j in range(a):  # point-mass plant, fp32, same model
+        for j in range(0 if gen else a):  # point-mass plant, fp32, same model
             x[2 * j] = x[2 * j] + dt * x[2 * j + 1] + (dt * dt / 2) * u[j]
             x[2 * j + 1] = x[2 * j + 1] + dt * u[j]
     ts = np.sort(np.asarray(ts)) * 1e3
@@ -489,7 +491,7 @@ def main():
                                    % (headline, ("learned %dx%d MLP model_base" % (net[1], net[0])) if is_mlp else "analytic model", K, H,
                                       ("BASELINE " + name) if name.startswith("configs") else name),
                        "K_global": K * world, "K_per_gpu": K, "H": H, "s_dim": s_dim, "a_dim": a,
-                       "lambda": 1.0, "sigma": "0.25*I", "dt": 0.1,
+                       "lambda": float(cfg_of(headline, H).get("lam", 1.0)), "sigma": "1500*I (6 thrusts, N)" if a == 6 else "0.25*I", "dt": 0.1,
                        "parallelism": "K-shard x%d" % world, "exchange": r["exchange"], "record_floats": r["record_size"]},
             "roofline": roofline_of(r),
         }

@@ -22,7 +22,7 @@ UNITS = ([("mppi_launch_mlp.hip", ["MPPI_UNIT_A=%d" % a], "mlp_a%d" % a) for a i
          + [("mppi_launch_gen.hip", [], "gen"), ("mppi_learner.hip", [], "learner"), ("mppi_capi.hip", [], "capi")])
 SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["mppi_device.hip.h", "mppi_kernels.hip.h", "mppi_mlp2.hip.h", "mppi_mlp_small.hip.h", "mppi_mlp32.hip.h",
-           "mppi_handle.hip.h", "mppi_gen.hip.h", "mppi_mfma32.hip.h"]
+           "mppi_handle.hip.h", "mppi_gen.hip.h", "mppi_mfma32.hip.h", "mppi_bx3.hip.h"]
 ARCH = "gfx950"
 
 

@@ -1362,6 +1362,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
 
 } // namespace mppi
 #include "mppi_mlp2.hip.h"
+#include "mppi_bx3.hip.h"
 #include "mppi_mlp_small.hip.h"
 #include "mppi_mlp32.hip.h"
 namespace mppi {

@@ -1,0 +1,43 @@
+"""bench.py end to end, every --workload, at small sizes: one JSON line with the contract's fields (the driver depends on it)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline")
+
+
+def run_bench(*argv):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--min-time", "0", *argv],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout  # ONE line on stdout
+    assert len(lines[0]) < 4096
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload,samples,horizon", [("pm1d", 128, 32), ("pm2d", 4096, 64), ("pm3d", 8192, 16), ("mlp", 2048, 8),
+                                                      ("mlp32", 4096, 8), ("auv", 4096, 8), ("nnauv", 4096, 8)])
+def test_every_workload_prints_the_contract_line(workload, samples, horizon):
+    out = run_bench("--workload", workload, "--samples", str(samples), "--horizon", str(horizon), "--no-subrecords", "--no-cpu-baseline")
+    for key in CONTRACT:
+        assert key in out, key
+    assert "rollouts/s" in out["metric"] and out["unit"] == "rollouts/s"
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 2
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert abs(out["value"] - samples / (out["ms_per_step"] * 1e-3)) <= 0.02 * out["value"]
+    assert out["config"]["workload"]
+    assert out["ms_per_control_step_sync"]["median"] > 0
+
+
+def test_cpu_baseline_rides_along_on_a_small_point_mass_run():
+    out = run_bench("--workload", "pm2d", "--no-subrecords")
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]

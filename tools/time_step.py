@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import mppi_tf_amd as m
 
-args = [v for v in sys.argv[1:] if v not in ("mlp", "bx3")]
+args = [v for v in sys.argv[1:] if v not in ("mlp", "bx3", "v1")]
 K, H, a, steps = (int(v) for v in (args[:4] + ["65536", "64", "3", "200"][len(args):]))
 mlp = None
 if "mlp" in sys.argv:  # SURVEY §8d synthetic 2x256 MLP
@@ -22,7 +22,8 @@ if "mlp" in sys.argv:  # SURVEY §8d synthetic 2x256 MLP
     b[2] *= 0.1
     mlp = dict(W=W, b=b)
 h = m.Handle(k=K, tau=H, s_dim=2 * a, a_dim=a, dt=0.1, lam=1.0, sigma=0.25 * np.eye(a), goal=([1, 0, .5, 0, .75, 0, .25, 0])[:2 * a], mlp=mlp,
-             mlp_bf16x3="bx3" in sys.argv)
+             mlp_bf16x3="bx3" in sys.argv, tuning=({"mlp_v1": 1} if "v1" in sys.argv else None))
+print(h.rollout_kernel_name())
 x = torch.zeros(2 * a, device="cuda")
 u = torch.zeros(a, device="cuda")
 for _ in range(20):
