@@ -1,8 +1,11 @@
-// mppi_bx3.hip.h — k_rollout_mlp_bx3p: the learned 2x256 MLP model_base on the BF16 matrix cores at fp32-class accuracy
-// (opt-in MPPI_FLAG_MLP_BF16X3), second design. Included by mppi_kernels.hip.h.
+// mppi_bx3.hip.h — k_rollout_mlp_bx3: the learned 2x256 MLP model_base on the BF16 matrix cores at fp32-class accuracy
+// (opt-in MPPI_FLAG_MLP_BF16X3). Included by mppi_kernels.hip.h. Second design (r03); the first — 8 waves in lock-step phases, two
+// barriers per step, 1.57 ms at BASELINE configs[3] against 1.22-1.25 ms for this one — is gone.
 //
-// Arithmetic: as k_rollout_mlp_bx3 (mppi_kernels.hip.h) — every fp32 operand split x = hi + lo into two bf16 values, a
-// product sum evaluated as three v_mfma_f32_32x32x16_bf16 into one fp32 accumulator (a_lo b_hi + a_hi b_lo + a_hi b_hi).
+// Arithmetic: every fp32 operand is split x = hi + lo into two bf16 values (hi = bf16(x), lo = bf16(x - hi), together 16 mantissa
+// bits) and a product sum is evaluated as three v_mfma_f32_32x32x16_bf16 into one fp32 accumulator (a_lo b_hi + a_hi b_lo + a_hi b_hi;
+// bf16 x bf16 is exact in fp32, the dropped lo x lo term is 2^-18 relative): sample costs after 64 recurrent steps within 9e-7
+// (relative) of fp64, against 4e-7 for exact fp32; the parity tests hold it to 2e-5. b1 rides as input k = NIN against a constant 1.
 // Structure: k_rollout_mlp2's (mppi_mlp2.hip.h) — ONE wave per SIMD, wave w owns hidden units [64w, 64w+64) of both
 // layers (2 M-tiles x 16 k-blocks x (hi, lo) x 4 registers = exactly a0-a255, pinned there by inline-asm MFMAs), TWO sets
 // of 32 rollouts per workgroup software-pipelined against each other, persistent workgroups, all cross-wave hand-offs
@@ -11,17 +14,22 @@
 // vector instructions of the SAME wave issue in its shadow for free — v_pk_*_f32 do not (17 cycles for the first, they
 // serialise with the MFMA), LDS reads nearly do. So instead of a few big lumps the other set's step is cut into ~95
 // PIECES of 5-8 plain (unpacked) vector instructions, one after each MFMA of the running set's stream of 96:
-//   layer 3 one accumulator register per piece (v_max + S v_fma), lane halves combined with v_permlane32_swap,
-//   barrier, cross-wave sum + state update + costs, noise + next inputs (normalise, split into bf16 hi/lo),
+//   layer 3 ON THE MATRIX CORE TOO (relu + split of the accumulator registers: they are the A fragments of
+//   out[rollout][n] = sum_u h2[rollout][u] W3[u][n], W3 stationary as 4 x (hi, lo) B fragments, 12 MFMAs; the first cut
+//   did it on the vector ALU with W3 rows from LDS: 24 B per lane and accumulator register, LDS-bandwidth-bound, 21 % of
+//   the kernel), barrier, cross-wave sum + state update + costs, noise + next inputs (normalise, split into bf16 hi/lo),
 //   6 layer-1 MFMAs, relu + split + image stores (one pair of accumulator registers per piece), barrier.
-// The h1 image keeps k_rollout_mlp_bx3's layout: [part][k-block][lane half][rollout] x 8 bf16, in the k order of an
+// The h1 image is [part][k-block][lane half][rollout] x 8 bf16, in the k order of an
 // accumulator tile, so a layer-1 accumulator register block IS a layer-2 B fragment (one ds_write_b128 / ds_read_b128
 // each); here a B fragment feeds both M-tiles of the wave (half the LDS reads per MFMA of the first design).
 // Layer 2's bias is the accumulators' initial value (8 LDS reads per set and step, once the set's image is written).
 #pragma once
 
+#ifndef MPPI_BX3_CUT
+#define MPPI_BX3_CUT 1000 // timing only: the pieces behind MFMA m >= CUT are left out (the cumulative cost of a half-step's pieces)
+#endif
 #ifndef MPPI_BX3_ABL
-#define MPPI_BX3_ABL 0 // timing-only ablations (wrong results): 1 no layer 3 / finish, 2 no preparation, 4 no barriers
+#define MPPI_BX3_ABL 0 // timing-only ablations (wrong results): 1 no layer 3 / finish, 2 no preparation, 4 no barriers, 8 no layer-3 pieces, 16 no relu/split pieces
 #endif
 
 namespace mppi {
@@ -30,7 +38,7 @@ constexpr int kBx3Threads = 256;
 constexpr int kBx3R = 64; // rollouts per workgroup: two sets of 32
 __host__ __device__ inline size_t bx3_lds_floats(int S, int A, int H)
 {
-    return (size_t)2 * 8192 + 2 * 4 * S * 32 + kHid * 8 + 2 * 2 * 4 * A * 32 + kHid + (size_t)(H * A + 3) / 4 * 4 + 64;
+    return (size_t)2 * 8192 + 2 * 4 * S * 32 + 2 * 2 * 4 * A * 32 + kHid + (size_t)(H * A + 3) / 4 * 4 + 64;
 }
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -38,9 +46,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // two floats -> one register of two bf16 (round to nearest even), low half = a
 __device__ __forceinline__ int pk_bf16(float a, float b)
 {
-    int r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(int, __builtin_convertvector((f32x2_){a, b}, bf16x2_)); // v_cvt_pk_bf16_f32 (as asm hipcc pads it with s_nop)
 }
 // (hi, lo) split of a pair: hi = bf16(x), lo = bf16(x - hi)
 __device__ __forceinline__ void split_pair(float a, float b, int &hi, int &lo)
@@ -51,7 +59,7 @@ __device__ __forceinline__ void split_pair(float a, float b, int &hi, int &lo)
 }
 
 template <int A, bool DIAG, int SRC>
-__global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
+__global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3(
     const DevConsts *__restrict__ C, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
     const float *__restrict__ U_dev, const float *__restrict__ eps_hbm,
     const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
@@ -66,9 +74,8 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
     const int H = C->H, HA = H * A, K = C->K_local;
     const int NG = (H + 3) / 4;
     float *img_s = smem;                     // [2 sets][2 parts][16 k-blocks][2 halves][32 rollouts] x 16 B = 2 x 32 KB
-    float *y_s = img_s + 2 * 8192;           // [2 sets][4 waves][SP][R][2]: output pairs (2p, 2p+1) of a rollout adjacent
-    float *w3_s = y_s + 2 * 4 * S * R;       // [kHid][8]
-    float *z_s = w3_s + kHid * 8;            // [2 sets][2 buffers][4*A][R] standard normals of a horizon group
+    float *y_s = img_s + 2 * 8192;           // [2 sets][4 waves][S][R]: layer-3 partial sums of the waves
+    float *z_s = y_s + 2 * 4 * S * R;        // [2 sets][2 buffers][4*A][R] standard normals of a horizon group
     float *b2_s = z_s + 2 * 2 * 4 * A * R;   // [kHid] layer-2 bias
     float *u_s = b2_s + kHid;                // [H*A] nominal controls
 
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
     // (the k order of an accumulator tile); layer 1: natural k order 8 hh + e, k = NIN is the bias row against a constant 1.
     // Every fragment is born as ONE 128-bit value (a ds_read_b128 of what the lane itself just wrote): assembled from four
     // scalars, hipcc copies the four registers into a fresh tuple in front of every MFMA that uses them.
-    i32x4 a2h[2][NKB], a2l[2][NKB], a1h[2], a1l[2];
+    i32x4 a2h[2][NKB], a2l[2][NKB], a1h[2], a1l[2], w3h[4], w3l[4];
     {
         int st_idx = (w * 64 + lane) * 4; // this lane's 16-byte slot of round-trip buffer entry 0 (floats); entry n at + n * 1024
         asm volatile("" : "+v"(st_idx));
@@ -138,17 +145,40 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
             stsq(st_idx + (2 * mt) * 1024, fh);
             stsq(st_idx + (2 * mt + 1) * 1024, fl);
         }
+        // layer 3: B fragment of k-block f = 2 mt + s (the wave's units 32 mt + 16 s ..+15 in accumulator order), column n = j
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            i32x4 fh, fl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v2[2];
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int e = 2 * q + o, unit = 64 * w + 16 * f + 8 * (e >> 2) + 4 * hh + (e & 3);
+                    v2[o] = j < S ? M->W3[(size_t)unit * S + (j < S ? j : 0)] : 0.0f;
+                }
+                int hi, lo;
+                split_pair(v2[0], v2[1], hi, lo);
+                fh[q] = hi; fl[q] = lo;
+            }
+            stsq(st_idx + (4 + 2 * f) * 1024, fh);
+            stsq(st_idx + (4 + 2 * f + 1) * 1024, fl);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             a1h[mt] = ldsq(ld_idx + (2 * mt) * 1024);
             a1l[mt] = ldsq(ld_idx + (2 * mt + 1) * 1024);
         }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            w3h[f] = ldsq(ld_idx + (4 + 2 * f) * 1024);
+            w3l[f] = ldsq(ld_idx + (4 + 2 * f + 1) * 1024);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads(); // the buffer is the image area
     }
     for (int i = tid; i < kHid; i += kBx3Threads) b2_s[i] = M->b2[i];
-    for (int i = tid; i < kHid * 8; i += kBx3Threads) w3_s[i] = (i & 7) < S ? M->W3[(i >> 3) * S + (i & 7)] : 0.0f;
     for (int i = tid; i < HA; i += kBx3Threads) u_s[i] = U_dev[i];
 
     // wave-uniform constants, read once (a barrier would otherwise force a re-fetch per step)
@@ -184,13 +214,11 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
     // LDS indices (floats), everything but a compile-time constant in ONE register per array (see mppi_mlp2.hip.h)
     int img_rd0 = (hh * 32 + j) * 4;
     int img_wr0 = (hh * 32 + j) * 4 + 4 * w * 256;
-    int w3_row0 = (int)(w3_s - smem) + (64 * w + 4 * hh) * 8;
-    int y_wr0[2] = {(int)(y_s - smem) + (0 * 4 + w) * S * R + 2 * j + hh, (int)(y_s - smem) + (1 * 4 + w) * S * R + 2 * j + hh};
-    int y_rd0 = (int)(y_s - smem) + 2 * j;
+    int y_wr0[2] = {(int)(y_s - smem) + ((0 * 4 + w) * S + (j < S ? j : 0)) * R + 4 * hh, (int)(y_s - smem) + ((1 * 4 + w) * S + (j < S ? j : 0)) * R + 4 * hh};
+    int y_rd0 = (int)(y_s - smem) + j;
     int z_rd0 = (int)(z_s - smem) + j;
     int b2_rd0 = (int)(b2_s - smem) + 64 * w + 4 * hh;
-    asm volatile("" : "+v"(img_rd0), "+v"(img_wr0), "+v"(w3_row0), "+v"(y_wr0[0]), "+v"(y_wr0[1]), "+v"(y_rd0), "+v"(z_rd0), "+v"(b2_rd0));
-    constexpr auto crow_of = [](int pi) { return 32 * (pi >> 4) + (pi & 3) + 8 * ((pi & 15) >> 2); };
+    asm volatile("" : "+v"(img_rd0), "+v"(img_wr0), "+v"(y_wr0[0]), "+v"(y_wr0[1]), "+v"(y_rd0), "+v"(z_rd0), "+v"(b2_rd0));
 
     using std::integral_constant;
     constexpr integral_constant<bool, true> yes{};
@@ -209,64 +237,81 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
     };
 
     struct StepRegs {       // values that live across pieces
-        float py[S];        // layer-3 partial sums of this lane's rows
-        float wrow[4][8];   // W3 rows in flight (ring of 4 accumulator registers)
-        f32x2 yv[SP][4];    // partial sums of the 4 waves
+        f32x16 yacc;        // layer 3: [rollout (register, lane half)][output n = lane & 31]
+        i32x4 ah, al;       // ... its A fragment under way: relu + split of 8 accumulator registers
+        float yv[S][4];     // partial sums of the 4 waves
         float zz[A], u[A], e[A], v[A];
         float in[8];        // the lane's 8 normalised layer-1 inputs
         i32x4 bh, bl;       // ... split: layer 1's B fragment
         int hi4[4], lo4[4]; // relu + split of 8 accumulator registers under way
+        float ra, rb, rah, rbh; // ... of the pair at hand, between the two halves of its piece
+        float sc;           // state cost under way
+        float acn;          // action cost of the step being prepared (the finish still needs the last step's)
     };
-    // ---- layer 3, accumulator register pi: request its W3 row; then py[n] += relu(h2) * W3[row][n]
-    auto l3_request = [&](auto pic, StepRegs &g) {
-        constexpr int pi = decltype(pic)::value, r = pi & 3;
-        const int idx = w3_row0 + crow_of(pi) * 8;
-        const f32x4 lo = lds4(idx);
-        g.wrow[r][0] = lo.x; g.wrow[r][1] = lo.y; g.wrow[r][2] = lo.z; g.wrow[r][3] = lo.w;
-        if constexpr (S > 4 && S <= 6) { const f32x2 hi = lds2(idx + 4); g.wrow[r][4] = hi.x; g.wrow[r][5] = hi.y; }
-        if constexpr (S > 6) { const f32x4 hi = lds4(idx + 4); g.wrow[r][4] = hi.x; g.wrow[r][5] = hi.y; g.wrow[r][6] = hi.z; g.wrow[r][7] = hi.w; }
-    };
-    auto l3_piece = [&](auto qc, auto pic, StepRegs &g) {
-        constexpr int q = decltype(qc)::value, pi = decltype(pic)::value;
+    // ---- layer 3. Pair piece pp (0..15): relu + split of accumulator registers 2 pp, 2 pp + 1 of the set; every 4th pair
+    // completes the A fragment of k-block f = pp >> 2 (rows = the set's rollouts, k = the wave's units 16 f ..+15)
+    auto l3_pair = [&](auto qc, auto ppc, StepRegs &g) {
+        constexpr int q = decltype(qc)::value, pp = decltype(ppc)::value, mt = pp >> 3, r0 = 2 * (pp & 7), f4 = pp & 3;
         f32x16 (&acc)[2] = q ? accB : accA;
-        float hv;
-        asm("v_max_f32 %0, 0, %1" : "=v"(hv) : "v"(acc[pi >> 4][pi & 15])); // fmaxf costs a canonicalising second v_max
-#pragma unroll
-        for (int n = 0; n < S; ++n) g.py[n] = pi == 0 ? hv * g.wrow[pi & 3][n] : __builtin_fmaf(hv, g.wrow[pi & 3][n], g.py[n]);
+        float a, b;
+        asm("v_max_f32 %0, 0, %1" : "=v"(a) : "v"(acc[mt][r0])); // fmaxf costs a canonicalising second v_max
+        asm("v_max_f32 %0, 0, %1" : "=v"(b) : "v"(acc[mt][r0 + 1]));
+        split_pair(a, b, g.hi4[f4], g.lo4[f4]);
+        if constexpr (f4 == 3) {
+            g.ah = i32x4{g.hi4[0], g.hi4[1], g.hi4[2], g.hi4[3]};
+            g.al = i32x4{g.lo4[0], g.lo4[1], g.lo4[2], g.lo4[3]};
+            asm volatile("" : "+v"(g.ah), "+v"(g.al));
+        } else {
+            asm volatile("" : "+v"(g.hi4[f4]), "+v"(g.lo4[f4]));
+        }
     };
-    // the lane halves hold different rows of the same column: one half-swap of (py[n], py[n+1]) and one add leave the total
-    // of output n in the lower half and of output n+1 in the upper half; one 64-lane store writes both
+    auto l3_mfma = [&](auto fc, auto ic, StepRegs &g) { // product i of 3 of k-block f
+        constexpr int f = decltype(fc)::value, i = decltype(ic)::value;
+        if constexpr (i == 0) mfma1(g.yacc, g.al, w3h[f], integral_constant<bool, f == 0>{});
+        else if constexpr (i == 1) mfma1(g.yacc, g.ah, w3l[f], no);
+        else mfma1(g.yacc, g.ah, w3h[f], no);
+    };
+    // lanes n = j < S hold output n of the set's 32 rollouts: register r is rollout (r & 3) + 8 (r >> 2) + 4 hh
     auto l3_store = [&](auto qc, StepRegs &g) {
         constexpr int q = decltype(qc)::value;
+        if (j < S) {
 #pragma unroll
-        for (int p2 = 0; p2 < SP; ++p2) {
-            float a = g.py[2 * p2], b = g.py[2 * p2 + 1];
-            permlane32_swap(a, b);
-            smem[y_wr0[q] + p2 * 2 * R] = a + b;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 v4 = {g.yacc[4 * g4], g.yacc[4 * g4 + 1], g.yacc[4 * g4 + 2], g.yacc[4 * g4 + 3]};
+                *static_cast<f32x4 *>(__builtin_assume_aligned(smem + y_wr0[q] + 8 * g4, 16)) = v4;
+            }
         }
     };
     // ---- finish: y = sum of the 4 waves' partial sums (fixed order) + b3, state update, cost of the step
-    auto fin_request = [&](auto qc, auto ic, StepRegs &g) {
-        constexpr int q = decltype(qc)::value, i = decltype(ic)::value, p2 = i >> 1;
+    auto fin_request = [&](auto qc, auto nc, StepRegs &g) { // output n of the 4 waves
+        constexpr int q = decltype(qc)::value, n = decltype(nc)::value;
 #pragma unroll
-        for (int ww = 2 * (i & 1); ww < 2 * (i & 1) + 2; ++ww) g.yv[p2][ww] = lds2(y_rd0 + ((q * 4 + ww) * SP + p2) * 2 * R);
+        for (int ww = 0; ww < 4; ++ww) g.yv[n][ww] = smem[y_rd0 + ((q * 4 + ww) * S + n) * R];
     };
     auto fin_piece = [&](auto qc, auto nc, StepRegs &g) { // output n
-        constexpr int q = decltype(qc)::value, n = decltype(nc)::value, p2 = n >> 1, o = n & 1;
+        constexpr int q = decltype(qc)::value, n = decltype(nc)::value;
         float (&x)[S] = q ? xB : xA;
-        float y = g.yv[p2][0][o] + g.yv[p2][1][o];
-        y = y + g.yv[p2][2][o];
-        y = y + g.yv[p2][3][o];
+        float y = g.yv[n][0] + g.yv[n][1];
+        y = y + g.yv[n][2];
+        y = y + g.yv[n][3];
         y = y + b3v[n];
         x[n] = x[n] + (y * ysd[n] + ymn[n]);
+        asm volatile("" : "+v"(x[n])); // the piece stays HERE: left alone hipcc sinks it to the first use of x[n] (one lump of ~80 instructions)
     };
-    auto cost_piece = [&](auto qc) {
-        constexpr int q = decltype(qc)::value;
+    auto cost_piece = [&](auto qc, auto ic, StepRegs &g) { // dimension i of (x - goal)^T Q (x - goal), as state_cost sums it
+        constexpr int q = decltype(qc)::value, i = decltype(ic)::value;
         float (&x)[S] = q ? xB : xA;
-        float &c = q ? cB : cA;
-        const float sc = state_cost<S, QFULL>(CC, x); // cost on the POST-step state
-        const float tmp = sc + (q ? acB : acA);
-        c = c + tmp;
+        const float d = x[i] - CC->goal[i];
+        const float term = d * (CC->qdiag[i] * d);
+        g.sc = i == 0 ? term : g.sc + term;
+        if constexpr (i == S - 1) {
+            float &c = q ? cB : cA;
+            const float tmp = g.sc + (q ? acB : acA); // cost on the POST-step state + the action cost of the step
+            c = c + tmp;
+            asm volatile("" : "+v"(c));
+        } else {
+            asm volatile("" : "+v"(g.sc));
+        }
     };
     // ---- preparation of step t: noise and nominal control, the lane's 8 normalised inputs, split
     auto prep_request = [&](auto qc, int t, StepRegs &g) {
@@ -282,16 +327,23 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
 #pragma unroll
         for (int i = 0; i < A; ++i) g.u[i] = u_s[t * A + i];
     };
-    auto noise_piece = [&](auto qc, StepRegs &g) {
-        constexpr int q = decltype(qc)::value;
-        if constexpr (SRC == SRC_PHILOX) scale_noise<A, DIAG>(PC, g.zz, g.e);
+    auto noise_piece = [&](auto qc, auto ic, StepRegs &g) { // 0: scale the noise, perturbed control; 1: action cost
+        constexpr int q = decltype(qc)::value, i = decltype(ic)::value;
+        if constexpr (i == 0) {
+            if constexpr (SRC == SRC_PHILOX) scale_noise<A, DIAG>(PC, g.zz, g.e);
 #pragma unroll
-        for (int i = 0; i < A; ++i) g.v[i] = g.u[i] + g.e[i];
-        (q ? acB : acA) = action_cost<A, DIAG>(PC, g.u, g.e);
+            for (int k = 0; k < A; ++k) g.v[k] = g.u[k] + g.e[k];
+#pragma unroll
+            for (int k = 0; k < A; ++k) asm volatile("" : "+v"(g.v[k]), "+v"(g.e[k]));
+        } else {
+            g.acn = action_cost<A, DIAG>(PC, g.u, g.e);
+            asm volatile("" : "+v"(g.acn));
+        }
     };
     auto input_piece = [&](auto qc, auto ec, StepRegs &g) { // inputs e, e + 1 of the lane: k = 8 hh + e
         constexpr int q = decltype(qc)::value, e0 = decltype(ec)::value;
         float (&x)[S] = q ? xB : xA;
+        if constexpr (e0 == 0) (q ? acB : acA) = g.acn; // behind the cost pieces of the step just finished
         auto raw = [&](int k) { return k < S ? x[k < S ? k : 0] : (k < NIN ? g.v[k < NIN && k >= S ? k - S : 0] : (k == NIN ? 1.0f : 0.0f)); };
 #pragma unroll
         for (int e = e0; e < e0 + 2; ++e) {
@@ -299,11 +351,13 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
             const float sel = hh ? hi : lo;
             g.in[e] = (sel - xms[e]) * xrs[e];
         }
+        asm volatile("" : "+v"(g.in[e0]), "+v"(g.in[e0 + 1]));
     };
     auto insplit_piece = [&](auto ec, StepRegs &g) {
         constexpr int e0 = decltype(ec)::value;
         int hi, lo;
         split_pair(g.in[e0], g.in[e0 + 1], hi, lo);
+        asm volatile("" : "+v"(hi), "+v"(lo));
         g.bh[e0 >> 1] = hi; g.bl[e0 >> 1] = lo;
     };
     auto l1_mfma = [&](auto qc, auto ic, StepRegs &g) { // MFMA i of 6: (mt, product)
@@ -315,18 +369,25 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
     };
     // relu + split of accumulator registers 2 pp, 2 pp + 1 of the set (pp = 0..15); every 4th pair completes a fragment
     // (8 registers = the B fragment of k-block 4 w + 2 mt + s) and stores it
-    auto relu_piece = [&](auto qc, auto ppc, StepRegs &g) {
-        constexpr int q = decltype(qc)::value, pp = decltype(ppc)::value, mt = pp >> 3, r0 = 2 * (pp & 7), f = (pp & 3);
+    auto relu_piece = [&](auto qc, auto ppc, auto halfc, StepRegs &g) {
+        constexpr int q = decltype(qc)::value, pp = decltype(ppc)::value, mt = pp >> 3, r0 = 2 * (pp & 7), f = (pp & 3), half = decltype(halfc)::value;
         f32x16 (&acc)[2] = q ? accB : accA;
-        float a, b;
-        asm("v_max_f32 %0, 0, %1" : "=v"(a) : "v"(acc[mt][r0]));
-        asm("v_max_f32 %0, 0, %1" : "=v"(b) : "v"(acc[mt][r0 + 1]));
-        split_pair(a, b, g.hi4[f], g.lo4[f]);
-        if constexpr (f == 3) {
-            constexpr int s = (pp & 7) >> 2;
-            const i32x4 h4 = {g.hi4[0], g.hi4[1], g.hi4[2], g.hi4[3]}, l4 = {g.lo4[0], g.lo4[1], g.lo4[2], g.lo4[3]};
-            stsq(img_wr0 + ((q * 2 + 0) * 16 + 2 * mt + s) * 256, h4);
-            stsq(img_wr0 + ((q * 2 + 1) * 16 + 2 * mt + s) * 256, l4);
+        if constexpr (half == 0) { // relu, hi = bf16 of the pair, hi back as floats
+            asm("v_max_f32 %0, 0, %1" : "=v"(g.ra) : "v"(acc[mt][r0]));
+            asm("v_max_f32 %0, 0, %1" : "=v"(g.rb) : "v"(acc[mt][r0 + 1]));
+            g.hi4[f] = pk_bf16(g.ra, g.rb);
+            g.rah = __builtin_bit_cast(float, g.hi4[f] << 16);
+            g.rbh = __builtin_bit_cast(float, g.hi4[f] & (int)0xffff0000);
+            asm volatile("" : "+v"(g.ra), "+v"(g.rb), "+v"(g.rah), "+v"(g.rbh), "+v"(g.hi4[f]));
+        } else { // lo = bf16 of what hi left; the 4th pair completes and stores the fragment
+            g.lo4[f] = pk_bf16(g.ra - g.rah, g.rb - g.rbh);
+            asm volatile("" : "+v"(g.lo4[f]));
+            if constexpr (f == 3) {
+                constexpr int s = (pp & 7) >> 2;
+                const i32x4 h4 = {g.hi4[0], g.hi4[1], g.hi4[2], g.hi4[3]}, l4 = {g.lo4[0], g.lo4[1], g.lo4[2], g.lo4[3]};
+                stsq(img_wr0 + ((q * 2 + 0) * 16 + 2 * mt + s) * 256, h4);
+                stsq(img_wr0 + ((q * 2 + 1) * 16 + 2 * mt + s) * 256, l4);
+            }
         }
     };
     // layer 2's bias as the initial value of the set's accumulators (register r of M-tile mt is row 32 mt + 8 (r >> 2) + 4 hh
@@ -353,22 +414,24 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
 
     // ---- One half-step: the 96 layer-2 MFMAs of set Q stream (k-block kb = m / 6: (mt, product) = (m & 1, (m % 6) >> 1));
     // after MFMA m comes piece m of the OTHER set O: it finishes its last step (FIN) and prepares step t_prep (PREP).
-    constexpr int M_L3 = 3;                        // layer 3 of accumulator register pi after MFMA pi + 3 (its W3 row is requested 3 MFMAs ahead)
-    constexpr int M_ST = M_L3 + 32;                // lane-half combine, partial sums -> LDS
+    constexpr int M_L3 = 2;                        // 16 pair pieces (relu + split of the set's layer-2 accumulators); the 3 layer-3 MFMAs of
+                                                   // k-block f ride in the 3 gaps after its 4th pair
+    constexpr int M_ST = M_L3 + 16 + 3 + 2;        // partial sums -> LDS (two MFMAs behind the last of layer 3)
     constexpr int M_BAR1 = M_ST + 1;               // barrier
-    constexpr int M_FRQ = M_BAR1 + 1;              // 2 SP requests of the 4 waves' partial sums
-    constexpr int M_PRQ = M_FRQ + 2 * SP;          // request noise and nominal control
-    constexpr int M_FIN = M_PRQ + 2;               // S pieces: y, state update
-    constexpr int M_COST = M_FIN + S;              // state cost
-    constexpr int M_NOISE = M_COST + 1;            // scale noise, action cost
-    constexpr int M_IN = M_NOISE + 1;              // 4 x (normalise a pair of inputs, split it)
+    constexpr int M_FRQ = M_BAR1 + 1;              // SP gaps: the 4 waves' partial sums of two outputs each
+    constexpr int M_FIN = M_FRQ + SP + 1;          // S pieces: y, state update
+    constexpr int M_COST = M_FIN + S;              // S pieces: state cost by dimension
+    constexpr int M_IN = M_COST + S;               // 4 x (normalise a pair of inputs, split it)
     constexpr int M_L1 = M_IN + 8;                 // 6 layer-1 MFMAs
+    constexpr int RELU_GAPS = S <= 6 ? 2 : 1;      // a relu + split piece (8 vector instructions) over two gaps where the schedule has them
     constexpr int M_RELU = M_L1 + 6 + 2;           // 16 pieces: relu + split of a register pair, image stores
-    constexpr int M_BAR2 = M_RELU + 16;            // barrier: the image of set O is complete
+    constexpr int M_BAR2 = M_RELU + 16 * RELU_GAPS; // barrier: the image of set O is complete
     constexpr int M_NG = M_BAR2 + 1;               // next horizon group's noise (every 4th step)
     constexpr int M_NEXT = M_BAR2 + 1 > 6 * 14 ? M_BAR2 + 1 : 6 * 14; // first B fragments of the next half-step (set O's new image): behind the
                                                    // barrier, and not before k-block 14 (ring entries 0 and 1 serve k-blocks 12 and 13 until then)
-    constexpr int M_ACC = M_BAR2 + 2;              // layer-2 bias into set O's accumulators (its image is written: they are free), 2 of 8 reads per piece
+    constexpr int M_ACC = M_BAR2 + 1;              // layer-2 bias into set O's accumulators (its image is written: they are free), 2 of 8 reads per gap
+    // the noise of the next step does not wait for the finish: requested during layer 3, scaled in the gaps of its last k-block
+    constexpr int M_PRQ = M_L3 + 8, M_NOISE = M_L3 + 16;
     static_assert(M_ACC + 4 <= 6 * NKB && M_NEXT < 6 * NKB, "the schedule of a half-step");
     i32x4 bqh[4], bql[4]; // B fragments (hi, lo) of k-blocks kb .. kb + 2: ring of 4, so that 16 and 17 = the next half-step's 0 and 1
     auto b_request = [&](int set, auto kbc) {
@@ -390,9 +453,12 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
             else mfma2(acc[mt], a2h[mt][kb], bqh[kb & 3]);
             __builtin_amdgcn_sched_barrier(0);
             // ---- LDS requests
-            if constexpr (i == 0 && kb + 2 < NKB) b_request(Q, integral_constant<int, kb + 2>{});
-            if constexpr (do_fin && m < 32) l3_request(integral_constant<int, m>{}, g);
-            if constexpr (do_fin && m >= M_FRQ && m < M_FRQ + 2 * SP) fin_request(Oc, integral_constant<int, m - M_FRQ>{}, g);
+            if constexpr (i == 0 && kb + 2 < NKB && !(MPPI_BX3_ABL & 32)) b_request(Q, integral_constant<int, kb + 2>{});
+            if constexpr (m < MPPI_BX3_CUT) {
+            if constexpr (do_fin && m >= M_FRQ && m < M_FRQ + SP) {
+                fin_request(Oc, integral_constant<int, 2 * (m - M_FRQ)>{}, g);
+                fin_request(Oc, integral_constant<int, 2 * (m - M_FRQ) + 1>{}, g);
+            }
             if constexpr (do_prep && m == M_PRQ) prep_request(Oc, t_prep, g);
             if constexpr (do_prep && m >= M_ACC && m < M_ACC + 4) {
                 acc_init(Oc, integral_constant<int, 2 * (m - M_ACC)>{});
@@ -400,26 +466,38 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- the piece
-            if constexpr (do_fin && m >= M_L3 && m < M_L3 + 32) l3_piece(Oc, integral_constant<int, m - M_L3>{}, g);
+            if constexpr (do_fin && !(MPPI_BX3_ABL & 8)) {
+                if constexpr (m >= M_L3 + 4 && m < M_L3 + 4 + 16 && ((m - M_L3) & 3) != 3) // behind the Q MFMA, in front of the pair piece
+                    l3_mfma(integral_constant<int, ((m - M_L3 - 4) / 4)>{}, integral_constant<int, ((m - M_L3) & 3)>{}, g);
+                if constexpr (m >= M_L3 && m < M_L3 + 16) l3_pair(Oc, integral_constant<int, m - M_L3>{}, g);
+            }
             if constexpr (do_fin && m == M_ST) l3_store(Oc, g);
             if constexpr (m == M_BAR1 || m == M_BAR2) {
                 if constexpr (!(MPPI_BX3_ABL & 4)) __syncthreads(); // the partial sums / the image of set O are complete
             }
             if constexpr (do_fin && m >= M_FIN && m < M_FIN + S) fin_piece(Oc, integral_constant<int, m - M_FIN>{}, g);
-            if constexpr (do_fin && m == M_COST) cost_piece(Oc);
-            if constexpr (do_prep && m == M_NOISE) noise_piece(Oc, g);
+            if constexpr (do_fin && m >= M_COST && m < M_COST + S) cost_piece(Oc, integral_constant<int, m - M_COST>{}, g);
+            if constexpr (do_prep && m >= M_NOISE && m < M_NOISE + 2) noise_piece(Oc, integral_constant<int, m - M_NOISE>{}, g);
             if constexpr (do_prep && m >= M_IN && m < M_IN + 8) {
                 if constexpr (((m - M_IN) & 1) == 0) input_piece(Oc, integral_constant<int, (m - M_IN)>{}, g);
                 else insplit_piece(integral_constant<int, (m - M_IN) - 1>{}, g);
             }
             if constexpr (do_prep && m >= M_L1 && m < M_L1 + 6) l1_mfma(Oc, integral_constant<int, m - M_L1>{}, g);
-            if constexpr (do_prep && m >= M_RELU && m < M_RELU + 16) relu_piece(Oc, integral_constant<int, m - M_RELU>{}, g);
+            if constexpr (do_prep && m >= M_RELU && m < M_RELU + 16 * RELU_GAPS && !(MPPI_BX3_ABL & 16)) {
+                if constexpr (RELU_GAPS == 2) {
+                    relu_piece(Oc, integral_constant<int, (m - M_RELU) / 2>{}, integral_constant<int, ((m - M_RELU) & 1)>{}, g);
+                } else {
+                    relu_piece(Oc, integral_constant<int, m - M_RELU>{}, integral_constant<int, 0>{}, g);
+                    relu_piece(Oc, integral_constant<int, m - M_RELU>{}, integral_constant<int, 1>{}, g);
+                }
+            }
             if constexpr (m == M_NG && Q == 1 && SRC == SRC_PHILOX && do_prep) {
                 if ((t_prep & 3) == 1) {
                     const int gn = (t_prep >> 2) + 1;
                     if (gn < NG) noise_groups(gn);
                 }
             }
+            } // CUT
             if constexpr (m == M_NEXT) { // the next half-step streams set O
                 b_request(O, integral_constant<int, 16>{});
                 b_request(O, integral_constant<int, 17>{});
@@ -429,6 +507,9 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
     };
 
     const int n_tiles = (K + kBx3R - 1) / kBx3R;
+#ifdef MPPI_BX3_STAMP
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     k0 = tile * kBx3R;
     cA = 0.0f; cB = 0.0f;
@@ -441,14 +522,18 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
         integral_constant<int, 0> c0;
         StepRegs g;
         prep_request(c0, 0, g);
-        noise_piece(c0, g);
+        noise_piece(c0, integral_constant<int, 0>{}, g);
+        noise_piece(c0, integral_constant<int, 1>{}, g);
         static_for<0, 4>([&](auto ic) {
             input_piece(c0, integral_constant<int, 2 * decltype(ic)::value>{}, g);
             insplit_piece(integral_constant<int, 2 * decltype(ic)::value>{}, g);
         });
         static_for<0, 6>([&](auto ic) { l1_mfma(c0, ic, g); });
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(accA[0]), "+v"(accA[1])); // MFMA D -> vector reader
-        static_for<0, 16>([&](auto ic) { relu_piece(c0, ic, g); });
+        static_for<0, 16>([&](auto ic) {
+            relu_piece(c0, ic, integral_constant<int, 0>{}, g);
+            relu_piece(c0, ic, integral_constant<int, 1>{}, g);
+        });
         static_for<0, 8>([&](auto ic) { acc_init(c0, ic); });
     }
     __syncthreads();
@@ -471,15 +556,16 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
         integral_constant<int, 1> c1;
         StepRegs g;
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(accB[0]), "+v"(accB[1]));
-        static_for<0, 32>([&](auto pic) {
-            l3_request(pic, g);
-            l3_piece(c1, pic, g);
+        static_for<0, 4>([&](auto fc) {
+            static_for<0, 4>([&](auto ic) { l3_pair(c1, integral_constant<int, 4 * decltype(fc)::value + decltype(ic)::value>{}, g); });
+            static_for<0, 3>([&](auto ic) { l3_mfma(fc, ic, g); });
         });
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(g.yacc));
         l3_store(c1, g);
         __syncthreads();
-        static_for<0, 2 * SP>([&](auto ic) { fin_request(c1, ic, g); });
+        static_for<0, S>([&](auto ic) { fin_request(c1, ic, g); });
         static_for<0, S>([&](auto nc) { fin_piece(c1, nc, g); });
-        cost_piece(c1);
+        static_for<0, S>([&](auto nc) { cost_piece(c1, nc, g); });
     }
     cA = cA + state_cost<S, QFULL>(CC, xA); // terminal cost, controller_base.cpp:271-272
     cB = cB + state_cost<S, QFULL>(CC, xB);
@@ -492,6 +578,11 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3p(
     mlp_tile_record<A, DIAG, 4>(C, c, valid, w, lane, kk, H, NG, SRC, eps_hbm, seed, koff + (unsigned long long)kk, base,
                                 partials + (size_t)record_slot(tile, rsc) * rsb, rsc);
     } // tiles
+#ifdef MPPI_BX3_STAMP
+    if (tid == 0 && blockIdx.x == 0) // shader clock against the 100 MHz reference: the clock the MFMA stream really ran at
+        printf("bx3 workgroup 0: %llu shader cycles in %llu ticks of 100 MHz = %.0f MHz\n", __builtin_amdgcn_s_memtime() - st_c0,
+               __builtin_amdgcn_s_memrealtime() - st_r0, 100.0 * (double)(__builtin_amdgcn_s_memtime() - st_c0) / (double)(__builtin_amdgcn_s_memrealtime() - st_r0));
+#endif
 }
 
 } // namespace mppi

@@ -289,7 +289,6 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     h->mlp_small = ((cfg->model_kind == MPPI_MODEL_MLP && cfg->mlp->widths[0] != kHid) || cfg->model_kind == MPPI_MODEL_NN_AUV) ? cfg->mlp->widths[0] : 0;
     h->is_gen = gen ? 1 : 0;
     h->mlp_v2 = (cfg->model_kind == MPPI_MODEL_MLP && !h->mlp_small && !h->mlp_bx3 && a <= 3) ? 1 : 0; // a_dim = 4: two h1 images + the rest exceed 160 KiB of LDS
-    h->bx3_p = h->mlp_bx3;
     h->nb_mlp = cfg->model_kind == MPPI_MODEL_MLP ? (h->mlp_v2 ? (h->K_local + kMlp2R - 1) / kMlp2R : (h->K_local + kMlpR - 1) / kMlpR) : 0;
 
     mppi_status st = MPPI_OK;
@@ -641,8 +640,8 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
         if (h->mlp_small == 32 && !h->mlp32_valu) std::snprintf(buf, n, "mppi::k_rollout_mlp32<%d>", h->a);
         else if (h->mlp_small) std::snprintf(buf, n, "mppi::k_rollout_mlp_small<%d, %d>", h->a, h->mlp_small);
         else if (h->mlp_v2 && !h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp2<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
-        else if (h->mlp_bx3 && h->bx3_p) std::snprintf(buf, n, "mppi::k_rollout_mlp_bx3p<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
-        else std::snprintf(buf, n, "mppi::%s<%d, %s>", h->mlp_bx3 ? "k_rollout_mlp_bx3" : "k_rollout_mlp", h->a, h->sigma_diag ? "true" : "false");
+        else if (h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp_bx3<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
+        else std::snprintf(buf, n, "mppi::k_rollout_mlp<%d, %s>", h->a, h->sigma_diag ? "true" : "false");
     else if (!h->normalize && pc_eligible(h))
         std::snprintf(buf, n, "mppi::k_rollout_pc<%d, %d, %d, %s>", h->a, h->pc_np,
                       h->pc_np == 3 ? (NG <= 18 ? 6 : 11) : (NG <= 20 ? 4 : 8), h->sigma_diag ? "true" : "false");
@@ -1000,8 +999,7 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
         h->pc_lds_min = value; break;
     case MPPI_TUNE_SYNC_SPIN: h->sync_spin = value != 0; break;
     case MPPI_TUNE_MLP_V1: // the first exact-fp32 MLP kernel (8 waves, 64 rollouts per workgroup), for A/B timing
-        if (h->hc.model_kind != MPPI_MODEL_MLP || h->mlp_small) return fail(h, MPPI_ERR_INVALID_ARG, "not a 2x256 MLP handle");
-        if (h->mlp_bx3) { h->bx3_p = value == 0; break; } // split-bf16: the lock-step kernel instead of the pipelined one
+        if (h->hc.model_kind != MPPI_MODEL_MLP || h->mlp_bx3 || h->mlp_small) return fail(h, MPPI_ERR_INVALID_ARG, "not an exact-fp32 2x256 MLP handle");
         h->mlp_v2 = (value == 0 && h->a <= 3) ? 1 : 0;
         h->nb_mlp = h->mlp_v2 ? (h->K_local + kMlp2R - 1) / kMlp2R : (h->K_local + kMlpR - 1) / kMlpR; // d_part is sized for the larger count
         break;

@@ -25,7 +25,6 @@ struct mppi_handle {
     int nbp = 0;          // record slots in d_part: record_pad(max(nb, nb_mlp)), the column stride of every rollout launch
     int part_nb = 0;      // tile count whose slots currently hold records (0: all slots neutral)
     int mlp_bx3 = 0;      // MPPI_FLAG_MLP_BF16X3: split-bf16 matrix-core variant of the MLP rollout
-    int bx3_p = 0;        // ... on k_rollout_mlp_bx3p (one wave per SIMD, two pipelined sets); 0 (MPPI_TUNE_MLP_V1): the first, lock-step kernel
     int mlp_small = 0;    // hidden width (16 or 32) of a small learned model served by k_rollout_mlp_small, else 0
     MlpSmallArgs small_args{};
     int mlp32_valu = 0;   // tuning: a Dense(32) network on k_rollout_mlp_small instead of k_rollout_mlp32

@@ -189,7 +189,7 @@ __device__ __forceinline__ void static_for(F &&f)
 
 // -DMPPI_PC_TIMELINE (tools/timeline.py, timing study only): every wave stamps s_memrealtime (100 MHz) at its
 // phase boundaries into LDS and the consumer dumps the 64 stamps in place of the tile's costs.
-#if defined(MPPI_PC_TIMELINE) || defined(MPPI_MLP_TIMELINE)
+#if defined(MPPI_PC_TIMELINE)
 __device__ __forceinline__ unsigned long long pc_stamp()
 {
     unsigned long long t;
@@ -1065,294 +1065,6 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
         c = c + tmp;
     }
     c = c + state_cost<S, QFULL>(C, x); // terminal cost, controller_base.cpp:271-272
-    if (w == 0 && valid) cost[k0 + lane] = c;
-    if (MODE == MODE_COST_ONLY) return;
-
-    mlp_tile_record<A, DIAG>(C, c, valid, w, lane, kk, H, NG, SRC, eps_hbm, seed, gk, base,
-                             partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc); // element (b, col) at partials[b*rsb + col*rsc]
-}
-
-// ----------------------------------------------------------------------------------------
-// k_rollout_mlp_bx3: the same rollout with the two big layers on the BF16 matrix cores at fp32-class accuracy
-// (opt-in: MPPI_FLAG_MLP_BF16X3). Every fp32 operand is split x = hi + lo into two bf16 values (hi = bf16(x),
-// lo = bf16(x - hi), together 16 mantissa bits) and a product sum Σ a·b is evaluated as three
-// v_mfma_f32_32x32x16_bf16 into one fp32 accumulator:  a_lo·b_hi + a_hi·b_lo + a_hi·b_hi  (the dropped lo·lo term is
-// 2^-18 relative). bf16 x bf16 products are exact in fp32, so what is lost is the 2^-17 tail of each operand: over the
-// 64-step recurrence the sample costs are within 9e-7 (relative) of fp64, against 4e-7 for exact fp32 (measured on the
-// synthetic 2x256 network; the parity tests hold it to the same 2e-5 as the fp32 kernel). Three bf16 MFMAs at 16x the
-// fp32-MFMA rate = 5.3x the fp32 peak.
-// Same decomposition as k_rollout_mlp (wave w owns hidden units [32w, 32w+32) of both layers, weights stationary
-// in registers, rollout on the lane); what changes:
-//   * A fragments: 16 k-blocks x (hi, lo) x 4 VGPRs = 128 VGPRs of W2, in the k order of an accumulator tile
-//     (element j of lane half h = k 16s + 8(j>>2) + 4h + (j&3)), so that
-//   * the layer-1 result goes to LDS exactly as it sits in the accumulator registers: relu, split, and ONE
-//     ds_write_b128 per (k-block, column block, part); layer 2 reads each B fragment back with one ds_read_b128
-//     (image [part][k-block][h][rollout][8 bf16] = 64 KB, conflict-free);
-//   * biases: b1 as input k = NIN against a constant 1 (exact in bf16), b2 as the accumulator's initial value.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split_bf16(float x, __bf16 &hi, __bf16 &lo)
-{
-    hi = (__bf16)x; // round to nearest even
-    lo = (__bf16)(x - (float)hi);
-}
-
-template <int A, bool DIAG>
-__global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp_bx3(
-    const DevConsts *__restrict__ C, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
-    const float *__restrict__ U_dev, const float *__restrict__ eps_hbm,
-    const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
-    const int SRC, const int MODE, const int rsb, const int rsc)
-{
-    constexpr bool QFULL = false;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int S = 2 * A, NIN = S + A;
-    static_assert(NIN + 1 <= 16, "inputs + bias must fit one k-block");
-    constexpr int R = kMlpR;
-    const int H = C->H, HA = H * A, K = C->K_local;
-    const int NG = (H + 3) / 4;
-    bf16x8 *img = reinterpret_cast<bf16x8 *>(smem); // [2 parts][16 k-blocks][2 halves][64 rollouts] x 16 B
-    float *y_s = smem + kHid * R;                   // [8][S][R]
-    float *w3_s = y_s + 8 * S * R;                  // [kHid][S]
-    float *z_s = w3_s + kHid * S;                   // [2][4*A][R]
-
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, j = lane & 31, hh = lane >> 5;
-    const int k0 = blockIdx.x * R;
-    const bool valid = (k0 + lane) < K;
-    const int kk = valid ? k0 + lane : K - 1;
-
-    // ---- stationary weights -> registers (hi/lo bf16 fragments)
-    const int unit = 32 * w + j;
-    bf16x8 a2h[16], a2l[16], a1h, a1l;
-#pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 16 * s2 + 8 * (e >> 2) + 4 * hh + (e & 3); // accumulator-tile k order
-            __bf16 hi, lo;
-            split_bf16(M->W2[(size_t)k * kHid + unit], hi, lo);
-            a2h[s2][e] = hi; a2l[s2][e] = lo;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = 8 * hh + e; // natural k order: the B fragment is built from the lane's own inputs
-        const float wv = k < NIN ? M->W1[(size_t)k * kHid + unit] : (k == NIN ? M->b1[unit] : 0.0f);
-        __bf16 hi, lo;
-        split_bf16(wv, hi, lo);
-        a1h[e] = hi; a1l[e] = lo;
-    }
-    f32x16 bias2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bias2[r] = M->b2[32 * w + (r & 3) + 8 * (r >> 2) + 4 * hh];
-    for (int i = tid; i < kHid * S; i += kMlpThreads) w3_s[i] = M->W3[i];
-
-    float x[S];
-#pragma unroll
-    for (int i = 0; i < S; ++i) x[i] = x_dev[i];
-    float c = 0.0f;
-    // wave-uniform normalisation constants, read once (a barrier would otherwise force a re-fetch per step); the
-    // division by xstd becomes a multiplication by its reciprocal: this path is tolerance-bound, not order-bound
-    float xm[NIN], xr[NIN], b3v[S], ysd[S], ymn[S];
-#pragma unroll
-    for (int i = 0; i < NIN; ++i) { xm[i] = M->xmean[i]; xr[i] = 1.0f / M->xstd[i]; }
-#pragma unroll
-    for (int i = 0; i < S; ++i) { b3v[i] = M->b3[i]; ysd[i] = M->ystd[i]; ymn[i] = M->ymean[i]; }
-    PcProducerConsts<A> pcst;
-    pcst.template load<DIAG>(C);
-    const PcProducerConsts<A> *PC = &pcst;
-    PcConsumerConsts<S> ccst;
-    ccst.load(C);
-    const PcConsumerConsts<S> *CC = &ccst;
-    const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)kk;
-    const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
-    const unsigned long long seed = C->seed;
-    if (SRC == SRC_PHILOX && w == 0) { // horizon group 0
-        float z[4 * A];
-        normals_group<A>(seed, gk, base, z);
-#pragma unroll
-        for (int m = 0; m < 4 * A; ++m) z_s[m * R + lane] = z[m];
-    }
-    __syncthreads();
-
-#if defined(MPPI_MLP_TIMELINE)
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = pc_stamp();
-#define MLP_PH(i) do { const unsigned long long tn_ = pc_stamp(); tph[i] += tn_ - tlast; tlast = tn_; } while (0)
-#else
-#define MLP_PH(i) do { } while (0)
-#endif
-    for (int t = 0; t < H; ++t) {
-        float u[A], e[A], v[A];
-        if (SRC == SRC_PHILOX) {
-            const float *zb = z_s + ((t >> 2) & 1) * (4 * A * R) + (t & 3) * A * R + lane;
-            float zz[A];
-#pragma unroll
-            for (int i = 0; i < A; ++i) zz[i] = zb[i * R];
-            scale_noise<A, DIAG>(PC, zz, e);
-        } else {
-#pragma unroll
-            for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
-        }
-#pragma unroll
-        for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
-        const float ac = action_cost<A, DIAG>(PC, u, e);
-
-        // normalised inputs of this lane's rollout, the bias input 1, zero padding -> two 8-element fragments
-        bf16x8 f0h, f0l, f1h, f1l;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float val = 0.0f;
-            if (i < S) val = (x[i] - xm[i]) * xr[i];
-            else if (i < NIN) val = (v[i - S] - xm[i]) * xr[i];
-            else if (i == NIN) val = 1.0f;
-            __bf16 hi, lo;
-            split_bf16(val, hi, lo);
-            if (i < 8) { f0h[i] = hi; f0l[i] = lo; } else { f1h[i - 8] = hi; f1l[i - 8] = lo; }
-        }
-        MLP_PH(0); // noise, action cost, input normalisation + split
-        // ---- layer 1. Column block cb's B fragment of lane (r, h) is inputs [8h, 8h+8) of rollout 32cb+r, held by
-        // lane (r, cb): its own fragment when cb == h, its partner's (lane^32) otherwise — one exchange per step.
-        bf16x8 th, tl;
-        {
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            const i32x4 sh = __builtin_bit_cast(i32x4, hh ? f0h : f1h), sl = __builtin_bit_cast(i32x4, hh ? f0l : f1l);
-            i32x4 rh, rl;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { rh[q] = __shfl_xor(sh[q], 32, 64); rl[q] = __shfl_xor(sl[q], 32, 64); }
-            th = __builtin_bit_cast(bf16x8, rh); tl = __builtin_bit_cast(bf16x8, rl);
-        }
-        const bf16x8 b0h = hh ? th : f0h, b0l = hh ? tl : f0l;
-        const bf16x8 b1h = hh ? f1h : th, b1l = hh ? f1l : tl;
-        f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        f32x16 acc1 = acc0;
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc1, 0, 0, 0);
-        MLP_PH(1); // exchange + layer-1 MFMAs issued
-        // relu, split, and out to the image in accumulator order: registers 8s..8s+7 are the 8 elements of this lane's
-        // B fragment of k-block 2w+s
-#pragma unroll
-        for (int s1 = 0; s1 < 2; ++s1) {
-            bf16x8 h0h, h0l, h1h, h1l;
-#pragma unroll
-            for (int e2 = 0; e2 < 8; ++e2) {
-                __bf16 hi, lo;
-                split_bf16(fmaxf(acc0[8 * s1 + e2], 0.0f), hi, lo);
-                h0h[e2] = hi; h0l[e2] = lo;
-                split_bf16(fmaxf(acc1[8 * s1 + e2], 0.0f), hi, lo);
-                h1h[e2] = hi; h1l[e2] = lo;
-            }
-            const int kb = 2 * w + s1;
-            img[((0 * 16 + kb) * 2 + hh) * 64 + j] = h0h;
-            img[((1 * 16 + kb) * 2 + hh) * 64 + j] = h0l;
-            img[((0 * 16 + kb) * 2 + hh) * 64 + 32 + j] = h1h;
-            img[((1 * 16 + kb) * 2 + hh) * 64 + 32 + j] = h1l;
-        }
-        MLP_PH(2); // relu + split + image writes
-        __syncthreads();
-        MLP_PH(3); // barrier 1
-
-        // the next horizon group's normals, once per workgroup (wave g%8), into the other half of the buffer
-        if (SRC == SRC_PHILOX && (t & 3) == 0) {
-            const int gn = (t >> 2) + 1;
-            if (gn < NG && (gn & 7) == w) {
-                float z[4 * A];
-                normals_group<A>(seed, gk, base + (unsigned long long)gn, z);
-                float *zd = z_s + (gn & 1) * (4 * A * R) + lane;
-#pragma unroll
-                for (int m = 0; m < 4 * A; ++m) zd[m * R] = z[m];
-            }
-        }
-
-        // ---- layer 2: 16 k-blocks x 2 column blocks x 3 products; two k-blocks of fragments in flight per batch
-        acc0 = bias2;
-        acc1 = bias2;
-        const bf16x8 *ih = img + hh * 64 + j, *il = img + (16 * 2 + hh) * 64 + j;
-#if defined(MPPI_ABLATE_BX3_L2)
-#pragma unroll
-        for (int kb = 0; kb < 2; kb += 2) {
-#else
-#pragma unroll
-        for (int kb = 0; kb < 16; kb += 2) {
-#endif
-            bf16x8 q0h[2], q0l[2], q1h[2], q1l[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                q0h[q] = ih[(kb + q) * 128]; q0l[q] = il[(kb + q) * 128];
-                q1h[q] = ih[(kb + q) * 128 + 32]; q1l[q] = il[(kb + q) * 128 + 32];
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2l[kb + q], q0h[q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2l[kb + q], q1h[q], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2h[kb + q], q0l[q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2h[kb + q], q1l[q], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2h[kb + q], q0h[q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2h[kb + q], q1h[q], acc1, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-        MLP_PH(4); // next group's noise (1 wave in 8, every 4th step) + layer-2 MFMAs issued
-        // ---- layer 3 partial over this wave's 32 units (16 per lane half), both column blocks, fp32 VALU
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 py[S]; // (column block 0, column block 1): one v_pk_fma_f32 per (row, output)
-#pragma unroll
-        for (int n = 0; n < S; ++n) py[n] = (f32x2){0.0f, 0.0f};
-#if defined(MPPI_ABLATE_BX3_L3)
-#pragma unroll
-        for (int r = 0; r < 1; ++r) {
-#else
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-#endif
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const f32x2 hv = {fmaxf(acc0[r], 0.0f), fmaxf(acc1[r], 0.0f)};
-            const float *w3 = w3_s + (32 * w + row) * S;
-#pragma unroll
-            for (int n = 0; n < S; ++n) {
-                const float wv = w3[n];
-                py[n] = __builtin_elementwise_fma(hv, (f32x2){wv, wv}, py[n]);
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < S; ++n) { // halves hold different rows: lane half hh keeps column block hh
-            const float keep = hh ? py[n][1] : py[n][0];
-            const float send = hh ? py[n][0] : py[n][1];
-            y_s[(w * S + n) * R + lane] = keep + __shfl_xor(send, 32, 64);
-        }
-        MLP_PH(5); // layer 3 (waits for the MFMA results) + partial writes
-        __syncthreads();
-        MLP_PH(6); // barrier 2
-
-        // ---- y = Σ_waves partial + b3 (fixed order), state update, costs
-#pragma unroll
-        for (int n = 0; n < S; ++n) {
-            float y = y_s[(0 * S + n) * R + lane];
-#pragma unroll
-            for (int ww = 1; ww < 8; ++ww) y = y + y_s[(ww * S + n) * R + lane];
-            y = y + b3v[n];
-            x[n] = x[n] + (y * ysd[n] + ymn[n]);
-        }
-        const float sc = state_cost<S, QFULL>(CC, x); // cost on the POST-step state
-        const float tmp = sc + ac;
-        c = c + tmp;
-        MLP_PH(7); // y reduction, state update, costs
-    }
-#if defined(MPPI_MLP_TIMELINE)
-    if (lane < 8) { float v_ = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v_ = lane == q ? (float)tph[q] : v_;
-        c = v_; }
-    if (valid && lane < 8) cost[k0 + 8 * w + lane] = c; // wave w's 8 phase totals at cost[k0 + 8w ..]
-    return;
-#endif
-    c = c + state_cost<S, QFULL>(CC, x); // terminal cost, controller_base.cpp:271-272
     if (w == 0 && valid) cost[k0 + lane] = c;
     if (MODE == MODE_COST_ONLY) return;
 

@@ -35,7 +35,7 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
         hipExtLaunchKernelGGL(kern, g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const MlpDev *)h->dM, x_dev, U_dev, eps, \
                               (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);                \
     } while (0)
-    if (h->mlp_bx3 && h->bx3_p) { // one tile-walking workgroup of 4 waves per CU
+    if (h->mlp_bx3) { // one tile-walking workgroup of 4 waves per CU
         const size_t ldsp = bx3_lds_floats(2 * A, A, h->H) * 4;
         const dim3 gp(std::min(h->nb_mlp, h->n_cu)), bp(kBx3Threads);
 #define MPPI_BX3P_L(KERN)                                                                                               \
@@ -46,15 +46,12 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
                               (const unsigned long long *)h->d_step, cost, h->d_part, mode, 1, h->nbp);                     \
     } while (0)
         if (src == SRC_PHILOX) {
-            if (h->sigma_diag) MPPI_BX3P_L((k_rollout_mlp_bx3p<A, true, SRC_PHILOX>));
-            else MPPI_BX3P_L((k_rollout_mlp_bx3p<A, false, SRC_PHILOX>));
+            if (h->sigma_diag) MPPI_BX3P_L((k_rollout_mlp_bx3<A, true, SRC_PHILOX>));
+            else MPPI_BX3P_L((k_rollout_mlp_bx3<A, false, SRC_PHILOX>));
         } else if (src == SRC_HBM) {
-            MPPI_BX3P_L((k_rollout_mlp_bx3p<A, false, SRC_HBM>));
+            MPPI_BX3P_L((k_rollout_mlp_bx3<A, false, SRC_HBM>));
         } else return hipErrorInvalidValue;
 #undef MPPI_BX3P_L
-    } else if (h->mlp_bx3) {
-        if (h->sigma_diag) MPPI_MLP_L((k_rollout_mlp_bx3<A, true>), 8);
-        else MPPI_MLP_L((k_rollout_mlp_bx3<A, false>), 16);
     } else if (h->mlp_v2) {
         if constexpr (A <= 3) {
 #define MPPI_MLP2_L(KERN, BIT)                                                                                          \
