@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libmppi_hip.so")
 # (source, defines, object stem). Heaviest first: the pool starts them first.
 # The MLP units are compiled without the SLP vectoriser: what it finds in k_rollout_mlp_bx3's pieces becomes v_pk_*_f32, which
-# serialise with the bf16 MFMA they are meant to hide behind (the other MLP kernels write their packed math explicitly).
+# serialise with the bf16 MFMA they are meant to hide behind (the other MLP kernels write their packed math explicitly). The
+# 13-state unit too: the pairs it finds in the Fossen model cost two s_mov / v_mov each to assemble (0.30 -> 0.26 ms per step).
 MLP_FLAGS = ["-fno-slp-vectorize"]
 UNITS = ([("mppi_launch_mlp.hip", ["MPPI_UNIT_A=%d" % a], "mlp_a%d" % a) for a in (3, 2, 1, 4)]
          + [("mppi_launch_pc.hip", ["MPPI_UNIT_A=%d" % a], "pc_a%d" % a) for a in (4, 3, 2, 1)]
@@ -74,7 +75,7 @@ def _compile_all(objdir, extra, force, verbose):
         obj = os.path.join(objdir, stem + ".o")
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps(src)):
             return obj
-        cmd = [cc, *flags(extra), *(MLP_FLAGS if stem.startswith("mlp_") else []), *["-D" + d for d in defs], "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc, *flags(extra), *(MLP_FLAGS if stem.startswith("mlp_") or stem == "gen" else []), *["-D" + d for d in defs], "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -36,8 +36,87 @@ struct GenConsts {
     float lin_damp[36], lin_damp_fwd[36], quad_damp[6];
     // StaticQuatCost: Q [10x10] (goal comes from DevConsts.goal[13])                    static_cost.py:92-100
     float q10[100];
+    float q10p[100];        // the same, rows paired: q10p[(p*10 + j)*2 + o] = q10[(2p + o)*10 + j] (one 8-byte scalar load feeds v_pk_mul_f32)
     // ElipseCost3D after prepare_consts                                                  elipse_cost.py:141-167
     float e3_q[4], e3_axis[3], e3_map[3], e3_gv, e3_mS, e3_mV;
+    __device__ __forceinline__ float lin_diag(int i) const { return lin_damp[i * 7]; }
+    __device__ __forceinline__ float fwd_diag(int i) const { return lin_damp_fwd[i * 7]; }
+    // a = M (v1, v2) as the reference splits it (M11 v1 + M12 v2 ; M21 v1 + M22 v2), and y = inv(M) r as a dense row sum
+    __device__ __forceinline__ void mass_times(const float (&vel)[6], float (&a)[6]) const
+    {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float s1 = (mtot[i * 6] * vel[0] + mtot[i * 6 + 1] * vel[1]) + mtot[i * 6 + 2] * vel[2];
+            const float s2 = (mtot[i * 6 + 3] * vel[3] + mtot[i * 6 + 4] * vel[4]) + mtot[i * 6 + 5] * vel[5];
+            a[i] = s1 + s2;
+        }
+    }
+    __device__ __forceinline__ void inv_mass_times(const float (&r)[6], float (&y)[6]) const
+    {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float acc = inv_mtot[i * 6] * r[0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) acc = acc + inv_mtot[i * 6 + j] * r[j];
+            y[i] = acc;
+        }
+    }
+};
+
+// The Fossen model's constants as a kernel-local copy (same accessors as GenConsts, so auv_state_dot takes either): the two
+// 6x6 matrices every state_dot multiplies with live in VECTOR registers (72 of the 256 a one-wave-per-SIMD kernel owns), as
+// row pairs. Left to the scalar file — 280 constants for ~100 SGPRs — hipcc spills them into VGPR lanes and pays a
+// v_readlane per use.
+typedef float f32x2g __attribute__((ext_vector_type(2)));
+struct AuvLocal {
+    int rk, damp_diag;
+    float dt, fng_z, fnb_z, cog[3], cob[3];
+    f32x2g mt2[18], iv2[18];              // rows (2p, 2p+1) of column j side by side: [p*6 + j] = (M[2p][j], M[2p+1][j])
+    const float *lin_damp, *lin_damp_fwd; // the dense forms stay behind scalar loads (damp_diag = 0 only)
+    float ldd[6], lfd[6], quad_damp[6];   // diagonals of the linear damping matrices, the quadratic coefficients
+    __device__ __forceinline__ void load(const GenConsts *__restrict__ G)
+    {
+        rk = G->rk; damp_diag = G->damp_diag; dt = G->dt; fng_z = G->fng_z; fnb_z = G->fnb_z;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { cog[i] = G->cog[i]; cob[i] = G->cob[i]; }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                mt2[p * 6 + j] = f32x2g{G->mtot[(2 * p) * 6 + j], G->mtot[(2 * p + 1) * 6 + j]};
+                iv2[p * 6 + j] = f32x2g{G->inv_mtot[(2 * p) * 6 + j], G->inv_mtot[(2 * p + 1) * 6 + j]};
+                asm volatile("" : "+v"(mt2[p * 6 + j]), "+v"(iv2[p * 6 + j]));
+            }
+        lin_damp = G->lin_damp; lin_damp_fwd = G->lin_damp_fwd;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            ldd[i] = G->lin_damp[i * 7]; lfd[i] = G->lin_damp_fwd[i * 7]; quad_damp[i] = G->quad_damp[i];
+            asm volatile("" : "+v"(ldd[i]), "+v"(lfd[i]), "+v"(quad_damp[i]));
+        }
+    }
+    __device__ __forceinline__ float lin_diag(int i) const { return ldd[i]; }
+    __device__ __forceinline__ float fwd_diag(int i) const { return lfd[i]; }
+    // two rows per v_pk_mul_f32 / v_pk_add_f32, every row's operations and their order as in GenConsts' scalar forms
+    __device__ __forceinline__ void mass_times(const float (&vel)[6], float (&a)[6]) const
+    {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const f32x2g s1 = (mt2[p * 6] * f32x2g{vel[0], vel[0]} + mt2[p * 6 + 1] * f32x2g{vel[1], vel[1]}) + mt2[p * 6 + 2] * f32x2g{vel[2], vel[2]};
+            const f32x2g s2 = (mt2[p * 6 + 3] * f32x2g{vel[3], vel[3]} + mt2[p * 6 + 4] * f32x2g{vel[4], vel[4]}) + mt2[p * 6 + 5] * f32x2g{vel[5], vel[5]};
+            const f32x2g t = s1 + s2;
+            a[2 * p] = t.x; a[2 * p + 1] = t.y;
+        }
+    }
+    __device__ __forceinline__ void inv_mass_times(const float (&r)[6], float (&y)[6]) const
+    {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            f32x2g acc = iv2[p * 6] * f32x2g{r[0], r[0]};
+#pragma unroll
+            for (int j = 1; j < 6; ++j) acc = acc + iv2[p * 6 + j] * f32x2g{r[j], r[j]};
+            y[2 * p] = acc.x; y[2 * p + 1] = acc.y;
+        }
+    }
 };
 
 // ---------------------------------------------------------------------------------------- AUVModel
@@ -81,7 +160,8 @@ __device__ __forceinline__ void matvec_n(const float *__restrict__ M, const floa
 
 // auv_model.py:308-351 state_dot = (J(eta) nu, invM (tau - C nu - D nu - g)); the zero blocks of the reference's dense products are skipped
 // pieces: NULL, or 18 floats that receive C nu [6], D nu [6], g [6] (what the reference's tests look at one by one)
-__device__ __forceinline__ void auv_state_dot(const GenConsts *__restrict__ G, const float (&x)[kGenS], const float (&u)[kGenA],
+template <class GT>
+__device__ __forceinline__ void auv_state_dot(const GT *__restrict__ G, const float (&x)[kGenS], const float (&u)[kGenA],
                                               float (&xd)[kGenS], float *pieces = nullptr)
 {
     const float q[4] = {x[3], x[4], x[5], x[6]};
@@ -102,7 +182,7 @@ __device__ __forceinline__ void auv_state_dot(const GenConsts *__restrict__ G, c
     if (G->damp_diag) { // off-diagonal entries: (-0 - v0*0) + (-0) = +-0, times v_j = +-0: dropped
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const float d1 = (-1.0f * G->lin_damp[i * 7]) - (v0 * G->lin_damp_fwd[i * 7]);
+            const float d1 = (-1.0f * G->lin_diag(i)) - (v0 * G->fwd_diag(i));
             const float dii = d1 + (-1.0f * (G->quad_damp[i] * fabsf(vel[i])));
             Dv[i] = dii * vel[i];
         }
@@ -120,16 +200,9 @@ __device__ __forceinline__ void auv_state_dot(const GenConsts *__restrict__ G, c
         }
     }
     // Coriolis (:512-545): a1 = M11 v1 + M12 v2, a2 = M21 v1 + M22 v2; C = [[0, -S(a1)], [-S(a1), -S(a2)]]
-    float a1[3], a2[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float s1 = (G->mtot[i * 6] * vel[0] + G->mtot[i * 6 + 1] * vel[1]) + G->mtot[i * 6 + 2] * vel[2];
-        const float s2 = (G->mtot[i * 6 + 3] * vel[3] + G->mtot[i * 6 + 4] * vel[4]) + G->mtot[i * 6 + 5] * vel[5];
-        a1[i] = s1 + s2;
-        const float r1 = (G->mtot[(3 + i) * 6] * vel[0] + G->mtot[(3 + i) * 6 + 1] * vel[1]) + G->mtot[(3 + i) * 6 + 2] * vel[2];
-        const float r2 = (G->mtot[(3 + i) * 6 + 3] * vel[3] + G->mtot[(3 + i) * 6 + 4] * vel[4]) + G->mtot[(3 + i) * 6 + 5] * vel[5];
-        a2[i] = r1 + r2;
-    }
+    float a6[6];
+    G->mass_times(vel, a6);
+    const float a1[3] = {a6[0], a6[1], a6[2]}, a2[3] = {a6[3], a6[4], a6[5]};
     // -S(a) = [[-0, a2, -a1], [-a2, -0, a0], [a1, -a0, -0]]; rows of C v as running sums over j = 0..5 without the zero terms
     float Cv[6];
     Cv[0] = a1[2] * vel[4] + (-a1[1]) * vel[5];
@@ -157,7 +230,7 @@ __device__ __forceinline__ void auv_state_dot(const GenConsts *__restrict__ G, c
 #pragma unroll
         for (int i = 0; i < 6; ++i) { pieces[i] = Cv[i]; pieces[6 + i] = Dv[i]; }
     }
-    matvec_n<6>(G->inv_mtot, rhs, acc6);
+    G->inv_mass_times(rhs, acc6);
 #pragma unroll
     for (int i = 0; i < 6; ++i) xd[7 + i] = acc6[i];
 }
@@ -175,7 +248,8 @@ __device__ __forceinline__ void normalize_quat(float (&x)[kGenS])
 }
 
 // auv_model.py:279-306 step(rk) + normalize_quat. rk is wave-uniform.
-__device__ __forceinline__ void auv_step(const GenConsts *__restrict__ G, float (&x)[kGenS], const float (&u)[kGenA])
+template <class GT>
+__device__ __forceinline__ void auv_step(const GT *__restrict__ G, float (&x)[kGenS], const float (&u)[kGenA])
 {
     const float dt = G->dt;
     float k1[kGenS], tmp[kGenS];
@@ -223,7 +297,14 @@ __device__ __forceinline__ float state_cost_quat(const DevConsts *__restrict__ C
     d[3] = 2.0f * acosf(dot);
 #pragma unroll
     for (int i = 0; i < 6; ++i) d[4 + i] = x[7 + i] - C->goal[7 + i];
-    matvec_n<10>(G->q10, d, left);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) { // rows 2p, 2p+1 of Q d: the row sums of matvec_n<10>, two at a time
+        const f32x2g *qp = reinterpret_cast<const f32x2g *>(G->q10p) + p * 10;
+        f32x2g a2 = qp[0] * f32x2g{d[0], d[0]};
+#pragma unroll
+        for (int jj = 1; jj < 10; ++jj) a2 = a2 + qp[jj] * f32x2g{d[jj], d[jj]};
+        left[2 * p] = a2.x; left[2 * p + 1] = a2.y;
+    }
     float acc = d[0] * left[0];
 #pragma unroll
     for (int i = 1; i < 10; ++i) acc = acc + d[i] * left[i];
@@ -396,6 +477,8 @@ __global__ __launch_bounds__(64) void k_rollout_gen(
 #pragma unroll
         for (int i = 0; i < S; ++i) x[i] = x_dev[i];
         float z[4 * A];
+        AuvLocal al;
+        if (MODEL == GEN_MODEL_AUV) al.load(G);
         for (int t = 0; t < H; ++t) {
             if (SRC == SRC_PHILOX && (t & 3) == 0) normals_group<A>(seed, gk, base + (unsigned long long)(t >> 2), z);
             float u[A], e[A], v[A];
@@ -422,7 +505,7 @@ __global__ __launch_bounds__(64) void k_rollout_gen(
             for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; } // to_apply, controller_base.cpp:258
             const float ac = action_cost<A, DIAG>(C, u, e);
             if (MODEL == GEN_MODEL_AUV) {
-                auv_step(G, x, v);
+                auv_step(&al, x, v);
             } else {
                 int zoff; // opaque zero offset: keeps the weight loads inside the horizon loop (see k_rollout_mlp_small)
                 asm("s_mov_b32 %0, 0" : "=s"(zoff) : "s"(t));

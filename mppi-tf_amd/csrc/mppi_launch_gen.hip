@@ -104,6 +104,9 @@ const char *mppi_gen_fill(mppi_handle *h, const mppi_config *cfg)
     if (cfg->state_cost_kind == MPPI_STATE_COST_QUAT) {
         if (!cfg->quat_Q) return "StaticQuatCost needs cfg.quat_Q [10*10] (static_cost.py:92-100)";
         for (int i = 0; i < 100; ++i) c.q10[i] = cfg->quat_Q[i];
+        for (int p = 0; p < 5; ++p)
+            for (int j = 0; j < 10; ++j)
+                for (int o = 0; o < 2; ++o) c.q10p[(p * 10 + j) * 2 + o] = c.q10[(2 * p + o) * 10 + j];
     }
     if (cfg->state_cost_kind == MPPI_STATE_COST_ELLIPSE3D) {
         const float *e = cfg->ellipse3d; // normal[3], aVec[3], axis[2], speed, mState, mVel
