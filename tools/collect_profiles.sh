@@ -7,6 +7,7 @@ set -u
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
+rm -rf $OUT   # never mix passes of different runs (gpurun merges gpurun_out/ back over what is already there: clear the local copy too)
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
