@@ -401,13 +401,13 @@ def roofline_of(r):
 
 def sub_record(s):
     name = CONFIG_NAME.get((s["workload"], s["K_per_gpu"], s["H"], 1)) or CONFIG_NAME.get((s["workload"], s["K_per_gpu"], s["H"], 8)) or \
-        {"mlp32": "reference Dense(32)x3 net", "nnauv": "reference NNAUVModel shape s13 a6", "auv": "reference Fossen AUVModel rk2"}.get(s["workload"], "")
+        {"mlp32": "ref Dense(32)x3", "nnauv": "ref NNAUVModel s13 a6", "auv": "ref Fossen AUVModel rk2"}.get(s["workload"], "")
     if "bx3" in s["kernel"]:
         name += " +BF16X3"
     rf = roofline_of(s)
     keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "kernel_us", "floor_us", "valu_busy_us", "dispatch_fixed_us",
             "mfma_busy_frac", "algorithmic_TFLOP_per_s", "traffic")
-    d = {"config": name, "workload": s["workload"], "K": s["K_per_gpu"], "H": s["H"], "value": r4(s["rollouts_per_s"]), "unit": "rollouts/s",
+    d = {"config": name, "workload": s["workload"], "K": s["K_per_gpu"], "H": s["H"], "value": r4(s["rollouts_per_s"]),
          "ms_per_step": r4(s["ms_per_step"]), "steps": s["steps"] * len(s["batches_s"]),
          "roofline": {k: rf[k] for k in keep if rf.get(k) is not None}}
     if s["workload"] == "nnauv":
@@ -469,6 +469,7 @@ def main():
             subs.append(rn.run("mlp", 65536, 64, 20, 3, 0.0))
             subs.append(rn.run("mlp", 65536, 64, 20, 3, 0.0, mlp_bf16x3=True))
             subs.append(rn.run("mlp32", 65536, 64, 50, 5, 0.0))
+            subs.append(rn.run("mlp32", 65536, 64, 50, 5, 0.0, mlp_bf16x3=True))
             for w in ("nnauv", "auv"):
                 try:
                     subs.append(rn.run(w, 65536, 64, 20, 3, 0.0))

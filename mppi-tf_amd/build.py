@@ -20,13 +20,16 @@ SO = os.path.join(HERE, "libmppi_hip.so")
 # serialise with the bf16 MFMA they are meant to hide behind (the other MLP kernels write their packed math explicitly). The
 # 13-state unit too: the pairs it finds in the Fossen model cost two s_mov / v_mov each to assemble (0.30 -> 0.26 ms per step).
 MLP_FLAGS = ["-fno-slp-vectorize"]
+# ... and with builtin MFMAs in VGPR form: by default hipcc parks their accumulators in a0-a255 and pays a v_accvgpr_read / _write per
+# register on either side of every layer of k_rollout_mlp32_bx3 (the asm MFMAs of the other kernels name their registers themselves)
+MLP_ONLY_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 UNITS = ([("mppi_launch_mlp.hip", ["MPPI_UNIT_A=%d" % a], "mlp_a%d" % a) for a in (3, 2, 1, 4)]
          + [("mppi_launch_pc.hip", ["MPPI_UNIT_A=%d" % a], "pc_a%d" % a) for a in (4, 3, 2, 1)]
          + [("mppi_launch_tile.hip", ["MPPI_UNIT_A=%d" % a], "tile_a%d" % a) for a in (4, 3, 2, 1)]
          + [("mppi_launch_gen.hip", [], "gen"), ("mppi_learner.hip", [], "learner"), ("mppi_capi.hip", [], "capi")])
 SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["mppi_device.hip.h", "mppi_kernels.hip.h", "mppi_mlp2.hip.h", "mppi_mlp_small.hip.h", "mppi_mlp32.hip.h",
-           "mppi_handle.hip.h", "mppi_gen.hip.h", "mppi_mfma32.hip.h", "mppi_bx3.hip.h"]
+           "mppi_handle.hip.h", "mppi_gen.hip.h", "mppi_mfma32.hip.h", "mppi_bx3.hip.h", "mppi_mlp32b.hip.h"]
 ARCH = "gfx950"
 
 
@@ -75,7 +78,7 @@ def _compile_all(objdir, extra, force, verbose):
         obj = os.path.join(objdir, stem + ".o")
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps(src)):
             return obj
-        cmd = [cc, *flags(extra), *(MLP_FLAGS if stem.startswith("mlp_") or stem == "gen" else []), *["-D" + d for d in defs], "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc, *flags(extra), *(MLP_FLAGS if stem.startswith("mlp_") or stem == "gen" else []), *(MLP_ONLY_FLAGS if stem.startswith("mlp_") else []), *["-D" + d for d in defs], "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -205,7 +205,8 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         const bool big = d->n_layers == 3 && same && hid == kHid, small = same && (hid == 16 || hid == 32);
         if (!big && !small)
             return fail(nullptr, MPPI_ERR_UNSUPPORTED, "MLP kernels exist for hidden widths {256,256} (matrix cores) and 1-3 equal hidden layers of 16 or 32 (nn_model.py:54-60)");
-        if (small && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "MPPI_FLAG_MLP_BF16X3 applies to the 256-wide network only");
+        if (small && hid != 32 && (cfg->flags & MPPI_FLAG_MLP_BF16X3))
+            return fail(nullptr, MPPI_ERR_INVALID_ARG, "MPPI_FLAG_MLP_BF16X3 applies to the 256-wide and the 32-wide networks");
         if (s != 2 * a || a > 4) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "MLP rollouts are instantiated for s_dim == 2*a_dim, a_dim <= 4");
         if (cfg->q_is_full) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "MLP rollouts are instantiated for a diagonal Q");
     }
@@ -637,7 +638,8 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
     const int NG = (h->H + 3) / 4;
     if (h->is_gen) std::snprintf(buf, n, "%s", mppi_gen_kernel_name(h));
     else if (h->hc.model_kind == MPPI_MODEL_MLP)
-        if (h->mlp_small == 32 && !h->mlp32_valu) std::snprintf(buf, n, "mppi::k_rollout_mlp32<%d>", h->a);
+        if (h->mlp_small == 32 && h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp32_bx3<%d>", h->a);
+        else if (h->mlp_small == 32 && !h->mlp32_valu) std::snprintf(buf, n, "mppi::k_rollout_mlp32<%d>", h->a);
         else if (h->mlp_small) std::snprintf(buf, n, "mppi::k_rollout_mlp_small<%d, %d>", h->a, h->mlp_small);
         else if (h->mlp_v2 && !h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp2<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
         else if (h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp_bx3<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
@@ -1004,7 +1006,7 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
         h->nb_mlp = h->mlp_v2 ? (h->K_local + kMlp2R - 1) / kMlp2R : (h->K_local + kMlpR - 1) / kMlpR; // d_part is sized for the larger count
         break;
     case MPPI_TUNE_MLP32_VALU:
-        if (h->mlp_small != 32) return fail(h, MPPI_ERR_INVALID_ARG, "not a Dense(32) MLP handle");
+        if (h->mlp_small != 32 || h->mlp_bx3) return fail(h, MPPI_ERR_INVALID_ARG, "not an exact-fp32 Dense(32) MLP handle");
         h->mlp32_valu = value != 0; break;
     case MPPI_TUNE_P2P_FAULT:
         if (value < 0 || value > 2) return fail(h, MPPI_ERR_INVALID_ARG, "fault: 0 none, 1 export, 2 probe");

@@ -1077,6 +1077,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
 #include "mppi_bx3.hip.h"
 #include "mppi_mlp_small.hip.h"
 #include "mppi_mlp32.hip.h"
+#include "mppi_mlp32b.hip.h"
 namespace mppi {
 
 // min / max of the costs (Py normalizeCost, controller_base.py:468-474): out[0]=min, out[1]=max-min

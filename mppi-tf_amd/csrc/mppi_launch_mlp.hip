@@ -13,6 +13,11 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
     const size_t lds = (h->mlp_v2 ? mlp2_lds_floats(2 * A, A, h->H) : mlp_lds_floats(2 * A, A)) * 4;
     const dim3 g(h->mlp_v2 ? std::min(h->nb_mlp, h->n_cu) : h->nb_mlp), b(h->mlp_v2 ? kMlp2Threads : kMlpThreads);
     if (mode != MODE_ROLLOUT && mode != MODE_COST_ONLY) return hipErrorInvalidValue;
+    if (h->mlp_small == 32 && h->mlp_bx3) { // ... on the bf16 matrix cores, every operand split in two (MPPI_FLAG_MLP_BF16X3)
+        hipExtLaunchKernelGGL((k_rollout_mlp32_bx3<A>), dim3(h->nb_mlp), dim3(kMlp32Threads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC,
+                              (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);
+        return hipGetLastError();
+    }
     if (h->mlp_small == 32 && !h->mlp32_valu) { // matrix cores, weights stationary in registers: 2 waves x 32 rollouts per tile
         hipExtLaunchKernelGGL((k_rollout_mlp32<A>), dim3(h->nb_mlp), dim3(kMlp32Threads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC,
                               (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);

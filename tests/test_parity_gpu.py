@@ -675,8 +675,9 @@ def test_small_mlp_single_step_reference_order_is_bit_exact(m, hid, n_hidden):
 
 # (hidden width, hidden layers, Handle tuning): Dense(32) runs on the matrix cores (k_rollout_mlp32) by default and on the
 # vector ALU (k_rollout_mlp_small) with mlp32_valu; Dense(16) on the vector ALU
-SMALL_KERNELS = [(32, 3, None), (32, 3, {"mlp32_valu": 1}), (16, 3, None), (32, 1, None), (32, 2, None), (16, 2, None), (32, 1, {"mlp32_valu": 1})]
-SMALL_KERNEL_IDS = ["32x3-mfma", "32x3-valu", "16x3", "32x1-mfma", "32x2-mfma", "16x2", "32x1-valu"]
+SMALL_KERNELS = [(32, 3, None), (32, 3, {"mlp32_valu": 1}), (16, 3, None), (32, 1, None), (32, 2, None), (16, 2, None), (32, 1, {"mlp32_valu": 1}),
+                 (32, 3, "bf16x3"), (32, 2, "bf16x3"), (32, 1, "bf16x3")]  # "bf16x3": k_rollout_mlp32_bx3 (MPPI_FLAG_MLP_BF16X3)
+SMALL_KERNEL_IDS = ["32x3-mfma", "32x3-valu", "16x3", "32x1-mfma", "32x2-mfma", "16x2", "32x1-valu", "32x3-bf16x3", "32x2-bf16x3", "32x1-bf16x3"]
 
 
 @pytest.mark.parametrize("hid,n_hidden,tuning", SMALL_KERNELS, ids=SMALL_KERNEL_IDS)
@@ -686,17 +687,22 @@ def test_small_mlp_control_step_against_oracle(m, K, H, a, cond, hid, n_hidden, 
     U' within north_star's 1e-5 wherever the fp32 CPU evaluation itself is (see MLP_VARIANTS: K=1000, H=130, a=1 at
     lambda=1 is not — fp32 CPU 2.2e-5, this kernel 1.6e-5); ragged K (33, 100, 1000: partial last tile) and a horizon
     that is no multiple of 4. `cond`: the shapes that ARE well conditioned carry the absolute 1e-5 bar unconditionally."""
+    if tuning == "bf16x3":  # the split-bf16 kernel carries the 2x256 split-bf16 kernel's bars (MLP_VARIANTS)
+        h = check_mlp_step(m, K, H, a, 300 + H, dict(mlp_bf16x3=True), 2e-5, 8.0, hid=hid, n_hidden=n_hidden, well_conditioned=cond)
+        assert "k_rollout_mlp32_bx3" in h.rollout_kernel_name()
+        return
     check_mlp_step(m, K, H, a, 300 + H, dict(tuning=tuning) if tuning else {}, 1e-5, 4.0, hid=hid, n_hidden=n_hidden, well_conditioned=cond)
 
 
-def test_small_mlp_fused_philox_step_and_sharding(m):
+@pytest.mark.parametrize("bx3", [False, True], ids=["fp32mfma", "bf16x3"])
+def test_small_mlp_fused_philox_step_and_sharding(m, bx3):
     """The reference's {32,32,32,s} network on the fused Philox path: U' against the fp64 oracle on the noise the step
     exported; the device noise is the oracle's Philox stream; and the 4-way K-sharded step reproduces the unsharded one."""
     import torch
     K, H, a = 8192, 20, 3
     mlp = make_mlp(6, a, seed=5, hid=32, n_hidden=3)
     sigma = 0.25 * np.eye(a)
-    cfg = dict(k=K, tau=H, s_dim=6, a_dim=a, lam=1.0, sigma=sigma, goal=GOAL3, mlp=mlp, seed=7)
+    cfg = dict(k=K, tau=H, s_dim=6, a_dim=a, lam=1.0, sigma=sigma, goal=GOAL3, mlp=mlp, seed=7, mlp_bf16x3=bx3)
     h = m.Handle(**cfg)
     p64 = orc.Problem(tau=H, s=6, a=a, lam=1.0, sigma=sigma, goal=GOAL3, mlp=mlp, threads=0, dtype=np.float64)
     x = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
@@ -705,8 +711,9 @@ def test_small_mlp_fused_philox_step_and_sharding(m):
     eps = h.debug_get(m.DBG_NOISE)
     np.testing.assert_allclose(eps, orc.noise(7, 0, 0, K, H, a, sigma), rtol=0, atol=5e-6)
     u64, U64, c64 = p64.next_with_noise(x, U_in, eps)
-    assert np.abs(h.get_action_sequence().astype(np.float64) - np.asarray(U64)).max() <= 1e-5
-    assert np.abs(u.astype(np.float64) - np.asarray(u64)).max() <= 1e-5
+    bar = 2e-5 if bx3 else 1e-5  # MLP_VARIANTS' bars
+    assert np.abs(h.get_action_sequence().astype(np.float64) - np.asarray(U64)).max() <= bar
+    assert np.abs(u.astype(np.float64) - np.asarray(u64)).max() <= bar
     c = h.debug_get(m.DBG_COSTS).astype(np.float64)
     assert (np.abs(c - np.asarray(c64)) / np.abs(np.asarray(c64))).max() < 2e-5
     # 4 shards on one device: partial records -> combine == the unsharded update
@@ -725,14 +732,14 @@ def test_small_mlp_fused_philox_step_and_sharding(m):
 
 def test_mlp_shapes_without_a_kernel_are_refused(m):
     """Widths that neither kernel family serves answer MPPI_ERR_UNSUPPORTED with the reason; the split-bf16 flag is the
-    256-wide network's."""
+    256-wide and the 32-wide networks'."""
     a, s = 3, 6
     with pytest.raises(m.MppiError) as e:
         m.Handle(k=64, tau=4, s_dim=s, a_dim=a, sigma=0.25 * np.eye(a), mlp=make_mlp(s, a, hid=64, n_hidden=2))
     assert e.value.status == 4 and "16 or 32" in str(e.value)  # MPPI_ERR_UNSUPPORTED
     with pytest.raises(m.MppiError) as e:
-        m.Handle(k=64, tau=4, s_dim=s, a_dim=a, sigma=0.25 * np.eye(a), mlp=make_mlp(s, a, hid=32, n_hidden=3), mlp_bf16x3=True)
-    assert e.value.status == 1  # MPPI_ERR_INVALID_ARG
+        m.Handle(k=64, tau=4, s_dim=s, a_dim=a, sigma=0.25 * np.eye(a), mlp=make_mlp(s, a, hid=16, n_hidden=3), mlp_bf16x3=True)
+    assert e.value.status == 1  # MPPI_ERR_INVALID_ARG (the 32-wide network has a split-bf16 kernel, the 16-wide one does not)
 
 
 def mlp_full_size_properties(m, h, p64, x, U_in, n_check=1536):

@@ -10,8 +10,8 @@ passes + 2 wait states, passes = 16 for a 32x32 f32 MFMA (v_mfma_f32_32x32x2_f32
 An instruction is one wait state, `s_nop N` is N + 1, an intervening MFMA on another accumulator its own pass count (the matrix
 pipe runs one MFMA at a time, in order). NOT a hazard: the next MFMA accumulating into the same
 destination (SrcC = vDst, back to back), and MFMAs reading it as SrcC. An MFMA reading a pending destination as A or B IS
-one. The scan follows straight-line code: a label or a branch ends the window (the window is then simply not checked
-further: this is a lower bound on what is found, which is what a tripwire needs)."""
+one. The scan follows the fall-through path: labels and conditional branches do not end the window, an unconditional branch
+does (the window is then simply not checked further: this is a lower bound on what is found, which is what a tripwire needs)."""
 import os
 import re
 import subprocess
@@ -56,9 +56,13 @@ def scan(name, lines):
         txt = ln.split("//")[0].strip()
         if not txt:
             continue
-        if txt.endswith(":") or txt.startswith("s_cbranch") or txt.startswith("s_branch") or txt.startswith("s_endpgm") or txt.startswith("s_setpc"):
+        if txt.endswith(":"):  # a label: the fall-through path arrives here with everything still pending
+            continue
+        if txt.startswith("s_branch") or txt.startswith("s_endpgm") or txt.startswith("s_setpc"):
             pend = []
             continue
+        # (a conditional branch falls through when not taken: it counts as the one wait state it is — r03: an inline-asm v_max
+        # behind `MFMA; s_cbranch` read a builtin MFMA's result too early and the scan, which used to stop at branches, missed it)
         op, _, rest = txt.partition(" ")
         ops = [o.strip() for o in rest.split(",")]
         step = 1
