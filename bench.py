@@ -407,10 +407,9 @@ def sub_record(s):
     rf = roofline_of(s)
     keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "kernel_us", "floor_us", "valu_busy_us", "dispatch_fixed_us",
             "mfma_busy_frac", "algorithmic_TFLOP_per_s", "traffic")
-    d = {"config": name, "workload": s["workload"], "K": s["K_per_gpu"], "H": s["H"], "value": r4(s["rollouts_per_s"]),
-         "ms_per_step": r4(s["ms_per_step"]), "steps": s["steps"] * len(s["batches_s"]),
+    d = {"config": name, "K": s["K_per_gpu"], "H": s["H"], "value": r4(s["rollouts_per_s"]), "ms_per_step": r4(s["ms_per_step"]),
          "roofline": {k: rf[k] for k in keep if rf.get(k) is not None}}
-    if s["workload"] == "nnauv":
+    if s["workload"] == "nnauv" and "bx3" not in s["kernel"]:
         d["weights"] = trained_nnauv()[1]
     return d
 
@@ -470,9 +469,9 @@ def main():
             subs.append(rn.run("mlp", 65536, 64, 20, 3, 0.0, mlp_bf16x3=True))
             subs.append(rn.run("mlp32", 65536, 64, 50, 5, 0.0))
             subs.append(rn.run("mlp32", 65536, 64, 50, 5, 0.0, mlp_bf16x3=True))
-            for w in ("nnauv", "auv"):
+            for w, kw in (("nnauv", {}), ("nnauv", dict(mlp_bf16x3=True)), ("auv", {})):
                 try:
-                    subs.append(rn.run(w, 65536, 64, 20, 3, 0.0))
+                    subs.append(rn.run(w, 65536, 64, 20, 3, 0.0, **kw))
                 except Exception as e:  # a sub-record must never cost the headline
                     sys.stderr.write("bench.py: sub-record %s skipped: %s\n" % (w, e))
         else:  # configs[4]'s per-GPU shape on every rank: K = 65536 x N, H = 128, learned 2x256 model (C5 itself at N = 8)

@@ -71,7 +71,7 @@ enum { MPPI_STATE_COST_QUADRATIC = 0, /* (x-g)ᵀQ(x-g)   src/cost_base.cpp:56-6
 /* mppi_config.flags */
 enum { MPPI_FLAG_UPSILON_SCALES_NOISE = 1, /* Py build_noise: eps = (υΣ)·z while the cost keeps Σ⁻¹ of the
                                               un-augmented Σ (controller_base.py:362-368, cost_base.py:35-41) */
-       MPPI_FLAG_MLP_BF16X3 = 2 /* learned point-mass model, 256-wide or 32-wide hidden layers: the layers run on the BF16
+       MPPI_FLAG_MLP_BF16X3 = 2 /* learned models (point mass: 256- or 32-wide hidden layers; NNAUVModel: 32-wide): the layers run on the BF16
                                    matrix cores with every fp32 operand split into two bf16 values and three products per
                                    term (fp32 accumulate): ~2x the rounding error of the exact-fp32 path (sample costs
                                    within 1e-6 relative of fp64 on the synthetic network), 1.7-3.3x its speed. Off by

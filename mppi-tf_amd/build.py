@@ -21,7 +21,7 @@ SO = os.path.join(HERE, "libmppi_hip.so")
 # 13-state unit too: the pairs it finds in the Fossen model cost two s_mov / v_mov each to assemble (0.30 -> 0.26 ms per step).
 MLP_FLAGS = ["-fno-slp-vectorize"]
 # ... and with builtin MFMAs in VGPR form: by default hipcc parks their accumulators in a0-a255 and pays a v_accvgpr_read / _write per
-# register on either side of every layer of k_rollout_mlp32_bx3 (the asm MFMAs of the other kernels name their registers themselves)
+# register on either side of every layer of k_rollout_mlp32_bx3 / k_rollout_nnauv32_bx3 (the asm MFMAs of the other kernels name their registers themselves)
 MLP_ONLY_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 UNITS = ([("mppi_launch_mlp.hip", ["MPPI_UNIT_A=%d" % a], "mlp_a%d" % a) for a in (3, 2, 1, 4)]
          + [("mppi_launch_pc.hip", ["MPPI_UNIT_A=%d" % a], "pc_a%d" % a) for a in (4, 3, 2, 1)]
@@ -78,7 +78,7 @@ def _compile_all(objdir, extra, force, verbose):
         obj = os.path.join(objdir, stem + ".o")
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps(src)):
             return obj
-        cmd = [cc, *flags(extra), *(MLP_FLAGS if stem.startswith("mlp_") or stem == "gen" else []), *(MLP_ONLY_FLAGS if stem.startswith("mlp_") else []), *["-D" + d for d in defs], "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc, *flags(extra), *(MLP_FLAGS if stem.startswith("mlp_") or stem == "gen" else []), *(MLP_ONLY_FLAGS if stem.startswith("mlp_") or stem == "gen" else []), *["-D" + d for d in defs], "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -185,7 +185,7 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         bool same = hid == 16 || hid == 32;
         for (int l = 0; l + 1 < d->n_layers; ++l) same = same && d->widths[l] == hid;
         if (!same) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "NNAUVModel kernels exist for 1-3 equal hidden layers of 16 or 32 (nn_model.py:54-60)");
-        if (cfg->flags & MPPI_FLAG_MLP_BF16X3) return fail(nullptr, MPPI_ERR_INVALID_ARG, "MPPI_FLAG_MLP_BF16X3 applies to the 256-wide network only");
+        if (hid != 32 && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "MPPI_FLAG_MLP_BF16X3 applies to the 256-wide and the 32-wide networks");
     }
     if (cfg->state_cost_kind == MPPI_STATE_COST_ELLIPSE) {
         if (!cfg->ellipse) return fail(nullptr, MPPI_ERR_INVALID_ARG, "the elliptic cost needs cfg.ellipse[7]");
@@ -286,7 +286,7 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     else if (a > 4) h->no_rollout = "rollout kernels are instantiated for a_dim <= 4";
     else if (tile_lds_floats(h->HA, R) * 4 > lds_cap) h->no_rollout = "tau*a_dim too large: the 16-rollout LDS tile exceeds 160 KiB";
     h->R = R; h->nb = (h->K_local + R - 1) / R; h->tile_lds = tile_lds_floats(h->HA, R) * 4;
-    h->mlp_bx3 = (cfg->model_kind == MPPI_MODEL_MLP && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) ? 1 : 0;
+    h->mlp_bx3 = ((cfg->model_kind == MPPI_MODEL_MLP || cfg->model_kind == MPPI_MODEL_NN_AUV) && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) ? 1 : 0;
     h->mlp_small = ((cfg->model_kind == MPPI_MODEL_MLP && cfg->mlp->widths[0] != kHid) || cfg->model_kind == MPPI_MODEL_NN_AUV) ? cfg->mlp->widths[0] : 0;
     h->is_gen = gen ? 1 : 0;
     h->mlp_v2 = (cfg->model_kind == MPPI_MODEL_MLP && !h->mlp_small && !h->mlp_bx3 && a <= 3) ? 1 : 0; // a_dim = 4: two h1 images + the rest exceed 160 KiB of LDS

@@ -712,6 +712,186 @@ __global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnauv32(
                                 base, partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc);
 }
 
+// k_rollout_nnauv32_bx3: the same NNAUVModel network on the BF16 matrix cores at fp32-class accuracy (opt-in MPPI_FLAG_MLP_BF16X3), the
+// design of k_rollout_mlp32_bx3 (mppi_mlp32b.hip.h): every operand split x = hi + lo (two bf16), three products per term, a 32-wide
+// layer = 6 v_mfma_f32_32x32x16_bf16, registers 8 kb .. 8 kb + 7 of a lane (relu'd, split) are the next layer's B fragment of k-block
+// kb, and the output layer rides the matrix core too: A row m carries output (m & 3) + 4 (m >> 3) — 13 of the 16 a lane half holds,
+// each output once per half — so register n of EVERY lane is output n of its rollout. The 16 inputs fill layer 1's k-block: its bias
+// is the C operand. Builtin MFMAs (hipcc sees their hazards), compiled in VGPR form.
+__global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnauv32_bx3(
+    const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
+    const float *__restrict__ U_dev, const float *__restrict__ eps_hbm, const unsigned long long *__restrict__ step_ctr,
+    float *__restrict__ cost, float *__restrict__ partials, const int SRC, const int MODE, const int rsb, const int rsc)
+{
+    constexpr int S = kGenS, A = kGenA, NIN = kGenNin, XOFF = 3, HID = 32;
+    static_assert(NIN == 16 && S <= 16, "the inputs are exactly one k-block; the outputs fit the 16 registers both lane halves share");
+    constexpr bool DIAG = false;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    __shared__ float z_s[2][4 * A][32]; // per wave: the normals of one horizon group
+    __shared__ float cost_s[64];
+    const int H = C->H, HA = H * A, K = C->K_local;
+    const int NG = (H + 3) / 4;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
+    const int k0 = blockIdx.x * 64;
+    const int kk = min(k0 + 32 * w + j, K - 1); // rollouts past K recompute the last sample, outside every sum
+    const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
+    const unsigned long long seed = C->seed;
+    const unsigned int gk = (unsigned int)C->k_offset + (unsigned int)kk;
+    const int n_hidden = M->n_layers - 1;
+    auto frag = [](const int (&v)[4]) { return __builtin_bit_cast(bf16x8, i32x4{v[0], v[1], v[2], v[3]}); };
+    auto k_unit = [&](int kb, int e) { return 16 * kb + 8 * (e >> 2) + 4 * hh + (e & 3); }; // hidden unit behind k slot 8 hh + e of k-block kb
+    auto row_of = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * hh; };                     // accumulator register r of this lane half
+
+    // ---- stationary operands (hi, lo)
+    bf16x8 a1h, a1l, ahh[2][2], ahl[2][2], aoh[2], aol[2];
+    f32x16 b1t, bht[2], bot;
+    {
+        int hi[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) // layer 1: natural k order 8 hh + e
+            split_pair(M->Wl[0][(8 * hh + 2 * q) * HID + j], M->Wl[0][(8 * hh + 2 * q + 1) * HID + j], hi[q], lo[q]);
+        a1h = frag(hi); a1l = frag(lo);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b1t[r] = M->bl[0][row_of(r)];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const bool have = l + 2 <= n_hidden; // hidden-to-hidden layer l exists
+            const float *Wl = have ? M->Wl[l + 1] : M->Wl[0], *bl = have ? M->bl[l + 1] : M->bl[0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    split_pair(have ? Wl[k_unit(kb, 2 * q) * HID + j] : 0.0f, have ? Wl[k_unit(kb, 2 * q + 1) * HID + j] : 0.0f, hi[q], lo[q]);
+                ahh[l][kb] = frag(hi); ahl[l][kb] = frag(lo);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bht[l][r] = have ? bl[row_of(r)] : 0.0f;
+        }
+        const float *W3g = M->Wl[n_hidden], *b3g = M->bl[n_hidden];
+        const int ld3 = M->ld[n_hidden];               // 14: the host pads the 13-wide output layer to an even width
+        const int out_j = (j & 3) + 4 * (j >> 3);      // the output this lane's A row carries (>= S: none)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                split_pair(out_j < S ? W3g[k_unit(kb, 2 * q) * ld3 + (out_j < S ? out_j : 0)] : 0.0f,
+                           out_j < S ? W3g[k_unit(kb, 2 * q + 1) * ld3 + (out_j < S ? out_j : 0)] : 0.0f, hi[q], lo[q]);
+            aoh[kb] = frag(hi); aol[kb] = frag(lo);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bot[r] = r < S ? b3g[r < S ? r : 0] : 0.0f; // register r = row (r & 3) + 8 (r >> 2) + 4 hh = output r
+    }
+    float xms[8], xrs[8], ysd[S], ymn[S]; // the lane's 8 inputs are k = 8 hh + e
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        xms[e] = hh ? M->xmean[8 + e] : M->xmean[e];
+        xrs[e] = 1.0f / (hh ? M->xstd[8 + e] : M->xstd[e]);
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) { ysd[i] = M->ystd[i]; ymn[i] = M->ymean[i]; }
+    float x[S], c = 0.0f;
+#pragma unroll
+    for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+    __syncthreads();
+
+    auto next_b = [&](const f32x16 &acc, bf16x8 (&bh)[2], bf16x8 (&bl)[2]) { // relu + split: the next layer's two B fragments
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            int hi[4], lo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { // v_med3_f32(x, 0, +inf): a relu hipcc can see behind its own MFMAs (mppi_mlp32b.hip.h)
+                const float ra = __builtin_amdgcn_fmed3f(acc[8 * kb + 2 * q], 0.0f, __builtin_inff());
+                const float rb = __builtin_amdgcn_fmed3f(acc[8 * kb + 2 * q + 1], 0.0f, __builtin_inff());
+                split_pair(ra, rb, hi[q], lo[q]);
+            }
+            bh[kb] = frag(hi); bl[kb] = frag(lo);
+        }
+    };
+    auto layer = [&](const bf16x8 (&wh)[2], const bf16x8 (&wl)[2], const bf16x8 (&bh)[2], const bf16x8 (&bl)[2], f32x16 acc) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kb], bh[kb], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kb], bl[kb], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kb], bh[kb], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+
+    for (int t = 0; t < H; ++t) {
+        if (SRC == SRC_PHILOX && (t & 3) == 0) { // this wave's normals of the group: block q by the half with q & 1 == hh
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < A; ++q) {
+                if ((q & 1) == hh) {
+                    const float4 n = normals_of_block(seed, (unsigned long long)gk, (base + (unsigned long long)(t >> 2)) * A + q);
+                    z_s[w][4 * q + 0][j] = n.x; z_s[w][4 * q + 1][j] = n.y; z_s[w][4 * q + 2][j] = n.z; z_s[w][4 * q + 3][j] = n.w;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): one wave's LDS accesses complete in order
+            __builtin_amdgcn_wave_barrier();
+        }
+        float u[A], e[A], v[A];
+        if (SRC == SRC_PHILOX) {
+            float z1[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) z1[i] = z_s[w][(t & 3) * A + i][j];
+            scale_noise<A, DIAG>(C, z1, e);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
+        }
+#pragma unroll
+        for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
+        const float ac = action_cost<A, DIAG>(C, u, e);
+        // layer 1: the B fragment of lane (j, hh) is inputs 8 hh .. 8 hh + 7 of rollout j; input i = x[3 + i] for i < 10, else v[i - 10]
+        auto raw = [&](int i) { return i < S - XOFF ? x[i < S - XOFF ? XOFF + i : 0] : v[i >= S - XOFF ? i - (S - XOFF) : 0]; };
+        int ih[4], il[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float in2[2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int ee = 2 * q + o;
+                const float sel = hh ? raw(8 + ee) : raw(ee);
+                in2[o] = (sel - xms[ee]) * xrs[ee];
+            }
+            split_pair(in2[0], in2[1], ih[q], il[q]);
+        }
+        const bf16x8 inh = frag(ih), inl = frag(il);
+        f32x16 acc = b1t;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, inh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, inl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, inh, acc, 0, 0, 0);
+        bf16x8 bh[2], bl[2];
+        if (n_hidden >= 2) {
+            next_b(acc, bh, bl);
+            acc = layer(ahh[0], ahl[0], bh, bl, bht[0]);
+            if (n_hidden >= 3) {
+                next_b(acc, bh, bl);
+                acc = layer(ahh[1], ahl[1], bh, bl, bht[1]);
+            }
+        }
+        next_b(acc, bh, bl);
+        acc = layer(aoh, aol, bh, bl, bot); // register n (< 13) of every lane: output n of rollout j, bias included
+#pragma unroll
+        for (int n = 0; n < S; ++n) x[n] = x[n] + (acc[n] * ysd[n] + ymn[n]); // next_state = state + delta (nn_model.py:303-304)
+        const float sc = gen_state_cost(C, G, x); // cost on the POST-step state
+        const float tmp = sc + ac;
+        c = c + tmp;
+    }
+    c = c + gen_state_cost(C, G, x); // terminal cost, controller_base.cpp:271-272
+    // lane l of BOTH waves now stands for rollout k0 + l of the tile
+    if (hh == 0) cost_s[32 * w + j] = c;
+    __syncthreads();
+    const float ct = cost_s[lane];
+    const bool valid = (k0 + lane) < K;
+    const int kt = valid ? k0 + lane : K - 1;
+    if (w == 0 && valid) cost[k0 + lane] = ct;
+    if (MODE == MODE_COST_ONLY) return;
+    mlp_tile_record<A, DIAG, 2>(C, ct, valid, w, lane, kt, H, NG, SRC, eps_hbm, seed, (unsigned long long)C->k_offset + (unsigned long long)kt,
+                                base, partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc);
+}
+
 // ElipseCost3D's three terms for k states -> out [k, 3] (position, orientation, velocity error)
 __global__ void k_e3_terms(const GenConsts *__restrict__ G, const float *__restrict__ x, int k, int in_plane, float *__restrict__ out)
 {

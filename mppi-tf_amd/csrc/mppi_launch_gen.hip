@@ -162,8 +162,12 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
     // Dense(32) NNAUVModel: the matrix-core kernel (rollouts and cost-only passes; the record-from-given-costs / noise-export modes
     // and MPPI_TUNE_MLP32_VALU stay on the vector-ALU kernel)
     if (h->hc.model_kind == MPPI_MODEL_NN_AUV && h->mlp_small == 32 && !h->mlp32_valu && (mode == MODE_ROLLOUT || mode == MODE_COST_ONLY) && noise_out == nullptr) {
-        hipExtLaunchKernelGGL(k_rollout_nnauv32, grid, dim3(kNnauv32Threads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,
-                              (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp);
+        if (h->mlp_bx3) // MPPI_FLAG_MLP_BF16X3: the bf16 matrix cores, every operand split in two
+            hipExtLaunchKernelGGL(k_rollout_nnauv32_bx3, grid, dim3(kNnauv32Threads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,
+                                  (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp);
+        else
+            hipExtLaunchKernelGGL(k_rollout_nnauv32, grid, dim3(kNnauv32Threads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,
+                                  (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp);
         return hipGetLastError();
     }
     if (h->hc.model_kind == MPPI_MODEL_AUV) MPPI_GEN_L(GEN_MODEL_AUV, 32);
@@ -176,7 +180,7 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
 const char *mppi_gen_kernel_name(const mppi_handle *h)
 {
     if (h->hc.model_kind == MPPI_MODEL_AUV) return "mppi::k_rollout_gen<0, 32>";
-    if (h->mlp_small == 32 && !h->mlp32_valu) return "mppi::k_rollout_nnauv32";
+    if (h->mlp_small == 32 && !h->mlp32_valu) return h->mlp_bx3 ? "mppi::k_rollout_nnauv32_bx3" : "mppi::k_rollout_nnauv32";
     return h->mlp_small == 16 ? "mppi::k_rollout_gen<1, 16>" : "mppi::k_rollout_gen<1, 32>";
 }
 

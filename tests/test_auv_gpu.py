@@ -302,8 +302,9 @@ def test_auv_sharded_equals_unsharded_and_normalize(m, G):
     assert np.abs(un - u_ref).max() / 200.0 < 1e-5
 
 
-@pytest.mark.parametrize("hid,n_hidden,tuning", [(32, 3, None), (32, 3, {"mlp32_valu": 1}), (16, 2, None), (32, 1, None), (32, 2, None)],
-                         ids=["32x3-mfma", "32x3-valu", "16x2", "32x1-mfma", "32x2-mfma"])
+@pytest.mark.parametrize("hid,n_hidden,tuning", [(32, 3, None), (32, 3, {"mlp32_valu": 1}), (16, 2, None), (32, 1, None), (32, 2, None),
+                                                 (32, 3, "bf16x3"), (32, 1, "bf16x3")],
+                         ids=["32x3-mfma", "32x3-valu", "16x2", "32x1-mfma", "32x2-mfma", "32x3-bf16x3", "32x1-bf16x3"])
 @pytest.mark.parametrize("cost", ["quadratic", "quat"])
 def test_nnauv_control_step_against_oracle(m, hid, n_hidden, tuning, cost):
     """The learned 13-state model in the full path: NNAUVModel (input 16, output 13) with the quadratic or the quaternion cost —
@@ -321,10 +322,12 @@ def test_nnauv_control_step_against_oracle(m, hid, n_hidden, tuning, cost):
         mlp["W"][-1] = (0.2 * mlp["W"][-1]).astype(F32)
         mlp["b"][-1] = (0.2 * mlp["b"][-1]).astype(F32)
     ck = dict(goal=GOAL13, Q=np.array([10.0] * 3 + [5.0] * 4 + [1.0] * 6)) if cost == "quadratic" else dict(goal=goal_q, Q=Q10 / 10, quat_cost=True)
-    cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv=mlp, seed=9, tuning=tuning, **ck)
+    bx3 = tuning == "bf16x3"  # MPPI_FLAG_MLP_BF16X3: k_rollout_nnauv32_bx3, held to the split-bf16 kernels' bars (8x the fp32 CPU's error, 2e-5)
+    fac, bar = (8, 2e-5) if bx3 else (4, 1e-5)
+    cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv=mlp, seed=9, tuning=None if bx3 else tuning, mlp_bf16x3=bx3, **ck)
     h = m.Handle(**cfg)
     # Dense(32): the matrix cores (k_rollout_nnauv32, the accumulators of one layer are the next layer's B operands) unless tuned onto the vector ALU
-    assert h.rollout_kernel_name() == ("mppi::k_rollout_nnauv32" if hid == 32 and not tuning else "mppi::k_rollout_gen<1, %d>" % hid)
+    assert h.rollout_kernel_name() == ("mppi::k_rollout_nnauv32_bx3" if bx3 else "mppi::k_rollout_nnauv32" if hid == 32 and not tuning else "mppi::k_rollout_gen<1, %d>" % hid)
     mk = lambda dt: orc.Problem(tau=H, s=13, a=6, lam=1.0, sigma=sigma, nnauv=mlp, threads=0, dtype=dt, **ck)
     p32, p64 = mk(F32), mk(np.float64)
     rng = np.random.default_rng(1)
@@ -339,8 +342,8 @@ def test_nnauv_control_step_against_oracle(m, hid, n_hidden, tuning, cost):
     rel = lambda a: float((np.abs(a - c64) / np.abs(c64)).max())
     eu, eu_cpu = float(np.abs(h.get_action_sequence() - U64).max()), float(np.abs(np.asarray(U32, np.float64) - U64).max())
     print("NNAUV %dx%d %s: rel cost err GPU %.3g / CPU %.3g; max|dU'| GPU %.3g / CPU %.3g" % (hid, n_hidden, cost, rel(c), rel(c32.astype(np.float64)), eu, eu_cpu))
-    assert rel(c) < 2e-5 and rel(c) < 4 * max(rel(c32.astype(np.float64)), 1e-6)
-    assert eu <= max(1e-5, 4 * eu_cpu)
+    assert rel(c) < 2e-5 and rel(c) < fac * max(rel(c32.astype(np.float64)), 1e-6)
+    assert eu <= max(bar, fac * eu_cpu)
     # fused Philox step on the exported noise + sharding
     U_in = h.get_action_sequence()
     u2 = h.next(x0)
@@ -349,7 +352,7 @@ def test_nnauv_control_step_against_oracle(m, hid, n_hidden, tuning, cost):
     _, U64b, c64b = p64.next_with_noise(x0, U_in, noise)
     _, U32b, _ = p32.next_with_noise(x0, U_in, noise)
     assert np.isfinite(c64b).all()
-    assert np.abs(h.get_action_sequence() - U64b).max() <= max(1e-5, 4 * np.abs(np.asarray(U32b, np.float64) - U64b).max())
+    assert np.abs(h.get_action_sequence() - U64b).max() <= max(bar, fac * np.abs(np.asarray(U32b, np.float64) - U64b).max())
     shards = 4
     hs = [m.Handle(shard_rank=g, shard_count=shards, **cfg) for g in range(shards)]
     xd = torch.tensor(x0, device="cuda")
