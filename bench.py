@@ -488,8 +488,7 @@ def main():
             "n_gpus": world, "steps": r["steps"], "warmup": args.warmup,
             "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "state_steps_per_s": r["rollouts_per_s"] * H,
-            "batches": {"n": len(b), "steps_each": r["steps"], "min_s": r4(min(b)), "median_s": r4(float(np.median(b))), "max_s": r4(max(b))},
+            "batches": {"n": len(b), "steps_each": r["steps"], "median_s": r4(float(np.median(b))), "max_s": r4(max(b))},
             "config": {"workload": "%s %s, K=%d H=%d per GPU (%s), on-device Philox noise, device-resident x/U"
                                    % (headline, ("learned %dx%d MLP model_base" % (net[1], net[0])) if is_mlp else "analytic model", K, H,
                                       ("BASELINE " + name) if name.startswith("configs") else name),
