@@ -2,6 +2,7 @@
 """The reference's Python entry point (scripts/main.py:13-121) against the MI355X control step:
    python examples/main.py --new --config examples/config/point_mass3d.yaml --task examples/config/static_task3d.yaml -s 200 -l --log_dir runs/a
    python examples/main.py --replay --log_dir runs/a/controller
+   python examples/main.py --new --config examples/config/uuv_sim.yaml --model examples/config/rexrov2.yaml --task examples/config/static_quat_task.yaml -s 50
 parses the same YAML keys, builds Simulation / PointMassModel / StaticCost / ControllerBase with the
 reference's constructor arguments, runs the closed loop, and writes the transition log as CSV.
 --new / --replay are the reference's mutually exclusive modes (main.py:17-24): with -l the run's config and task are
@@ -55,11 +56,55 @@ def get_cost(task_file, lam, gamma, upsilon, sigma):  # scripts/src/cost.py:51-6
     if task["type"] == "static":  # cost.py:7-11
         goal = np.asarray(task["goal"], np.float32).reshape(-1, 1)
         return m.StaticCost(lam, gamma, upsilon, sigma, goal, np.asarray(task["Q"], np.float32), diag=bool(task.get("diag", False)))
+    if task["type"] == "static_quat":  # cost.py:13-17: 13-state goal, Q over (position, attitude angle, velocities) = 10
+        goal = np.asarray(task["goal"], np.float32).reshape(-1, 1)
+        return m.StaticQuatCost(lam, gamma, upsilon, sigma, goal, np.asarray(task["Q"], np.float32), diag=bool(task.get("diag", False)))
     if task["type"] == "elipse":  # cost.py:21-30 — which hands task['center_y'] to center_x and vice versa; reproduced
         center_y, center_x = task["center_x"], task["center_y"]
         return m.ElipseCost(lam, gamma, upsilon, sigma, task["a"], task["b"], center_x, center_y, task["speed"],
                             task["m_state"], task["m_vel"])
-    raise NotImplementedError("cost types on the accelerated path: static, elipse (SURVEY §8f row 4: elipse3d / waypoints are not)")
+    if task["type"] == "elipse3d":
+        # cost.py:33-42 still calls ElipseCost3D with the 2-D class's argument list (a, b, centre, depth -10, speed, ...), which the class
+        # (elipse_cost.py:101-122: normal, aVec, axis, center, speed, v_speed, mState, mVel) no longer takes. Read as what it means:
+        # an ellipse with half-axes a, b in the horizontal plane at depth -10, or the class's own keys when the task file has them.
+        center_y, center_x = task["center_x"], task["center_y"]
+        return m.ElipseCost3D(lam, gamma, upsilon, sigma, np.asarray(task.get("normal", [0.0, 0.0, 1.0]), np.float32).reshape(3, 1),
+                              np.asarray(task.get("aVec", [1.0, 0.0, 0.0]), np.float32).reshape(3, 1),
+                              np.asarray(task.get("axis", [task["a"], task["b"]]), np.float32).reshape(2, 1),
+                              np.asarray(task.get("center", [center_x, center_y, task.get("depth", -10.0)]), np.float32).reshape(3, 1),
+                              task["speed"], task.get("v_speed", 0.0), task["m_state"], task["m_vel"])
+    raise NotImplementedError("cost types on the accelerated path: static, static_quat, elipse, elipse3d (waypoints: broken in the reference itself)")
+
+
+def get_model(model_dict, samples, dt, state_dim, action_dim, name="model"):  # scripts/src/model.py:52-66
+    kind = model_dict["type"]
+    if kind == "point_mass":
+        return m.PointMassModel(model_dict["mass"], dt, state_dim, action_dim)
+    if kind == "auv":  # model.py:41-49
+        return m.AUVModel(modelDict=model_dict, inertialFrameId=model_dict.get("frame_id", "world"), actionDim=action_dim, name=name, k=samples,
+                          dt=dt, parameters=model_dict)
+    raise NotImplementedError("model types of this entry point: point_mass, auv (auv_nn needs a Keras weight file: build NNAUVModel from "
+                              "LearnerBase-trained weights instead, tests/test_learner_gpu.py)")
+
+
+class AUVSimulation:
+    """Host-loop plant for the 13-state family: the Fossen model itself, one device step per control step (the reference drives
+    uuv_simulator over ROS, which is not part of this build). Same getState / step / getTime surface as Simulation."""
+
+    def __init__(self, model, x0=None, dt=0.1):
+        self.model, self.dt, self.time = model, float(dt), 0.0
+        self.x = np.asarray(x0 if x0 is not None else [0, 0, 0, 0, 0, 0, 1] + [0] * 6, np.float32).reshape(13, 1)
+
+    def getTime(self):
+        return self.time
+
+    def getState(self):
+        return self.x.copy()
+
+    def step(self, u, goal=None):
+        self.x = np.asarray(self.model.predict(self.x[None], np.asarray(u, np.float32).reshape(1, -1, 1)), np.float32).reshape(13, 1)
+        self.time += self.dt
+        return self.getState()
 
 
 def main():
@@ -71,6 +116,8 @@ def main():
                                                 "--new -l: where <log_dir>/controller/ is created")
     ap.add_argument("--config", type=str)
     ap.add_argument("--task", type=str)
+    ap.add_argument("--model", type=str, default=None, help="model description file (config/models/*.yaml: type point_mass | auv); "
+                                                              "default: the point mass of --config")
     ap.add_argument("-l", "--log", action="store_true", help="leave config.yaml / task.yaml (and the CSV) in the log dir")
     ap.add_argument("-s", "--steps", type=int, default=200)
     ap.add_argument("--csv", type=str, default=None, help="write the (x, u, x_next) log here (DataBase::toCSV's bytes)")
@@ -89,9 +136,15 @@ def main():
         logdir = write_log_dir(args.log_dir, conf, parse_config(args.task))
         if args.csv is None:
             args.csv = os.path.join(logdir, "transitions.csv")
-    s_dim, a_dim = conf["state-dim"], conf["action-dim"]
-    sim = Simulation(conf.get("env"), s_dim, a_dim, None, False, dt=conf["dt"], mass=conf.get("mass", 1.0))
-    model = m.PointMassModel(conf.get("mass", 1.0), conf["dt"], s_dim, a_dim)
+    model_dict = parse_config(args.model) if args.model else conf.get("model") or {"type": "point_mass", "mass": conf.get("mass", 1.0)}
+    if args.log and args.model:
+        conf = dict(conf, model=model_dict)  # a replay finds the model in the dumped config
+        write_log_dir(args.log_dir, conf, parse_config(args.task))
+    auv = model_dict["type"] == "auv"
+    s_dim, a_dim = conf.get("state-dim", 13 if auv else None), conf.get("action-dim", 6 if auv else None)
+    model = get_model(model_dict, conf["samples"], conf["dt"], s_dim, a_dim)
+    sim = AUVSimulation(model, conf.get("x0"), conf["dt"]) if auv else Simulation(conf.get("env"), s_dim, a_dim, None, False, dt=conf["dt"],
+                                                                                  mass=model_dict.get("mass", 1.0))
     cost = get_cost(args.task, conf["lambda"], conf.get("gamma", 1.0), conf.get("upsilon", 1.0), conf["noise"])
     cont = m.ControllerBase(model, cost, k=conf["samples"], tau=conf["horizon"], sDim=s_dim, aDim=a_dim,
                             lam=conf["lambda"], upsilon=conf.get("upsilon", 1.0), sigma=np.asarray(conf["noise"], np.float32))
@@ -104,8 +157,14 @@ def main():
         x_next = sim.step(u)
         cont.save(x, u, x_next)
     steady = np.sort(ts[min(5, len(ts) - 1):])  # the first calls load the code objects
-    if hasattr(cost, "getGoal"):
-        tail = "|x - goal| = %.4f" % float(np.linalg.norm(sim.getState().ravel() - cost.getGoal().ravel()))
+    goal_of = getattr(cost, "getGoal", None) or getattr(cost, "get_goal", None)
+    if goal_of is not None and auv:  # StaticCost on 13 states / StaticQuatCost: distance in position
+        tail = "|p - goal_p| = %.4f m" % float(np.linalg.norm(sim.getState().ravel()[:3] - np.asarray(goal_of()).ravel()[:3]))
+    elif goal_of is not None:
+        tail = "|x - goal| = %.4f" % float(np.linalg.norm(sim.getState().ravel() - np.asarray(goal_of()).ravel()))
+    elif hasattr(cost, "position_error"):  # ElipseCost3D
+        st = sim.getState()[None]
+        tail = "elipse3d state cost %.4f, speed %.3f m/s" % (float(np.ravel(cost.state_cost("s", st))[0]), float(np.linalg.norm(st[0, 7:10, 0])))
     else:
         d = cost.dist(sim.getState())
         tail = "elipse x_dist = %.4f v_dist = %.4f" % (float(d["x_dist"]), float(d["v_dist"]))
