@@ -7,6 +7,8 @@ compiled without FMA contraction; the host constants come from the same double G
 3D-ellipse costs within 2e-6 relative (device acosf vs libm); learned-model rollouts as the other MLP kernels (costs within
 4x the fp32 CPU's own error against fp64). Control updates: |dU'| <= 1e-5 x the noise scale (north_star's 1e-5 for unit noise).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,7 @@ from conftest import load_golden
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F32 = np.float32
 CLOSE = dict(rtol=1e-6, atol=1e-6)
 
