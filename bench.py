@@ -45,7 +45,8 @@ VALU_F32_PEAK_TFLOPS = 157.3              # 256 CUs x 4 SIMDs x 64 FLOP/clk (v_p
 GOALS = {1: [1.0, 0.0], 2: [1.0, 0.0, 0.0, 0.0], 3: [1.0, 0.0, 0.5, 0.0, 0.75, 0.0]}  # MuJoCo target sites
 # workload -> (a_dim, learned model: None | (hidden width, hidden layers))
 WORKLOADS = {"pm1d": (1, None), "pm2d": (2, None), "pm3d": (3, None), "mlp": (3, (256, 2)), "mlp32": (3, (32, 3)),
-             "auv": (6, None), "nnauv": (6, (32, 3))}
+             "auv": (6, None), "nnauv": (6, (32, 3)), "nnspeed": (6, (16, 3))}  # nnspeed: NNAUVModelSpeed, Dense(16)x3 + Dense(6)
+GEN = ("auv", "nnauv", "nnspeed")
 CONFIG_NAME = {("pm1d", 128, 32, 1): "configs[0]", ("pm2d", 4096, 64, 1): "configs[1]", ("pm3d", 65536, 64, 1): "configs[2]",
                ("mlp", 65536, 64, 1): "configs[3]", ("mlp", 65536, 128, 8): "configs[4]"}
 
@@ -89,9 +90,9 @@ def self_launch(args):
 def cfg_of(workload, H):
     import numpy as np
     a = WORKLOADS[workload][0]
-    if workload in ("auv", "nnauv"):  # the reference's AUV task: 13-state quaternion pose, 6 thrusts (config/tasks/static_cost_auv.yaml)
+    if workload in GEN:  # the reference's AUV task: 13-state quaternion pose, 6 thrusts (config/tasks/static_cost_auv.yaml)
         from mppi_tf_amd.auv import auv_task
-        return auv_task(H, learned=(workload == "nnauv"))
+        return auv_task(H, learned=(workload != "auv"))
     return dict(tau=H, s_dim=2 * a, a_dim=a, dt=0.1, mass=1.0, lam=1.0, sigma=(0.25 * np.eye(a)).astype(np.float32),
                 goal=GOALS[a], seed=1)
 
@@ -137,26 +138,32 @@ def trained_nnauv():
     return _trained["nnauv"]
 
 
+def model_kw_of(workload, mlp):
+    return {"nnauv": dict(nnauv=mlp), "nnspeed": dict(nnauv_speed=mlp)}.get(workload, dict(mlp=mlp))
+
+
 def mlp_of(workload):
     a, net = WORKLOADS[workload]
     if net is None:
         return None
     if workload == "nnauv":  # NNAUVModel: input = state without the position + action (nn_model.py:289-293), output = 13
         return trained_nnauv()[0]
+    if workload == "nnspeed":  # NNAUVModelSpeed: 15 inputs (Euler angles, velocities, forces), 6 outputs; synthetic weights (SURVEY §8d recipe)
+        return synthetic_mlp(15, 6, 0, *net)
     return synthetic_mlp(3 * a, 2 * a, 0, *net)
 
 
 def work_per_state_step(workload):
     """algorithmic work of one (k, t) pair: (bytes, flop)"""
     a, net = WORKLOADS[workload]
-    s = 13 if workload in ("auv", "nnauv") else 2 * a
+    s = 13 if workload in GEN else 2 * a
     flop = 6 * s + 5 * a + 3
     if workload == "auv":
         flop = 2 * 330 + 40 + 5 * a + 3  # two state_dot evaluations (rk2) of the Fossen model + quaternion normalisation + costs
     if net:
         hid, n_hidden = net
-        n_in = 16 if workload == "nnauv" else s + a
-        flop += 2 * (n_in * hid + (n_hidden - 1) * hid * hid + hid * s)
+        n_in, n_out = {"nnauv": (16, s), "nnspeed": (15, 6)}.get(workload, (s + a, s))
+        flop += 2 * (n_in * hid + (n_hidden - 1) * hid * hid + hid * n_out) + (120 if workload == "nnspeed" else 0)  # + Euler angles, quaternion kinematics
     return 12 * a, flop  # bytes: the noise written once and read twice, fp32
 
 
@@ -191,9 +198,9 @@ def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20):
     import numpy as np
     a = WORKLOADS[workload][0]
     cfg = cfg_of(workload, H)
-    gen = workload in ("auv", "nnauv")  # 13-state family: the state is held at the task's x0 (no host plant for the Fossen model here)
+    gen = workload in GEN  # 13-state family: the state is held at the task's x0 (no host plant for the Fossen model here)
     x = np.asarray(cfg.pop("x0"), np.float32) if gen else np.zeros(2 * a, np.float32)
-    h = m.Handle(k=K, **(dict(nnauv=mlp) if workload == "nnauv" else dict(mlp=mlp)), **cfg)
+    h = m.Handle(k=K, **model_kw_of(workload, mlp), **cfg)
     if mlp is not None or gen:
         steps, warmup = 20, 3
     dt, ts = 0.1, []
@@ -271,7 +278,7 @@ class Runner:
         x = torch.zeros(cfg["s_dim"], dtype=torch.float32, device=self.dev)
         if "x0" in cfg:
             x = torch.tensor(cfg.pop("x0"), dtype=torch.float32, device=self.dev)
-        model_kw = dict(nnauv=mlp) if workload == "nnauv" else dict(mlp=mlp)
+        model_kw = model_kw_of(workload, mlp)
         ctl = ShardedController(device_index=self.local_rank, k=K * self.world, exchange=os.environ.get("MPPI_EXCHANGE", "auto"),
                                 p2p_timeout_ms=1000, **model_kw, **cfg, **handle_kw)
         assert ctl.backend.h.k_local == K
@@ -512,7 +519,7 @@ def main():
         if world == 1:
             med, p95 = sync_latency(m, headline, H, K, r["mlp"])
             out["ms_per_control_step_sync"] = {"median": r4(med), "p95": r4(p95)}
-            if not args.no_cpu_baseline and headline not in ("auv", "nnauv"):
+            if not args.no_cpu_baseline and headline not in GEN:
                 out["cpu_baseline"] = cpu_baseline(headline, H, K, r["mlp"])
         line = json.dumps(out)
         sys.stdout.flush()

@@ -53,8 +53,11 @@ typedef enum {
 enum { MPPI_MODEL_POINT_MASS = 0, /* x' = A x + (B/m) v, src/model_base.cpp:53-82 */
        MPPI_MODEL_MLP = 1,        /* x' = x + denorm(MLP(norm([x;v]))), nn_model.py:215-304 convention, point-mass state (s = 2a) */
        MPPI_MODEL_AUV = 2,        /* Fossen 6-DOF AUVModel, s = 13 (pos, quat xyzw, lin vel, ang vel), a = 6: models/auv_model.py:282-562 */
-       MPPI_MODEL_NN_AUV = 3 };   /* NNAUVModel: x' = x + denorm(nn(norm(concat(x[3:], u)))), s = 13, a = 6, nn input s+a-3 = 16,
+       MPPI_MODEL_NN_AUV = 3,     /* NNAUVModel: x' = x + denorm(nn(norm(concat(x[3:], u)))), s = 13, a = 6, nn input s+a-3 = 16,
                                      Dense(16|32, relu) x 1..3 + Dense(13): models/nn_model.py:179-304 */
+       MPPI_MODEL_NN_AUV_SPEED = 4 }; /* NNAUVModelSpeed: the network predicts the velocity delta from (Euler angles, velocities,
+                                     forces) = 15 inputs, Dense(16|32, relu) x 1..3 + Dense(6); the pose is integrated with the
+                                     quaternion kinematics over cfg.dt and renormalised: models/nn_model.py:307-588 */
 
 enum { MPPI_ACTION_COST_CPP = 0,  /* λ uᵀΣ⁻¹ε                          src/cost_base.cpp:63-68   */
        MPPI_ACTION_COST_PY = 1 }; /* ½[γ(uᵀΣ⁻¹u+2uᵀΣ⁻¹ε)+λ(1-1/υ)εᵀΣ⁻¹ε]  costs/cost_base.py:114-170 */

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MPPI_SO_PATH") or os.path.join(HERE, "libmppi_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_SINGULAR_SIGMA, ERR_ALLOC, ERR_IO, ERR_EXCHANGE = range(9)
-MODEL_POINT_MASS, MODEL_MLP, MODEL_AUV, MODEL_NN_AUV = 0, 1, 2, 3
+MODEL_POINT_MASS, MODEL_MLP, MODEL_AUV, MODEL_NN_AUV, MODEL_NN_AUV_SPEED = 0, 1, 2, 3, 4
 STATE_COST_QUADRATIC, STATE_COST_ELLIPSE, STATE_COST_QUAT, STATE_COST_ELLIPSE3D = 0, 1, 2, 3
 ACTION_COST_CPP, ACTION_COST_PY = 0, 1
 DBG_COSTS, DBG_BETA, DBG_ETA, DBG_WEIGHTS, DBG_NOISE, DBG_U_UPDATED = range(6)
@@ -163,7 +163,7 @@ class Handle:
                  sigma=None, goal=None, Q=None, q_is_full=None, action_cost=ACTION_COST_CPP,
                  normalize_cost=False, seed=1, device=0, shard_rank=0, shard_count=1, mlp=None,
                  upsilon_scales_noise=False, mlp_bf16x3=False, tuning=None, log_rows=0, ellipse=None,
-                 auv=None, nnauv=None, quat_cost=False, ellipse3d=None):
+                 auv=None, nnauv=None, quat_cost=False, ellipse3d=None, nnauv_speed=None):
         """mlp: dict(W=[W1,W2,W3], b=[b1,b2,b3], xmean=, xstd=, ymean=, ystd=) selects the learned
         model_base (Dense(256,relu) x2 + Dense(s_dim); Keras [in x out] kernels).
         tuning: dict of diagnostic switches (keys of TUNING) applied with mppi_set_tuning right after creation.
@@ -171,6 +171,7 @@ class Handle:
         auv: the reference's AUVModel `parameters` dict (auv_model.py:85-245: mass, volume, density, cog, cob, Ma, linear_damping,
         quad_damping, linear_damping_forward_speed, inertial{ixx..iyz}, rk) selects the Fossen model (s_dim 13, a_dim 6);
         nnauv: an mlp dict whose first kernel has s+a-3 = 16 rows selects NNAUVModel (nn_model.py:179-304);
+        nnauv_speed: an mlp dict with 15 input rows (Euler angles, velocities, forces) and 6 outputs selects NNAUVModelSpeed (nn_model.py:307-588);
         quat_cost: StaticQuatCost (static_cost.py:73-159) with goal [13] and Q [10,10] (or its 10 diagonal entries);
         ellipse3d: dict(normal, aVec, axis, speed, m_state, m_vel) selects ElipseCost3D (elipse_cost.py:101-246)."""
         lib = self.lib = load()
@@ -218,6 +219,8 @@ class Handle:
             cfg.state_cost_kind, cfg.ellipse3d = STATE_COST_ELLIPSE3D, fp(keep[-1])
         if nnauv is not None:
             mlp = nnauv
+        if nnauv_speed is not None:
+            mlp = nnauv_speed
         if sigma is not None:
             keep.append(f32(sigma, (a_dim, a_dim)))
             cfg.sigma = fp(keep[-1])
@@ -240,13 +243,15 @@ class Handle:
             Wp = (FP * len(Ws))(*[fp(w) for w in Ws])
             bp = (FP * len(bs))(*[fp(b) for b in bs])
             desc.widths, desc.W, desc.b = widths, Wp, bp
-            n_in = s_dim + a_dim - (3 if nnauv is not None else 0)
-            for name, n in (("xmean", n_in), ("xstd", n_in), ("ymean", s_dim), ("ystd", s_dim)):
+            n_in = 15 if nnauv_speed is not None else s_dim + a_dim - (3 if nnauv is not None else 0)
+            n_out = 6 if nnauv_speed is not None else s_dim
+            for name, n in (("xmean", n_in), ("xstd", n_in), ("ymean", n_out), ("ystd", n_out)):
                 if mlp.get(name) is not None:
                     keep.append(f32(mlp[name], (n,)))
                     setattr(desc, name, fp(keep[-1]))
             keep += [desc, widths, Wp, bp]
-            cfg.model_kind, cfg.mlp = (MODEL_NN_AUV if nnauv is not None else MODEL_MLP), C.pointer(desc)
+            cfg.model_kind = MODEL_NN_AUV_SPEED if nnauv_speed is not None else (MODEL_NN_AUV if nnauv is not None else MODEL_MLP)
+            cfg.mlp = C.pointer(desc)
         self.h = _H()
         self.k, self.tau, self.s, self.a = k, tau, s_dim, a_dim
         st = lib.mppi_create(C.byref(cfg), C.byref(self.h))

@@ -212,6 +212,87 @@ class NNAUVModel:
         return np.asarray(state) + np.asarray(delta)
 
 
+def euler_from_quaternion(q):
+    """tensorflow_graphics.geometry.transformation.euler.from_quaternion (what NNAUVModelSpeed.to_euler calls, nn_model.py:566-588), numpy,
+    float64: [k,4] (x, y, z, w) -> [k,3] (theta_x, theta_y, theta_z), R = Rz Ry Rx. Host bookkeeping (training data); the device
+    kernels carry their own fp32 form."""
+    q = np.asarray(q, np.float64).reshape(-1, 4)
+    eps = 2.0 * np.finfo(np.float64).eps
+    shr = 1.0 - 4.0 * eps
+    x, y, z, w = q.T
+    tx, ty, tz = 2 * x * shr, 2 * y * shr, 2 * z * shr
+    twx, twy, twz, txx, txy, txz, tyy, tyz, tzz = tx * w, ty * w, tz * w, tx * x, ty * x, tz * x, ty * y, tz * y, tz * z
+    r00, r10, r21, r22 = (1 - (tyy + tzz)) * shr, (txy + twz) * shr, (tyz + twx) * shr, (1 - (txx + tyy)) * shr
+    r20, r01, r02 = (txz - twy) * shr, (txy - twz) * shr, (txz + twy) * shr
+    sgn = lambda v: np.where(v >= 0, 1.0, -1.0)
+    th_y = -np.arcsin(r20)
+    sc = sgn(np.cos(th_y))
+    r00g, r22g = sgn(r00) * eps + r00, sgn(r22) * eps + r22
+    general = np.stack([np.arctan2(r21 * sc, r22g * sc), th_y, np.arctan2(r10 * sc, r00g * sc)], axis=-1)
+    s20 = sgn(r20)
+    lock = np.stack([np.arctan2(-s20 * r01, -s20 * (sgn(r02) * eps + r02)), -s20 * (np.pi / 2), np.zeros_like(r20)], axis=-1)
+    return np.where((np.abs(np.abs(r20) - 1.0) < 1e-6)[:, None], lock, general)
+
+
+class NNAUVModelSpeed(NNAUVModel):
+    """nn_model.py:307-588: the network — Dense(16, relu) x 3 + Dense(6) on 15 inputs (3 Euler angles, 6 velocities, 6 forces) — predicts
+    the velocity delta; the pose is integrated with the quaternion kinematics over dt and renormalised."""
+
+    def __init__(self, modelDict=None, inertialFrameId="world", k=1, stateDim=13, actionDim=6, mask=None, name="auv_nn_model",
+                 weightFile=None, weights=None, dt=0.1, device=0):
+        if weights is None:  # the reference's architecture (nn_model.py:340-346) with Keras' default glorot-uniform kernels, zero biases
+            rng = np.random.default_rng(0)
+            dims = [stateDim + actionDim - 3 - 1, 16, 16, 16, 6]
+            lim = [np.sqrt(6.0 / (dims[i] + dims[i + 1])) for i in range(4)]
+            weights = dict(W=[rng.uniform(-lim[i], lim[i], (dims[i], dims[i + 1])).astype(np.float32) for i in range(4)],
+                           b=[np.zeros(dims[i + 1], np.float32) for i in range(4)])
+        NNAUVModel.__init__(self, modelDict, inertialFrameId, k, stateDim, actionDim, mask, name, weightFile, weights, dt, device)
+        n_in = stateDim + actionDim - 3 - 1  # position dropped, quaternion -> Euler angles (nn_model.py:348-352)
+        self.Xmean, self.Xstd = np.zeros(n_in), np.ones(n_in)
+        self.Ymean, self.Ystd = np.zeros(6), np.ones(6)
+
+    def handle_kw(self):
+        """the Handle keyword ControllerBase passes on"""
+        return dict(nnauv_speed=self.mlp())
+
+    def _handle(self):
+        if self._h is None:
+            self._h = Handle(k=1, tau=1, s_dim=S_DIM, a_dim=A_DIM, dt=self._dt, sigma=np.eye(A_DIM), goal=np.zeros(S_DIM), device=self._device,
+                             **self.handle_kw())
+        return self._h
+
+    def to_euler(self, stateQ):  # :566-588 [k,13,1] -> [k,12,1]
+        st = np.asarray(stateQ, np.float64)
+        return np.concatenate([st[:, 0:3], euler_from_quaternion(st[:, 3:7, 0])[..., None], st[:, 7:]], axis=1)
+
+    def prepare_data(self, state, action):  # :438-461 -> [k,15]
+        X = np.concatenate([self.to_euler(state)[:, 3:], np.asarray(action, np.float64)], axis=1)[..., 0]
+        return (X - self.Xmean) / self.Xstd
+
+    def prepare_training_data(self, stateT, stateT1, action, norm=True):  # :382-436 -> X [k,15], Y [k,6] (velocity delta)
+        stateT, stateT1, action = (np.asarray(v, np.float64) for v in (stateT, stateT1, action))
+        X = np.concatenate([self.to_euler(stateT)[:, 3:], action], axis=1)[..., 0]
+        Y = (stateT1 - stateT)[:, 7:, 0]
+        if norm:
+            X, Y = (X - self.Xmean) / self.Xstd, (Y - self.Ymean) / self.Ystd
+        return X, Y
+
+    def next_state(self, state, delta):  # :463-472, on the device: the step with a zero network output would need the weights; host form
+        st = np.asarray(state, np.float64)
+        out = st.copy()
+        for i in range(st.shape[0]):
+            x, y, z, w = st[i, 3:7, 0]
+            rot = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                            [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                            [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            T = 0.5 * np.array([[-x, -y, -z], [w, -z, y], [z, w, -x], [-y, x, w]])  # this class's row order (:545-555)
+            pose = st[i, 0:7, 0] + np.concatenate([rot @ st[i, 7:10, 0], T @ st[i, 10:13, 0]]) * self._dt
+            pose[3:7] /= np.sqrt(max(float(pose[3:7] @ pose[3:7]), 1e-12))
+            out[i, 0:7, 0] = pose
+            out[i, 7:13, 0] = st[i, 7:13, 0] + np.asarray(delta, np.float64)[i].reshape(6)
+        return out
+
+
 class StaticQuatCost(CostBase):
     """static_cost.py:73-159: goal [13,1], Q [10,10] (or its diagonal with diag=True)."""
 

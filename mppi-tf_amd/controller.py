@@ -230,7 +230,9 @@ class ControllerBase:
         self._sigma = sigma
         # the model_base slot: the point-mass model (dt, mass), or a 13-state model that brings its own description
         model_kw = {}
-        if hasattr(model, "handle_parameters"):   # AUVModel (auv.py)
+        if hasattr(model, "handle_kw"):           # NNAUVModelSpeed (auv.py): brings its own Handle keyword
+            model_kw = model.handle_kw()
+        elif hasattr(model, "handle_parameters"):   # AUVModel (auv.py)
             model_kw = dict(auv=model.handle_parameters())
         elif hasattr(model, "mlp"):               # NNAUVModel (auv.py)
             model_kw = dict(nnauv=model.mlp())

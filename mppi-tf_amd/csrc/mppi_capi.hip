@@ -165,22 +165,25 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     if (cfg->shard_count < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_count)
         return fail(nullptr, MPPI_ERR_INVALID_ARG, "bad shard_rank/shard_count");
     if (cfg->model_kind == MPPI_MODEL_POINT_MASS && !(cfg->mass != 0.0f)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "mass must be non-zero");
-    if (cfg->model_kind < MPPI_MODEL_POINT_MASS || cfg->model_kind > MPPI_MODEL_NN_AUV)
+    if (cfg->model_kind < MPPI_MODEL_POINT_MASS || cfg->model_kind > MPPI_MODEL_NN_AUV_SPEED)
         return fail(nullptr, MPPI_ERR_INVALID_ARG, "unknown model kind");
     if (cfg->state_cost_kind < MPPI_STATE_COST_QUADRATIC || cfg->state_cost_kind > MPPI_STATE_COST_ELLIPSE3D)
         return fail(nullptr, MPPI_ERR_INVALID_ARG, "unknown state cost kind");
     // the 13-state AUV family (mppi_gen.hip.h): pose with a quaternion + body velocities, 6 generalised forces
-    const bool gen = cfg->model_kind == MPPI_MODEL_AUV || cfg->model_kind == MPPI_MODEL_NN_AUV;
+    const bool nn_speed = cfg->model_kind == MPPI_MODEL_NN_AUV_SPEED;
+    const bool gen = cfg->model_kind == MPPI_MODEL_AUV || cfg->model_kind == MPPI_MODEL_NN_AUV || nn_speed;
     const bool cost13 = cfg->state_cost_kind == MPPI_STATE_COST_QUAT || cfg->state_cost_kind == MPPI_STATE_COST_ELLIPSE3D;
     if (gen && (s != 13 || a != 6)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "AUVModel / NNAUVModel: s_dim = 13 (pos, quat, lin vel, ang vel), a_dim = 6");
     if (cost13 && s != 13) return fail(nullptr, MPPI_ERR_INVALID_ARG, "StaticQuatCost / ElipseCost3D read a 13-state (static_cost.py:141-159, elipse_cost.py:124-139)");
     if (cost13 && !gen && cfg->k * (long long)cfg->tau > 1) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "StaticQuatCost / ElipseCost3D rollouts need a 13-state model (MPPI_MODEL_AUV / MPPI_MODEL_NN_AUV)");
-    if (cfg->model_kind == MPPI_MODEL_NN_AUV) {
+    if (cfg->model_kind == MPPI_MODEL_NN_AUV || nn_speed) {
         const mppi_mlp_desc *d = cfg->mlp;
         if (!d || !d->widths || !d->W || !d->b) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NNAUVModel needs cfg.mlp with widths, W, b");
         if (d->n_layers < 2 || d->n_layers > kMlpSmallMaxLayers) return fail(nullptr, MPPI_ERR_UNSUPPORTED, "NNAUVModel: 2 to 4 Dense layers (1 to 3 hidden + the output layer)");
         for (int l = 0; l < d->n_layers; ++l) if (!d->W[l] || !d->b[l]) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NULL MLP weight pointer");
-        if (d->widths[d->n_layers - 1] != 13) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NNAUVModel: the last layer's width must be 13 (nn_model.py:59)");
+        if (!nn_speed && d->widths[d->n_layers - 1] != 13) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NNAUVModel: the last layer's width must be 13 (nn_model.py:59)");
+        if (nn_speed && d->widths[d->n_layers - 1] != 6) return fail(nullptr, MPPI_ERR_INVALID_ARG, "NNAUVModelSpeed: the last layer's width must be 6, the velocity delta (nn_model.py:345)");
+        if (nn_speed && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) return fail(nullptr, MPPI_ERR_INVALID_ARG, "MPPI_FLAG_MLP_BF16X3: no split-bf16 kernel for NNAUVModelSpeed");
         const int hid = d->widths[0];
         bool same = hid == 16 || hid == 32;
         for (int l = 0; l + 1 < d->n_layers; ++l) same = same && d->widths[l] == hid;
@@ -287,7 +290,8 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     else if (tile_lds_floats(h->HA, R) * 4 > lds_cap) h->no_rollout = "tau*a_dim too large: the 16-rollout LDS tile exceeds 160 KiB";
     h->R = R; h->nb = (h->K_local + R - 1) / R; h->tile_lds = tile_lds_floats(h->HA, R) * 4;
     h->mlp_bx3 = ((cfg->model_kind == MPPI_MODEL_MLP || cfg->model_kind == MPPI_MODEL_NN_AUV) && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) ? 1 : 0;
-    h->mlp_small = ((cfg->model_kind == MPPI_MODEL_MLP && cfg->mlp->widths[0] != kHid) || cfg->model_kind == MPPI_MODEL_NN_AUV) ? cfg->mlp->widths[0] : 0;
+    h->mlp_small = ((cfg->model_kind == MPPI_MODEL_MLP && cfg->mlp->widths[0] != kHid) || cfg->model_kind == MPPI_MODEL_NN_AUV ||
+                    cfg->model_kind == MPPI_MODEL_NN_AUV_SPEED) ? cfg->mlp->widths[0] : 0;
     h->is_gen = gen ? 1 : 0;
     h->mlp_v2 = (cfg->model_kind == MPPI_MODEL_MLP && !h->mlp_small && !h->mlp_bx3 && a <= 3) ? 1 : 0; // a_dim = 4: two h1 images + the rest exceed 160 KiB of LDS
     h->nb_mlp = cfg->model_kind == MPPI_MODEL_MLP ? (h->mlp_v2 ? (h->K_local + kMlp2R - 1) / kMlp2R : (h->K_local + kMlpR - 1) / kMlpR) : 0;
@@ -314,10 +318,12 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         const int nrec2 = (nrec + kGroup - 1) / kGroup, nrec3 = (nrec2 + kGroup - 1) / kGroup;
         HIP_TRY(h, hipMalloc((void **)&h->d_part2, sizeof(float) * (size_t)nrec2 * (2 + h->HA)));
         HIP_TRY(h, hipMalloc((void **)&h->d_part3, sizeof(float) * (size_t)nrec3 * (2 + h->HA)));
-        if (cfg->model_kind == MPPI_MODEL_MLP || cfg->model_kind == MPPI_MODEL_NN_AUV) {
+        if (cfg->model_kind == MPPI_MODEL_MLP || cfg->model_kind == MPPI_MODEL_NN_AUV || cfg->model_kind == MPPI_MODEL_NN_AUV_SPEED) {
             const mppi_mlp_desc *d = cfg->mlp;
-            const bool nnauv = cfg->model_kind == MPPI_MODEL_NN_AUV;
-            const int nin = nnauv ? s + a - 3 : s + a; // NNAUVModel.prepare_data drops the position (nn_model.py:289-293)
+            const bool speed = cfg->model_kind == MPPI_MODEL_NN_AUV_SPEED;
+            const bool nnauv = cfg->model_kind == MPPI_MODEL_NN_AUV || speed;
+            // NNAUVModel.prepare_data drops the position (nn_model.py:289-293); NNAUVModelSpeed's takes Euler angles, velocities, forces (:438-461)
+            const int nin = speed ? 15 : (nnauv ? s + a - 3 : s + a), nout = speed ? 6 : s;
             size_t total = 0;
             for (int l = 0, w_in = nin; l < d->n_layers; w_in = d->widths[l], ++l) total += (size_t)(w_in + 1) * (d->widths[l] + 1);
             HIP_TRY(h, hipMalloc((void **)&h->d_mlp_w, sizeof(float) * total));
@@ -349,8 +355,9 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
                 h->hm.W1 = h->hm.Wl[0]; h->hm.b1 = h->hm.bl[0]; h->hm.W2 = h->hm.Wl[1]; h->hm.b2 = h->hm.bl[1];
                 h->hm.W3 = h->hm.Wl[2]; h->hm.b3 = h->hm.bl[2];
             }
+            for (int i = 0; i < kMaxS + kMaxA; ++i) { h->hm.xmean[i] = 0.f; h->hm.xstd[i] = 1.f; }
             for (int i = 0; i < nin; ++i) { h->hm.xmean[i] = d->xmean ? d->xmean[i] : 0.f; h->hm.xstd[i] = d->xstd ? d->xstd[i] : 1.f; }
-            for (int i = 0; i < s; ++i) { h->hm.ymean[i] = d->ymean ? d->ymean[i] : 0.f; h->hm.ystd[i] = d->ystd ? d->ystd[i] : 1.f; }
+            for (int i = 0; i < nout; ++i) { h->hm.ymean[i] = d->ymean ? d->ymean[i] : 0.f; h->hm.ystd[i] = d->ystd ? d->ystd[i] : 1.f; }
             HIP_TRY(h, hipMemcpyAsync(h->dM, &h->hm, sizeof(MlpDev), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
         }

@@ -2,6 +2,8 @@
 // (SURVEY §8f row 4), as lane-per-rollout device code for gfx950:
 //   models  AUVModel   (Fossen 6-DOF rigid body, quaternion attitude, rk1/rk2/"rk4")   models/auv_model.py:282-562
 //           NNAUVModel (x' = x + denorm(nn(norm(concat(x[3:], u)))), Dense(16|32)x1..3)  models/nn_model.py:215-304
+//           NNAUVModelSpeed (the network predicts the velocity delta from Euler angles, velocities, forces;
+//                       the pose is integrated with the quaternion kinematics)           models/nn_model.py:307-588
 //   costs   StaticCost     (x-g)^T Q (x-g), s = 13                                     costs/static_cost.py:40-63
 //           StaticQuatCost d = (dp, 2 acos<q, g_q>, dv), d^T Q10 d                     costs/static_cost.py:73-159
 //           ElipseCost3D   plane-frame pose, |sum (p/axis)^2 - 1| + tangent angle + | |v|^2 - speed^2 |   costs/elipse_cost.py:101-246
@@ -21,7 +23,8 @@ namespace mppi {
 constexpr int kGenS = 13, kGenA = 6;
 constexpr int kGenNin = kGenS + kGenA - 3; // NNAUVModel's input: the state without the position, then the action
 
-enum GenModel { GEN_MODEL_AUV = 0, GEN_MODEL_NNAUV = 1 };
+enum GenModel { GEN_MODEL_AUV = 0, GEN_MODEL_NNAUV = 1, GEN_MODEL_NNAUV_SPEED = 2 };
+constexpr int kGenSpeedNin = 15; // NNAUVModelSpeed: 3 Euler angles, 6 velocities, 6 forces
 
 // Device-resident constants of the 13-state family (beside DevConsts, which keeps lambda, Sigma, goal, Q, seed ...).
 struct GenConsts {
@@ -442,6 +445,99 @@ __device__ __forceinline__ void nnauv_step(const MlpDev *__restrict__ M, const f
     }
 }
 
+// ---------------------------------------------------------------------------------------- NNAUVModelSpeed
+// tensorflow_graphics euler.from_quaternion as NNAUVModelSpeed.to_euler calls it (nn_model.py:566-588): (x, y, z, w) -> (theta_x, theta_y,
+// theta_z), R = Rz Ry Rx; entries "safe-shrunk" by (1 - 4 eps), the gimbal-lock branch for | |r20| - 1 | < 1e-6 (the tests pin the
+// CPU restatement of the same algorithm against scipy's as_euler('xyz')). asinf / atan2f are the device library's.
+__device__ __forceinline__ float nonzero_sign(float v) { return v >= 0.0f ? 1.0f : -1.0f; }
+__device__ __forceinline__ void euler_from_quat(const float (&q)[4], float (&e)[3])
+{
+    constexpr float eps = 2.0f * 1.1920928955078125e-07f, shr = 1.0f - 4.0f * eps;
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float tx = (2.0f * x) * shr, ty = (2.0f * y) * shr, tz = (2.0f * z) * shr;
+    const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    float r00 = (1.0f - (tyy + tzz)) * shr;
+    const float r10 = (txy + twz) * shr, r21 = (tyz + twx) * shr;
+    float r22 = (1.0f - (txx + tyy)) * shr;
+    const float r20 = (txz - twy) * shr, r01 = (txy - twz) * shr;
+    float r02 = (txz + twy) * shr;
+    if (fabsf(fabsf(r20) - 1.0f) < 1.0e-6f) { // gimbal lock
+        const float sg = nonzero_sign(r20);
+        r02 = nonzero_sign(r02) * eps + r02;
+        e[0] = atan2f(-sg * r01, -sg * r02);
+        e[1] = -sg * (float)(3.14159265358979323846 / 2.0);
+        e[2] = 0.0f;
+        return;
+    }
+    const float th_y = -asinf(r20);
+    const float sc = nonzero_sign(cosf(th_y));
+    r00 = nonzero_sign(r00) * eps + r00;
+    r22 = nonzero_sign(r22) * eps + r22;
+    e[2] = atan2f(r10 * sc, r00 * sc);
+    e[0] = atan2f(r21 * sc, r22 * sc);
+    e[1] = th_y;
+}
+
+// nn_model.py:463-472 next_state: pose' = normalize_quat(pose + J(x) vel dt), vel' = vel + delta; J = [[rot, 0], [0, T]] with THIS class's
+// T rows (:545-555: (-x,-y,-z), (w,-z,y), (z,w,-x), (-y,x,w) — AUVModel's rows rotated by one; the model is the specification)
+__device__ __forceinline__ void nnauv_speed_next_state(float dt, float (&x)[kGenS], const float (&delta)[6])
+{
+    const float q[4] = {x[3], x[4], x[5], x[6]};
+    float rot[9], T[12], xn[7];
+    auv_b2i(q, rot, T);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xn[i] = x[i] + ((rot[i * 3] * x[7] + rot[i * 3 + 1] * x[8]) + rot[i * 3 + 2] * x[9]) * dt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (i + 3) & 3;
+        xn[3 + i] = x[3 + i] + ((T[r * 3] * x[10] + T[r * 3 + 1] * x[11]) + T[r * 3 + 2] * x[12]) * dt;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x[i] = xn[i];
+    normalize_quat(x);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[7 + i] = x[7 + i] + delta[i];
+}
+
+// build_step_graph (:358-380): the Dense stack through the scalar cache (dense_pairs, as nnauv_step); 15 inputs, 6 outputs
+template <int HID>
+__device__ __forceinline__ void nnauv_speed_step(const DevConsts *__restrict__ C, const MlpDev *__restrict__ M, const float *const (&Wp)[kMlpSmallMaxLayers],
+                                                 const float *const (&bp)[kMlpSmallMaxLayers], int n_hidden,
+                                                 const float (&xm)[kGenNin], const float (&xr)[kGenNin], float (&x)[kGenS], const float (&v)[kGenA])
+{
+    constexpr int H2 = HID / 2, NI = kGenSpeedNin;
+    float in[NI], e[3];
+    const float q[4] = {x[3], x[4], x[5], x[6]};
+    euler_from_quat(q, e);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) in[i] = (e[i] - xm[i]) * xr[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) in[3 + i] = (x[7 + i] - xm[3 + i]) * xr[3 + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) in[9 + i] = (v[i] - xm[9 + i]) * xr[9 + i];
+    f32x2s ha[H2], hb[H2];
+    float hin[HID];
+    dense_pairs<NI, H2, true>(Wp[0], bp[0], in, ha);
+    for (int l = 1; l < n_hidden; ++l) {
+#pragma unroll
+        for (int o2 = 0; o2 < H2; ++o2) { hin[2 * o2] = ha[o2].x; hin[2 * o2 + 1] = ha[o2].y; }
+        const float *Wl = l == 1 ? Wp[1] : Wp[2], *bl = l == 1 ? bp[1] : bp[2];
+        dense_pairs<HID, H2, true>(Wl, bl, hin, hb);
+#pragma unroll
+        for (int o2 = 0; o2 < H2; ++o2) ha[o2] = hb[o2];
+    }
+#pragma unroll
+    for (int o2 = 0; o2 < H2; ++o2) { hin[2 * o2] = ha[o2].x; hin[2 * o2 + 1] = ha[o2].y; }
+    f32x2s y[3];
+    const float *Wo = n_hidden == 1 ? Wp[1] : (n_hidden == 2 ? Wp[2] : Wp[3]);
+    const float *bo = n_hidden == 1 ? bp[1] : (n_hidden == 2 ? bp[2] : bp[3]);
+    dense_pairs<HID, 3, false>(Wo, bo, hin, y);
+    float delta[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) delta[i] = ((i & 1) ? y[i / 2].y : y[i / 2].x) * M->ystd[i] + M->ymean[i];
+    nnauv_speed_next_state(C->dt, x, delta);
+}
+
 // ---------------------------------------------------------------------------------------- the rollout kernel
 // MODEL: GEN_MODEL_AUV | GEN_MODEL_NNAUV ; HID: hidden width of the NNAUV network (16 | 32; ignored for the AUV model).
 // mode: MODE_ROLLOUT (costs + record) | MODE_COST_ONLY | MODE_COSTS_GIVEN (record from given costs) ; noise_out != NULL
@@ -469,9 +565,9 @@ __global__ __launch_bounds__(64) void k_rollout_gen(
         c = cost[kk];
     } else {
         float xm[kGenNin], xr[kGenNin];
-        if (MODEL == GEN_MODEL_NNAUV) {
+        if (MODEL == GEN_MODEL_NNAUV || MODEL == GEN_MODEL_NNAUV_SPEED) {
 #pragma unroll
-            for (int i = 0; i < kGenNin; ++i) { xm[i] = M->xmean[i]; xr[i] = 1.0f / M->xstd[i]; }
+            for (int i = 0; i < kGenNin; ++i) { xm[i] = M->xmean[i]; xr[i] = 1.0f / M->xstd[i]; } // (the speed model uses 15 of the 16)
         }
         float x[S];
 #pragma unroll
@@ -512,7 +608,8 @@ __global__ __launch_bounds__(64) void k_rollout_gen(
                 const float *Wp[kMlpSmallMaxLayers], *bp[kMlpSmallMaxLayers];
 #pragma unroll
                 for (int l = 0; l < kMlpSmallMaxLayers; ++l) { Wp[l] = P.W[l] + zoff; bp[l] = P.b[l] + zoff; }
-                nnauv_step<HID>(M, Wp, bp, P.n_layers - 1, xm, xr, x, v);
+                if (MODEL == GEN_MODEL_NNAUV_SPEED) nnauv_speed_step<HID>(C, M, Wp, bp, P.n_layers - 1, xm, xr, x, v);
+                else nnauv_step<HID>(M, Wp, bp, P.n_layers - 1, xm, xr, x, v);
             }
             const float sc = gen_state_cost(C, G, x); // cost on the POST-step state
             const float tmp = sc + ac;                // Step_cost_result cost_base.cpp:49

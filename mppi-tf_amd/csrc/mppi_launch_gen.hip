@@ -171,7 +171,10 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
         return hipGetLastError();
     }
     if (h->hc.model_kind == MPPI_MODEL_AUV) MPPI_GEN_L(GEN_MODEL_AUV, 32);
-    else if (h->mlp_small == 16) MPPI_GEN_L(GEN_MODEL_NNAUV, 16);
+    else if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED) {
+        if (h->mlp_small == 16) MPPI_GEN_L(GEN_MODEL_NNAUV_SPEED, 16);
+        else MPPI_GEN_L(GEN_MODEL_NNAUV_SPEED, 32);
+    } else if (h->mlp_small == 16) MPPI_GEN_L(GEN_MODEL_NNAUV, 16);
     else MPPI_GEN_L(GEN_MODEL_NNAUV, 32);
 #undef MPPI_GEN_L
     return hipGetLastError();
@@ -180,6 +183,7 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
 const char *mppi_gen_kernel_name(const mppi_handle *h)
 {
     if (h->hc.model_kind == MPPI_MODEL_AUV) return "mppi::k_rollout_gen<0, 32>";
+    if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED) return h->mlp_small == 16 ? "mppi::k_rollout_gen<2, 16>" : "mppi::k_rollout_gen<2, 32>";
     if (h->mlp_small == 32 && !h->mlp32_valu) return h->mlp_bx3 ? "mppi::k_rollout_nnauv32_bx3" : "mppi::k_rollout_nnauv32";
     return h->mlp_small == 16 ? "mppi::k_rollout_gen<1, 16>" : "mppi::k_rollout_gen<1, 32>";
 }
@@ -187,15 +191,24 @@ const char *mppi_gen_kernel_name(const mppi_handle *h)
 // NNAUVModel.build_step_graph in the reference's plain order (mul and add rounded separately, input index ascending, division by
 // Xstd): the slow evaluation behind mppi_model_step, like k_mlp_step_ref. Reads the UNPADDED weights through MlpDev.
 static __global__ void k_nnauv_step_ref(const DevConsts *__restrict__ C, const MlpDev *__restrict__ M, const float *__restrict__ x, int kx,
-                                        const float *__restrict__ v, int k, float *__restrict__ scratch, float *__restrict__ out_next)
+                                        const float *__restrict__ v, int k, float *__restrict__ scratch, float *__restrict__ out_next, int speed)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
-    const int s = kGenS, a = kGenA, nin = kGenNin;
+    const int s = kGenS, a = kGenA, nin = speed ? kGenSpeedNin : kGenNin;
     float *cur = scratch + (size_t)i * 2 * 64, *nxt = cur + 64;
     const float *xi = x + (size_t)(kx == 1 ? 0 : i) * s;
-    for (int j = 0; j < s - 3; ++j) cur[j] = (xi[3 + j] - M->xmean[j]) / M->xstd[j];
-    for (int j = 0; j < a; ++j) cur[s - 3 + j] = (v[(size_t)i * a + j] - M->xmean[s - 3 + j]) / M->xstd[s - 3 + j];
+    if (speed) { // NNAUVModelSpeed.prepare_data (nn_model.py:438-461): Euler angles, velocities, forces
+        const float q[4] = {xi[3], xi[4], xi[5], xi[6]};
+        float e[3];
+        euler_from_quat(q, e);
+        for (int j = 0; j < 3; ++j) cur[j] = (e[j] - M->xmean[j]) / M->xstd[j];
+        for (int j = 0; j < 6; ++j) cur[3 + j] = (xi[7 + j] - M->xmean[3 + j]) / M->xstd[3 + j];
+        for (int j = 0; j < a; ++j) cur[9 + j] = (v[(size_t)i * a + j] - M->xmean[9 + j]) / M->xstd[9 + j];
+    } else {
+        for (int j = 0; j < s - 3; ++j) cur[j] = (xi[3 + j] - M->xmean[j]) / M->xstd[j];
+        for (int j = 0; j < a; ++j) cur[s - 3 + j] = (v[(size_t)i * a + j] - M->xmean[s - 3 + j]) / M->xstd[s - 3 + j];
+    }
     int width = nin;
     for (int l = 0; l < M->n_layers; ++l) {
         const int out_w = M->widths[l];
@@ -210,8 +223,15 @@ static __global__ void k_nnauv_step_ref(const DevConsts *__restrict__ C, const M
         float *t = cur; cur = nxt; nxt = t;
         width = out_w;
     }
+    if (speed) { // next_state (:463-472)
+        float xs[kGenS], delta[6];
+        for (int o = 0; o < s; ++o) xs[o] = xi[o];
+        for (int o = 0; o < 6; ++o) delta[o] = cur[o] * M->ystd[o] + M->ymean[o];
+        nnauv_speed_next_state(C->dt, xs, delta);
+        for (int o = 0; o < s; ++o) out_next[(size_t)i * s + o] = xs[o];
+        return;
+    }
     for (int o = 0; o < s; ++o) out_next[(size_t)i * s + o] = xi[o] + (cur[o] * M->ystd[o] + M->ymean[o]);
-    (void)C;
 }
 
 static __global__ void k_auv_step(const GenConsts *__restrict__ G, const float *__restrict__ x, int kx, const float *__restrict__ v, int k,
@@ -236,7 +256,8 @@ hipError_t mppi_gen_model_step(mppi_handle *h, hipStream_t st, const float *x, i
     const GenState *g = gs(h);
     const dim3 grid((k + 63) / 64), block(64);
     if (h->hc.model_kind == MPPI_MODEL_AUV) hipLaunchKernelGGL(k_auv_step, grid, block, 0, st, (const GenConsts *)g->dG, x, kx, v, k, out_next);
-    else hipLaunchKernelGGL(k_nnauv_step_ref, grid, block, 0, st, (const DevConsts *)h->dC, (const MlpDev *)h->dM, x, kx, v, k, scratch, out_next);
+    else hipLaunchKernelGGL(k_nnauv_step_ref, grid, block, 0, st, (const DevConsts *)h->dC, (const MlpDev *)h->dM, x, kx, v, k, scratch, out_next,
+                            h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED ? 1 : 0);
     return hipGetLastError();
 }
 

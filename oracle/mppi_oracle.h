@@ -51,6 +51,7 @@ extern "C" {
 #define ORC_MODEL_MLP 1
 #define ORC_MODEL_AUV 2            /* Fossen AUVModel                 models/auv_model.py:282-562 */
 #define ORC_MODEL_NNAUV 3          /* NNAUVModel                      models/nn_model.py:215-304 */
+#define ORC_MODEL_NNAUV_SPEED 4    /* NNAUVModelSpeed                 models/nn_model.py:307-588 */
 
 #define SUF(x) x##_f32
 #define REAL float

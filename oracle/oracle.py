@@ -18,7 +18,7 @@ _SO = os.path.join(_HERE, "libmppi_oracle.so")
 
 MAX_LAYERS = 8
 ACTION_COST_CPP, ACTION_COST_PY = 0, 1
-MODEL_POINT_MASS, MODEL_MLP, MODEL_AUV, MODEL_NNAUV = 0, 1, 2, 3
+MODEL_POINT_MASS, MODEL_MLP, MODEL_AUV, MODEL_NNAUV, MODEL_NNAUV_SPEED = 0, 1, 2, 3, 4
 STATE_COST_QUADRATIC, STATE_COST_ELLIPSE, STATE_COST_QUAT, STATE_COST_ELLIPSE3D = 0, 1, 2, 3
 
 
@@ -219,11 +219,13 @@ class Problem:
 
     def __init__(self, tau, s, a, dt=0.1, mass=1.0, lam=1.0, sigma=None, goal=None, Q=None,
                  gamma=1.0, upsilon=1.0, action_cost=ACTION_COST_CPP, mlp=None, threads=1,
-                 dtype=np.float32, ellipse=None, auv=None, nnauv=None, quat_cost=False, ellipse3d=None):
+                 dtype=np.float32, ellipse=None, auv=None, nnauv=None, quat_cost=False, ellipse3d=None, nnauv_speed=None):
         """ellipse: dict(a, b, cx, cy, speed, m_state, m_vel) selects ElipseCost's state cost (elipse_cost.py:9-85)
         instead of the quadratic one.
         auv: the reference's AUVModel `parameters` dict (auv_model.py:85-245; + "dt") selects the Fossen model (s=13, a=6);
         nnauv: an mlp dict with input width s+a-3 selects NNAUVModel (nn_model.py:215-304);
+        nnauv_speed: an mlp dict with 15 inputs (3 Euler angles, 6 velocities, 6 forces) and 6 outputs selects NNAUVModelSpeed
+        (nn_model.py:307-588), stepped with `dt`;
         quat_cost: StaticQuatCost (static_cost.py:73-159): goal [13], Q [10,10] (or its diagonal);
         ellipse3d: dict(normal, aVec, axis, speed, m_state, m_vel) selects ElipseCost3D (elipse_cost.py:101-246)."""
         I = self.I = _get(dtype)
@@ -256,6 +258,10 @@ class Problem:
         elif nnauv is not None:
             p.model_kind = MODEL_NNAUV
             self._fill_mlp(p.mlp, nnauv, n_in=s + a - 3)
+        elif nnauv_speed is not None:
+            p.model_kind = MODEL_NNAUV_SPEED
+            self._fill_mlp(p.mlp, nnauv_speed, n_in=15, n_out=6)
+            p.auv.dt = dt
         elif mlp is None:
             p.model_kind = MODEL_POINT_MASS
             self.A, self.B = pm_matrices(dt, mass, s, a, dtype)
@@ -264,7 +270,7 @@ class Problem:
             p.model_kind = MODEL_MLP
             self._fill_mlp(p.mlp, mlp)
 
-    def _fill_mlp(self, m, mlp, n_in=None):
+    def _fill_mlp(self, m, mlp, n_in=None, n_out=None):
         I = self.I
         Ws, bs = mlp["W"], mlp["b"]
         m.s, m.a, m.n_layers = self.s, self.a, len(Ws)
@@ -274,8 +280,9 @@ class Problem:
             m.widths[l] = W.shape[1]
             m.W[l], m.b[l] = I.ptr(W), I.ptr(b)
         n_in = self.s + self.a if n_in is None else n_in
+        n_out = self.s if n_out is None else n_out
         for name, default, n in (("xmean", 0.0, n_in), ("xstd", 1.0, n_in),
-                                 ("ymean", 0.0, self.s), ("ystd", 1.0, self.s)):
+                                 ("ymean", 0.0, n_out), ("ystd", 1.0, n_out)):
             v = I.arr(mlp.get(name, np.full(n, default)), (n,))
             self._keep.append(v)
             setattr(m, name, I.ptr(v))
@@ -580,6 +587,32 @@ def quat_dist(x, goal, dtype=np.float64):
     d = np.zeros(10, I.npdt)
     I.fn("orc_quat_dist")(I.ptr(x), I.ptr(g), I.ptr(d))
     return d
+
+
+def euler_from_quaternion(q, dtype=np.float64):
+    """tensorflow_graphics euler.from_quaternion as NNAUVModelSpeed.to_euler calls it (nn_model.py:566-588): [k,4] (x,y,z,w) -> [k,3]"""
+    I = _get(dtype)
+    q = I.arr(q, (-1, 4))
+    out = np.zeros((q.shape[0], 3), I.npdt)
+    f = I.fn("orc_euler_from_quat")
+    for i in range(q.shape[0]):
+        qi, ei = np.ascontiguousarray(q[i]), np.zeros(3, I.npdt)
+        f(I.ptr(qi), I.ptr(ei))
+        out[i] = ei
+    return out
+
+
+def nnauv_speed_prepare_data(state, action, xmean=None, xstd=None, dtype=np.float64):
+    """NNAUVModelSpeed.prepare_data (nn_model.py:438-461): concat(euler(state)[3:], action) normalised. [k,13],[k,6] -> [k,15]"""
+    st, ac = np.asarray(state, np.float64).reshape(-1, 13), np.asarray(action, np.float64).reshape(-1, 6)
+    X = np.concatenate([euler_from_quaternion(st[:, 3:7], dtype).astype(np.float64), st[:, 7:], ac], axis=1)
+    return (X - (0.0 if xmean is None else xmean)) / (1.0 if xstd is None else xstd)
+
+
+def nnauv_speed_prepare_training_data(state_t, state_t1, action, dtype=np.float64):
+    """NNAUVModelSpeed.prepare_training_data (nn_model.py:382-436), norm=False: X as prepare_data, Y = velocity delta [k,6]"""
+    st, st1 = np.asarray(state_t, np.float64).reshape(-1, 13), np.asarray(state_t1, np.float64).reshape(-1, 13)
+    return nnauv_speed_prepare_data(st, action, dtype=dtype), st1[:, 7:] - st[:, 7:]
 
 
 def nnauv_prepare_data(state, action, xmean=None, xstd=None):

@@ -156,6 +156,110 @@ def test_nnauv_single_step_reference_order_is_bit_exact(m, hid, n_hidden):
     np.testing.assert_array_equal(got, p32.model_next(x, u))
 
 
+def make_nnauv_speed(seed=0, hid=16, n_hidden=3):
+    rng = np.random.default_rng(seed)
+    dims = [15] + [hid] * n_hidden + [6]
+    W = [(rng.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(F32) for i in range(n_hidden + 1)]
+    b = [(rng.uniform(-1, 1, dims[i + 1]) / np.sqrt(dims[i])).astype(F32) for i in range(n_hidden + 1)]
+    W[-1] *= 0.1
+    b[-1] *= 0.1
+    return dict(W=W, b=b, xmean=rng.uniform(-0.1, 0.1, 15).astype(F32), xstd=rng.uniform(0.8, 1.2, 15).astype(F32),
+                ymean=rng.uniform(-0.01, 0.01, 6).astype(F32), ystd=rng.uniform(0.8, 1.2, 6).astype(F32))
+
+
+@pytest.mark.parametrize("hid,n_hidden", [(16, 3), (32, 3), (16, 1)])
+def test_nnauv_speed_single_step_and_data_preparation(m, hid, n_hidden):
+    """NNAUVModelSpeed (nn_model.py:307-588) through the mirror class: one device step against the fp32 and fp64 oracle (same operation
+    order in the reference-order helper kernel; the device's asinf / atan2f against libm's: a few ulp), unit quaternions out, and the
+    host-side prepare_data / prepare_training_data against the oracle's restatement."""
+    mlp = make_nnauv_speed(3, hid, n_hidden)
+    nn = m.NNAUVModelSpeed(weights=mlp, dt=0.1)
+    nn.set_Xmean_Xstd(mlp["xmean"], mlp["xstd"])
+    nn.set_Ymean_Ystd(mlp["ymean"], mlp["ystd"])
+    mk = lambda dt: orc.Problem(tau=2, s=13, a=6, dt=0.1, sigma=np.eye(6), goal=np.zeros(13), nnauv_speed=mlp, dtype=dt)
+    p32, p64 = mk(F32), mk(np.float64)
+    x, u = rand_states(256, 4)
+    u = (u / 200).astype(F32)
+    got = nn.build_step_graph("nn", x[..., None], u[..., None])[..., 0]
+    ref32, ref64 = p32.model_next(x, u), p64.model_next(x, u)
+    np.testing.assert_allclose(got, ref32, rtol=2e-6, atol=2e-6)
+    assert np.abs(got - ref64).max() <= 4 * max(np.abs(ref32 - ref64).max(), 1e-6)
+    assert np.abs(np.linalg.norm(got[:, 3:7], axis=1) - 1).max() < 1e-6
+    np.testing.assert_allclose(nn.prepare_data(x[..., None], u[..., None]), orc.nnauv_speed_prepare_data(x, u, mlp["xmean"], mlp["xstd"]),
+                               rtol=1e-9, atol=1e-9)
+    X, Y = nn.prepare_training_data(x[..., None], ref64[..., None], u[..., None], norm=False)
+    Xo, Yo = orc.nnauv_speed_prepare_training_data(x, ref64, u)
+    np.testing.assert_allclose(X, Xo, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(Y, Yo, rtol=1e-12, atol=1e-12)
+    bad = make_nnauv_speed(0, 16, 2)  # the velocity delta has 6 components
+    bad["W"][-1], bad["b"][-1] = np.zeros((16, 13), F32), np.zeros(13, F32)
+    with pytest.raises(m.MppiError):
+        m.Handle(k=64, tau=4, s_dim=13, a_dim=6, sigma=np.eye(6), goal=np.zeros(13), nnauv_speed=bad)
+
+
+@pytest.mark.parametrize("hid,n_hidden", [(16, 3), (32, 2)])
+@pytest.mark.parametrize("cost", ["quadratic", "quat"])
+def test_nnauv_speed_control_step_against_oracle(m, hid, n_hidden, cost):
+    """NNAUVModelSpeed in the full path (k_rollout_gen<2, hid>): costs as close to fp64 as an fp32 CPU evaluation is (4x), U' at 1e-5 on
+    unit noise; the fused Philox step on its own exported noise; 4-way sharding; ControllerBase(model=NNAUVModelSpeed, ...)."""
+    import torch
+    K, H = 2048, 10
+    mlp = make_nnauv_speed(7, hid, n_hidden)
+    sigma = 0.25 * np.eye(6)
+    goal_q = GOAL13[:3] + [0.0, 0.0, np.sin(0.5), np.cos(0.5)] + [0.0] * 6
+    ck = dict(goal=GOAL13, Q=np.array([10.0] * 3 + [5.0] * 4 + [1.0] * 6)) if cost == "quadratic" else dict(goal=goal_q, Q=Q10 / 10, quat_cost=True)
+    cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv_speed=mlp, seed=9, **ck)
+    h = m.Handle(**cfg)
+    assert h.rollout_kernel_name() == "mppi::k_rollout_gen<2, %d>" % hid
+    mk = lambda dt: orc.Problem(tau=H, s=13, a=6, dt=0.1, lam=1.0, sigma=sigma, nnauv_speed=mlp, threads=0, dtype=dt, **ck)
+    p32, p64 = mk(F32), mk(np.float64)
+    rng = np.random.default_rng(1)
+    x0 = np.array([0.5, -0.5, 0.2, 0.0, 0.0, 0.0, 1.0, 0.3, 0.0, -0.1, 0.0, 0.05, 0.0], F32)
+    U = (0.1 * rng.standard_normal((H, 6))).astype(F32)
+    eps = (0.25 * rng.standard_normal((K, H, 6))).astype(F32)
+    h.set_action_sequence(U)
+    h.next_with_noise(x0, eps)
+    u64, U64, c64 = p64.next_with_noise(x0, U, eps)
+    u32, U32, c32 = p32.next_with_noise(x0, U, eps)
+    c = h.debug_get(m.DBG_COSTS).astype(np.float64)
+    rel = lambda a: float((np.abs(a - c64) / np.abs(c64)).max())
+    eu, eu_cpu = float(np.abs(h.get_action_sequence() - U64).max()), float(np.abs(np.asarray(U32, np.float64) - U64).max())
+    print("NNAUVSpeed %dx%d %s: rel cost err GPU %.3g / CPU %.3g; max|dU'| GPU %.3g / CPU %.3g" % (hid, n_hidden, cost, rel(c), rel(c32.astype(np.float64)), eu, eu_cpu))
+    assert rel(c) < 2e-5 and rel(c) < 4 * max(rel(c32.astype(np.float64)), 1e-6)
+    assert eu <= max(1e-5, 4 * eu_cpu)
+    U_in = h.get_action_sequence()
+    h.next(x0)
+    noise = h.debug_get(m.DBG_NOISE)
+    np.testing.assert_allclose(noise, orc.noise(9, 1, 0, K, H, 6, sigma), rtol=0, atol=5e-6)
+    _, U64b, c64b = p64.next_with_noise(x0, U_in, noise)
+    _, U32b, _ = p32.next_with_noise(x0, U_in, noise)
+    assert np.isfinite(c64b).all()
+    assert np.abs(h.get_action_sequence() - U64b).max() <= max(1e-5, 4 * np.abs(np.asarray(U32b, np.float64) - U64b).max())
+    shards = 4
+    hs = [m.Handle(shard_rank=g, shard_count=shards, **cfg) for g in range(shards)]
+    xd = torch.tensor(x0, device="cuda")
+    n = hs[0].record_size
+    recs = torch.zeros(shards * n, device="cuda")
+    ud = torch.zeros(6, device="cuda")
+    one = torch.cuda.Stream()
+    for g, hg in enumerate(hs):
+        hg.set_action_sequence(U)
+        hg.shard_partial(xd.data_ptr(), recs[g * n:(g + 1) * n].data_ptr(), one.cuda_stream)
+    hs[0].shard_finish(recs.data_ptr(), shards, ud.data_ptr(), one.cuda_stream)
+    one.synchronize()
+    full = m.Handle(**cfg)
+    full.set_action_sequence(U)
+    np.testing.assert_allclose(ud.cpu().numpy(), full.next(x0), rtol=0, atol=2e-6)
+    if cost == "quat":  # the mirror classes: ControllerBase(model=NNAUVModelSpeed, cost=StaticQuatCost) builds the same controller
+        nn = m.NNAUVModelSpeed(weights=mlp, dt=0.1)
+        nn.set_Xmean_Xstd(mlp["xmean"], mlp["xstd"])
+        nn.set_Ymean_Ystd(mlp["ymean"], mlp["ystd"])
+        ctl = m.ControllerBase(model=nn, cost=m.StaticQuatCost(1.0, 1.0, 1.0, sigma, np.array(goal_q)[:, None], Q10 / 10), k=K, tau=H, sDim=13, aDim=6,
+                               lam=1.0, sigma=sigma, seed=9)
+        assert ctl._h.rollout_kernel_name() == "mppi::k_rollout_gen<2, %d>" % hid
+        assert np.isfinite(ctl.next(x0[:, None])).all()
+
+
 # ------------------------------------------------------------------------------------------------ costs
 GOAL13 = [1.0, 2.0, -3.0, 0.0, 0.0, np.sin(0.2), np.cos(0.2)] + [0.0] * 6
 Q10 = np.diag([100.0] * 3 + [10.0] + [1.0] * 6) + 0.01

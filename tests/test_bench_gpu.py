@@ -24,7 +24,7 @@ def run_bench(*argv):
 
 
 @pytest.mark.parametrize("workload,samples,horizon", [("pm1d", 128, 32), ("pm2d", 4096, 64), ("pm3d", 8192, 16), ("mlp", 2048, 8),
-                                                      ("mlp32", 4096, 8), ("auv", 4096, 8), ("nnauv", 4096, 8)])
+                                                      ("mlp32", 4096, 8), ("auv", 4096, 8), ("nnauv", 4096, 8), ("nnspeed", 4096, 8)])
 def test_every_workload_prints_the_contract_line(workload, samples, horizon):
     out = run_bench("--workload", workload, "--samples", str(samples), "--horizon", str(horizon), "--no-subrecords", "--no-cpu-baseline")
     for key in CONTRACT:

@@ -352,6 +352,62 @@ def test_nnauv_step_is_state_plus_denormalised_network_output():
     np.testing.assert_allclose(p.model_next(x, u), x + h * mlp["ystd"] + mlp["ymean"], rtol=1e-12, atol=1e-12)
 
 
+def test_euler_from_quaternion_against_scipy():
+    """NNAUVModelSpeed.to_euler calls tensorflow_graphics' euler.from_quaternion (third party, absent; the reference holds no test of this
+    model): the restatement is pinned by an independent implementation — scipy's Rotation.as_euler('xyz') (extrinsic x-y-z = R = Rz Ry Rx) —
+    on random attitudes, and by its own gimbal-lock branch at pitch = +-90 degrees."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal((4000, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    e = orc.euler_from_quaternion(q)
+    ref = Rotation.from_quat(q).as_euler("xyz")
+    assert np.abs(np.angle(np.exp(1j * (e - ref)))).max() < 1e-11
+    e32 = orc.euler_from_quaternion(q, np.float32).astype(np.float64)
+    far = np.abs(np.abs(e[:, 1]) - np.pi / 2) > 0.2  # away from the lock the fp32 evaluation (of the fp32-rounded attitude) is well conditioned
+    assert np.abs(np.angle(np.exp(1j * (e32 - e))))[far].max() < 1e-5
+    for sign in (1.0, -1.0):  # pitch = +-90 degrees: theta_z = 0, theta_y = +-pi/2, the attitude is reproduced
+        ql = Rotation.from_euler("xyz", [0.3, sign * np.pi / 2, 0.0]).as_quat()[None]
+        el = orc.euler_from_quaternion(ql)[0]
+        assert abs(el[1] - sign * np.pi / 2) < 1e-12 and el[2] == 0.0
+        assert np.abs(Rotation.from_euler("xyz", el).as_matrix() - Rotation.from_quat(ql[0]).as_matrix()).max() < 1e-6
+
+
+def test_nnauv_speed_step_against_numpy():
+    """NNAUVModelSpeed.build_step_graph (nn_model.py:358-380, 438-472): velocity delta from the network on (Euler angles, velocities,
+    forces); pose integrated with J(x) over dt with THIS class's T rows (:545-555), quaternion renormalised. Against numpy."""
+    rng = np.random.default_rng(1)
+    dims = [15, 16, 16, 16, 6]
+    mlp = dict(W=[rng.standard_normal((dims[i], dims[i + 1])) / 4 for i in range(4)], b=[rng.standard_normal(dims[i + 1]) / 10 for i in range(4)],
+               xmean=rng.standard_normal(15) / 10, xstd=1 + rng.random(15), ymean=rng.standard_normal(6) / 10, ystd=1 + rng.random(6))
+    dt = 0.1
+    p = orc.Problem(tau=4, s=13, a=6, dt=dt, sigma=np.eye(6), goal=np.zeros(13), nnauv_speed=mlp, dtype=np.float64)
+    x, u = rng.standard_normal((6, 13)), rng.standard_normal((6, 6))
+    x[:, 3:7] /= np.linalg.norm(x[:, 3:7], axis=1, keepdims=True)
+    h = orc.nnauv_speed_prepare_data(x, u, mlp["xmean"], mlp["xstd"])
+    assert h.shape == (6, 15)
+    for l in range(4):
+        h = h @ mlp["W"][l] + mlp["b"][l]
+        if l < 3:
+            h = np.maximum(h, 0)
+    delta = h * mlp["ystd"] + mlp["ymean"]
+    exp = x.copy()
+    for i in range(6):
+        qx, qy, qz, qw = x[i, 3:7]
+        rot = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                        [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                        [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+        T = 0.5 * np.array([[-qx, -qy, -qz], [qw, -qz, qy], [qz, qw, -qx], [-qy, qx, qw]])
+        pose = x[i, :7] + np.concatenate([rot @ x[i, 7:10], T @ x[i, 10:13]]) * dt
+        pose[3:7] /= np.linalg.norm(pose[3:7])
+        exp[i, :7], exp[i, 7:] = pose, x[i, 7:] + delta[i]
+    got = p.model_next(x, u)
+    np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-11)
+    assert np.abs(np.linalg.norm(got[:, 3:7], axis=1) - 1).max() < 1e-12
+    X, Y = orc.nnauv_speed_prepare_training_data(x, got, u)
+    np.testing.assert_allclose(Y, delta, rtol=1e-10, atol=1e-10)  # the training target IS the velocity delta
+
+
 def test_elipse3d_cost_pieces():
     g = load_golden("cost_elipse3d")
     b = g["base"]
