@@ -181,3 +181,34 @@ def test_train_the_auv_network_on_the_fossen_model_and_control_with_it(m):
     print("trained controller: rel cost err GPU %.3g / fp32 CPU %.3g; |du|/sigma GPU %.3g / fp32 CPU %.3g" % (rel(c), rel(c32.astype(np.float64)), e_gpu, e_cpu))
     assert rel(c) < 4 * max(rel(c32.astype(np.float64)), 1e-6)
     assert e_gpu <= max(1e-5, 4 * e_cpu)
+
+
+def test_train_the_speed_network_on_the_fossen_model(m):
+    """NNAUVModelSpeed (nn_model.py:307-588) through the same loop: its training pairs are (Euler angles, velocities, forces) -> the
+    velocity delta; LearnerBase's statistics and Adam on the device; the trained model's one-step velocity prediction of the Fossen
+    plant improves by 4x, and its pose step — the quaternion kinematics, no network involved — is the oracle's."""
+    from conftest import load_golden
+    P = load_golden("model_auv")["params"]
+    plant = m.AUVModel(actionDim=6, dt=0.1, parameters=P)
+    rng = np.random.default_rng(3)
+    n = 6000
+    x = rng.standard_normal((n, 13)) * np.array([1, 1, 1, 0, 0, 0, 0, .5, .5, .5, .2, .2, .2])
+    q = rng.standard_normal((n, 4)) * 0.3 + np.array([0, 0, 0, 1.0])
+    x[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    u = 300.0 * rng.standard_normal((n, 6))
+    xn = plant.build_step_graph("plant", x[..., None], u[..., None])
+    model = m.NNAUVModelSpeed(dt=0.1)
+    assert [w.shape for w in model.get_weights()[0::2]] == [(15, 16), (16, 16), (16, 16), (16, 6)]
+    learner = m.LearnerBase(model, bufferSize=n)
+    learner.add_rb(x[..., None], u[..., None], xn)
+    learner.stats()
+    assert model.Xstd.shape == (15,) and model.Ystd.shape == (6,) and np.all(model.Xstd > 0)
+    vel_mse = lambda: np.mean((model.build_step_graph("nn", x[:500, :, None], u[:500, :, None])[:, 7:] - xn[:500, 7:]) ** 2)
+    before = vel_mse()
+    first, last = learner.train_all(learningRate=3e-3, epoch=400)
+    after = vel_mse()
+    print("NNAUVModelSpeed trained on %d Fossen transitions: normalised loss %.4f -> %.4f, velocity MSE %.3g -> %.3g" % (n, first, last, before, after))
+    assert last < 0.25 * first and after < 0.25 * before
+    p64 = orc.Problem(tau=2, s=13, a=6, dt=0.1, sigma=np.eye(6), goal=np.zeros(13), nnauv_speed=model.mlp(), dtype=np.float64)
+    got = model.build_step_graph("nn", x[:500, :, None], u[:500, :, None])[..., 0]
+    np.testing.assert_allclose(got, p64.model_next(x[:500], u[:500]), rtol=1e-4, atol=1e-4)  # fp32 network on O(100 N) inputs against fp64
