@@ -166,6 +166,11 @@ const char *mppi_last_error(const mppi_handle *h);
  * step (the reference bakes the goal into the graph and ignores later calls — a bug we do
  * not reproduce). n must equal s_dim. */
 mppi_status mppi_set_goal(mppi_handle *h, const float *goal, int n);
+/* Replaces the learned model's weights and normalisation on an existing handle (same layer widths as at creation): what the
+ * reference's learner does to the variables the controller's graph reads (learners/learner_base.py:469-496 apply_gradients;
+ * models/nn_model.py set_Xmean_Xstd / set_Ymean_Ystd / update_weights). Waits for the handle's stream, copies, takes effect with
+ * the next step. MPPI_MODEL_MLP / _NN_AUV / _NN_AUV_SPEED handles. */
+mppi_status mppi_set_mlp(mppi_handle *h, const mppi_mlp_desc *mlp);
 /* replaces ControllerBase::next (controller_base.cpp:135-153): one control step with noise
  * drawn on the device (Philox4x32-10 via rocRAND's engine); returns u = U'[0] in u_out[a],
  * keeps shift(U') as the warm start, logs (x,u) like m_db.addX/addU. */

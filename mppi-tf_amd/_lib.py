@@ -71,6 +71,7 @@ SIGNATURES = {
     "mppi_destroy": (None, [_H]),
     "mppi_last_error": (C.c_char_p, [_H]),
     "mppi_set_goal": (C.c_int, [_H, FP, C.c_int]),
+    "mppi_set_mlp": (C.c_int, [_H, C.POINTER(MlpDesc)]),
     "mppi_next": (C.c_int, [_H, FP, C.c_int, FP, C.c_int]),
     "mppi_next_with_noise": (C.c_int, [_H, FP, C.c_int, FP, C.c_size_t, FP, C.c_int]),
     "mppi_save_next": (C.c_int, [_H, FP, C.c_int]),
@@ -156,6 +157,24 @@ def fp(a):
     return a.ctypes.data_as(FP) if a is not None else None
 
 
+def _mlp_desc(mlp, n_in, n_out):
+    """mppi_mlp_desc of an mlp dict(W, b[, xmean, xstd, ymean, ystd]) -> (desc, objects that must outlive its use)"""
+    Ws = [f32(w) for w in mlp["W"]]
+    bs = [f32(b).ravel() for b in mlp["b"]]
+    held = Ws + bs
+    desc = MlpDesc()
+    desc.n_layers = len(Ws)
+    widths = (C.c_int32 * len(Ws))(*[w.shape[1] for w in Ws])
+    Wp = (FP * len(Ws))(*[fp(w) for w in Ws])
+    bp = (FP * len(bs))(*[fp(b) for b in bs])
+    desc.widths, desc.W, desc.b = widths, Wp, bp
+    for name, n in (("xmean", n_in), ("xstd", n_in), ("ymean", n_out), ("ystd", n_out)):
+        if mlp.get(name) is not None:
+            held.append(f32(mlp[name], (n,)))
+            setattr(desc, name, fp(held[-1]))
+    return desc, held + [desc, widths, Wp, bp]
+
+
 class Handle:
     """RAII wrapper of one mppi_handle (one controller on one GPU)."""
 
@@ -233,23 +252,12 @@ class Handle:
                 q_is_full = q.ndim == 2
             keep.append(f32(q, (s_dim, s_dim) if q_is_full else (s_dim,)))
             cfg.Q, cfg.q_is_full = fp(keep[-1]), int(q_is_full)
+        self._mlp_io = None
         if mlp is not None:
-            Ws = [f32(w) for w in mlp["W"]]
-            bs = [f32(b).ravel() for b in mlp["b"]]
-            keep += Ws + bs
-            desc = MlpDesc()
-            desc.n_layers = len(Ws)
-            widths = (C.c_int32 * len(Ws))(*[w.shape[1] for w in Ws])
-            Wp = (FP * len(Ws))(*[fp(w) for w in Ws])
-            bp = (FP * len(bs))(*[fp(b) for b in bs])
-            desc.widths, desc.W, desc.b = widths, Wp, bp
             n_in = 15 if nnauv_speed is not None else s_dim + a_dim - (3 if nnauv is not None else 0)
-            n_out = 6 if nnauv_speed is not None else s_dim
-            for name, n in (("xmean", n_in), ("xstd", n_in), ("ymean", n_out), ("ystd", n_out)):
-                if mlp.get(name) is not None:
-                    keep.append(f32(mlp[name], (n,)))
-                    setattr(desc, name, fp(keep[-1]))
-            keep += [desc, widths, Wp, bp]
+            self._mlp_io = (n_in, 6 if nnauv_speed is not None else s_dim)
+            desc, held = _mlp_desc(mlp, *self._mlp_io)
+            keep += held
             cfg.model_kind = MODEL_NN_AUV_SPEED if nnauv_speed is not None else (MODEL_NN_AUV if nnauv is not None else MODEL_MLP)
             cfg.mlp = C.pointer(desc)
         self.h = _H()
@@ -297,6 +305,14 @@ class Handle:
     def set_goal(self, goal):
         g = f32(goal).ravel()
         self._check(self.lib.mppi_set_goal(self.h, fp(g), g.size))
+
+    def set_mlp(self, mlp):
+        """mppi_set_mlp: new weights / normalisation for a learned-model handle (same layer widths), from the next step on"""
+        if self._mlp_io is None:
+            raise MppiError(1, "not a learned-model handle")
+        desc, held = _mlp_desc(mlp, *self._mlp_io)
+        self._check(self.lib.mppi_set_mlp(self.h, C.byref(desc)))
+        del held
 
     def next(self, x):
         # persistent staging arrays with ready-made ctypes pointers: building them per call costs more host time

@@ -290,6 +290,13 @@ class ControllerBase:
     def save(self, x, u, xNext):
         self._h.save_next(np.asarray(xNext, np.float32).reshape(-1))
 
+    def update_model(self):
+        """Push the model object's current weights and normalisation into the controller (mppi_set_mlp): what happens implicitly in
+        the reference, where learner and controller share the model's tf.Variables (learner_base.py:469-496). Learned models only."""
+        if not hasattr(self._model, "mlp"):
+            raise AssertionError("the controller's model has no learned weights")
+        self._h.set_mlp(self._model.mlp())
+
     def set_goal(self, goal):
         self._cost.set_goal(goal)
         self._h.set_goal(np.asarray(goal, np.float32).reshape(-1))

@@ -153,6 +153,55 @@ extern "C" void mppi_destroy(mppi_handle *h)
     delete h;
 }
 
+// Upload a learned model's weights and normalisation (mppi_create: allocate = true; mppi_set_mlp: the same buffers again).
+static mppi_status upload_mlp(mppi_handle *h, const mppi_mlp_desc *d, bool allocate)
+{
+    const int s = h->s, a = h->a;
+    const bool speed = h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED;
+    const bool nnauv = h->hc.model_kind == MPPI_MODEL_NN_AUV || speed;
+    // NNAUVModel.prepare_data drops the position (nn_model.py:289-293); NNAUVModelSpeed's takes Euler angles, velocities, forces (:438-461)
+    const int nin = speed ? 15 : (nnauv ? s + a - 3 : s + a), nout = speed ? 6 : s;
+    if (allocate) {
+        size_t total = 0;
+        for (int l = 0, w_in = nin; l < d->n_layers; w_in = d->widths[l], ++l) total += (size_t)(w_in + 1) * (d->widths[l] + 1);
+        HIP_TRY(h, hipMalloc((void **)&h->d_mlp_w, sizeof(float) * total));
+        HIP_TRY(h, hipMalloc((void **)&h->dM, sizeof(MlpDev)));
+    }
+    float *p = h->d_mlp_w;
+    h->hm.n_layers = d->n_layers;
+    h->small_args.n_layers = d->n_layers;
+    std::vector<float> padded; // an odd output layer (NNAUVModel: 13) is stored with one zero column more: outputs stay pairs
+    for (int l = 0, w_in = nin; l < d->n_layers; w_in = d->widths[l], ++l) {
+        const int ld = (nnauv && (d->widths[l] & 1)) ? d->widths[l] + 1 : d->widths[l];
+        const size_t nw = (size_t)w_in * ld, nbias = (size_t)ld;
+        if (ld != d->widths[l]) {
+            padded.assign(nw + nbias, 0.0f);
+            for (int i = 0; i < w_in; ++i) for (int o = 0; o < d->widths[l]; ++o) padded[(size_t)i * ld + o] = d->W[l][(size_t)i * d->widths[l] + o];
+            for (int o = 0; o < d->widths[l]; ++o) padded[nw + o] = d->b[l][o];
+            HIP_TRY(h, hipMemcpyAsync(p, padded.data(), sizeof(float) * (nw + nbias), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        } else {
+            HIP_TRY(h, hipMemcpyAsync(p, d->W[l], sizeof(float) * nw, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(p + nw, d->b[l], sizeof(float) * nbias, hipMemcpyHostToDevice, h->stream));
+        }
+        h->hm.widths[l] = d->widths[l];
+        h->hm.ld[l] = ld;
+        h->hm.Wl[l] = h->small_args.W[l] = p;
+        h->hm.bl[l] = h->small_args.b[l] = p + nw;
+        p += nw + nbias;
+    }
+    if (!h->mlp_small && !nnauv) {
+        h->hm.W1 = h->hm.Wl[0]; h->hm.b1 = h->hm.bl[0]; h->hm.W2 = h->hm.Wl[1]; h->hm.b2 = h->hm.bl[1];
+        h->hm.W3 = h->hm.Wl[2]; h->hm.b3 = h->hm.bl[2];
+    }
+    for (int i = 0; i < kMaxS + kMaxA; ++i) { h->hm.xmean[i] = 0.f; h->hm.xstd[i] = 1.f; }
+    for (int i = 0; i < nin; ++i) { h->hm.xmean[i] = d->xmean ? d->xmean[i] : 0.f; h->hm.xstd[i] = d->xstd ? d->xstd[i] : 1.f; }
+    for (int i = 0; i < nout; ++i) { h->hm.ymean[i] = d->ymean ? d->ymean[i] : 0.f; h->hm.ystd[i] = d->ystd ? d->ystd[i] : 1.f; }
+    HIP_TRY(h, hipMemcpyAsync(h->dM, &h->hm, sizeof(MlpDev), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPPI_OK;
+}
+
 extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
 {
     if (!cfg || !out) return fail(nullptr, MPPI_ERR_INVALID_ARG, "cfg/out is NULL");
@@ -319,47 +368,7 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         HIP_TRY(h, hipMalloc((void **)&h->d_part2, sizeof(float) * (size_t)nrec2 * (2 + h->HA)));
         HIP_TRY(h, hipMalloc((void **)&h->d_part3, sizeof(float) * (size_t)nrec3 * (2 + h->HA)));
         if (cfg->model_kind == MPPI_MODEL_MLP || cfg->model_kind == MPPI_MODEL_NN_AUV || cfg->model_kind == MPPI_MODEL_NN_AUV_SPEED) {
-            const mppi_mlp_desc *d = cfg->mlp;
-            const bool speed = cfg->model_kind == MPPI_MODEL_NN_AUV_SPEED;
-            const bool nnauv = cfg->model_kind == MPPI_MODEL_NN_AUV || speed;
-            // NNAUVModel.prepare_data drops the position (nn_model.py:289-293); NNAUVModelSpeed's takes Euler angles, velocities, forces (:438-461)
-            const int nin = speed ? 15 : (nnauv ? s + a - 3 : s + a), nout = speed ? 6 : s;
-            size_t total = 0;
-            for (int l = 0, w_in = nin; l < d->n_layers; w_in = d->widths[l], ++l) total += (size_t)(w_in + 1) * (d->widths[l] + 1);
-            HIP_TRY(h, hipMalloc((void **)&h->d_mlp_w, sizeof(float) * total));
-            HIP_TRY(h, hipMalloc((void **)&h->dM, sizeof(MlpDev)));
-            float *p = h->d_mlp_w;
-            h->hm.n_layers = d->n_layers;
-            h->small_args.n_layers = d->n_layers;
-            std::vector<float> padded; // an odd output layer (NNAUVModel: 13) is stored with one zero column more: outputs stay pairs
-            for (int l = 0, w_in = nin; l < d->n_layers; w_in = d->widths[l], ++l) {
-                const int ld = (nnauv && (d->widths[l] & 1)) ? d->widths[l] + 1 : d->widths[l];
-                const size_t nw = (size_t)w_in * ld, nbias = (size_t)ld;
-                if (ld != d->widths[l]) {
-                    padded.assign(nw + nbias, 0.0f);
-                    for (int i = 0; i < w_in; ++i) for (int o = 0; o < d->widths[l]; ++o) padded[(size_t)i * ld + o] = d->W[l][(size_t)i * d->widths[l] + o];
-                    for (int o = 0; o < d->widths[l]; ++o) padded[nw + o] = d->b[l][o];
-                    HIP_TRY(h, hipMemcpyAsync(p, padded.data(), sizeof(float) * (nw + nbias), hipMemcpyHostToDevice, h->stream));
-                    HIP_TRY(h, hipStreamSynchronize(h->stream));
-                } else {
-                    HIP_TRY(h, hipMemcpyAsync(p, d->W[l], sizeof(float) * nw, hipMemcpyHostToDevice, h->stream));
-                    HIP_TRY(h, hipMemcpyAsync(p + nw, d->b[l], sizeof(float) * nbias, hipMemcpyHostToDevice, h->stream));
-                }
-                h->hm.widths[l] = d->widths[l];
-                h->hm.ld[l] = ld;
-                h->hm.Wl[l] = h->small_args.W[l] = p;
-                h->hm.bl[l] = h->small_args.b[l] = p + nw;
-                p += nw + nbias;
-            }
-            if (!h->mlp_small && !nnauv) {
-                h->hm.W1 = h->hm.Wl[0]; h->hm.b1 = h->hm.bl[0]; h->hm.W2 = h->hm.Wl[1]; h->hm.b2 = h->hm.bl[1];
-                h->hm.W3 = h->hm.Wl[2]; h->hm.b3 = h->hm.bl[2];
-            }
-            for (int i = 0; i < kMaxS + kMaxA; ++i) { h->hm.xmean[i] = 0.f; h->hm.xstd[i] = 1.f; }
-            for (int i = 0; i < nin; ++i) { h->hm.xmean[i] = d->xmean ? d->xmean[i] : 0.f; h->hm.xstd[i] = d->xstd ? d->xstd[i] : 1.f; }
-            for (int i = 0; i < nout; ++i) { h->hm.ymean[i] = d->ymean ? d->ymean[i] : 0.f; h->hm.ystd[i] = d->ystd ? d->ystd[i] : 1.f; }
-            HIP_TRY(h, hipMemcpyAsync(h->dM, &h->hm, sizeof(MlpDev), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (mppi_status st_ = upload_mlp(h, cfg->mlp, true); st_ != MPPI_OK) return st_;
         }
         HIP_TRY(h, hipMalloc((void **)&h->d_record, sizeof(float) * (2 + h->HA)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dbg, sizeof(float) * 8));
@@ -704,6 +713,22 @@ extern "C" mppi_status mppi_set_goal(mppi_handle *h, const float *goal, int n)
     HIP_TRY(h, hipSetDevice(h->device));
     for (int i = 0; i < n; ++i) h->hc.goal[i] = goal[i];
     return upload_consts(h);
+}
+
+extern "C" mppi_status mppi_set_mlp(mppi_handle *h, const mppi_mlp_desc *d)
+{
+    if (!h) return MPPI_ERR_INVALID_ARG;
+    const int mk = h->hc.model_kind;
+    if (mk != MPPI_MODEL_MLP && mk != MPPI_MODEL_NN_AUV && mk != MPPI_MODEL_NN_AUV_SPEED) return fail(h, MPPI_ERR_INVALID_ARG, "not a learned-model handle");
+    if (!d || !d->widths || !d->W || !d->b) return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_mlp needs widths, W, b");
+    if (d->n_layers != h->hm.n_layers) return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_mlp: the layer count is fixed at creation");
+    for (int l = 0; l < d->n_layers; ++l) {
+        if (d->widths[l] != h->hm.widths[l]) return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_mlp: the layer widths are fixed at creation");
+        if (!d->W[l] || !d->b[l]) return fail(h, MPPI_ERR_INVALID_ARG, "NULL MLP weight pointer");
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream)); // steps in flight read the old weights
+    return upload_mlp(h, d, false);
 }
 
 extern "C" mppi_status mppi_next_device(mppi_handle *h, const float *x_dev, float *u_dev, void *stream)

@@ -212,3 +212,61 @@ def test_train_the_speed_network_on_the_fossen_model(m):
     p64 = orc.Problem(tau=2, s=13, a=6, dt=0.1, sigma=np.eye(6), goal=np.zeros(13), nnauv_speed=model.mlp(), dtype=np.float64)
     got = model.build_step_graph("nn", x[:500, :, None], u[:500, :, None])[..., 0]
     np.testing.assert_allclose(got, p64.model_next(x[:500], u[:500]), rtol=1e-4, atol=1e-4)  # fp32 network on O(100 N) inputs against fp64
+
+
+def test_weights_pushed_into_a_live_controller(m):
+    """mppi_set_mlp / ControllerBase.update_model: a controller keeps running while the learner improves its model — after the push its
+    step equals the step of a controller CREATED with the new weights (same seed, same step counter), for the NNAUVModel on the matrix
+    cores, its split-bf16 form, the vector-ALU kernels and the point-mass 2x256 network; shapes are fixed at creation."""
+    rng = np.random.default_rng(5)
+
+    def nnauv(seed, hid=32, n_out=13, n_in=16):
+        r = np.random.default_rng(seed)
+        dims = [n_in, hid, hid, hid, n_out]
+        return dict(W=[(r.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i]) * (0.1 if i == 3 else 1)).astype(F32) for i in range(4)],
+                    b=[(r.uniform(-1, 1, dims[i + 1]) / np.sqrt(dims[i]) * (0.1 if i == 3 else 1)).astype(F32) for i in range(4)],
+                    xmean=r.uniform(-0.1, 0.1, n_in).astype(F32), xstd=r.uniform(0.8, 1.2, n_in).astype(F32),
+                    ymean=r.uniform(-0.01, 0.01, n_out).astype(F32), ystd=r.uniform(0.8, 1.2, n_out).astype(F32))
+
+    x13 = np.array([0.5, -0.5, 0.2, 0.0, 0.0, 0.0, 1.0, 0.3, 0.0, -0.1, 0.0, 0.05, 0.0], F32)
+    base = dict(k=1024, tau=6, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=0.25 * np.eye(6), goal=[1.0, 2.0, -3.0, 0, 0, 0, 1.0] + [0.0] * 6, seed=4)
+    cases = [("nnauv", dict(hid=32), {}), ("nnauv", dict(hid=32), dict(mlp_bf16x3=True)), ("nnauv", dict(hid=16), {}),
+             ("nnauv_speed", dict(hid=16, n_out=6, n_in=15), {})]
+    for key, shape, extra in cases:
+        old, new = nnauv(1, **shape), nnauv(2, **shape)
+        live = m.Handle(**base, **{key: old}, **extra)
+        live.set_mlp(new)
+        fresh = m.Handle(**base, **{key: new}, **extra)
+        np.testing.assert_array_equal(live.next(x13), fresh.next(x13))
+        with pytest.raises(m.MppiError):  # another width
+            live.set_mlp(nnauv(3, **dict(shape, hid=48 - shape["hid"])))
+    # point-mass 2x256 (k_rollout_mlp2): weights are re-read from memory by every launch
+    def pm(seed):
+        r = np.random.default_rng(seed)
+        dims = [9, 256, 256, 6]
+        return dict(W=[(r.uniform(-1, 1, (dims[i], dims[i + 1])) / np.sqrt(dims[i]) * (0.1 if i == 2 else 1)).astype(F32) for i in range(3)],
+                    b=[(r.uniform(-1, 1, dims[i + 1]) / np.sqrt(dims[i]) * (0.1 if i == 2 else 1)).astype(F32) for i in range(3)])
+    pb = dict(k=2048, tau=8, s_dim=6, a_dim=3, lam=1.0, sigma=0.25 * np.eye(3), goal=[1, 0, .5, 0, .75, 0], seed=4)
+    live = m.Handle(**pb, mlp=pm(1))
+    live.next(np.zeros(6, F32))
+    live.set_mlp(pm(2))
+    fresh = m.Handle(**pb, mlp=pm(2))
+    fresh.next(np.zeros(6, F32))  # same step counter: the Philox stream depends on it
+    x6 = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
+    # the first steps differed (other weights -> other U), so compare the rollout costs of the SAME nominal sequence instead
+    U = (0.1 * rng.standard_normal((8, 3))).astype(F32)
+    eps = (0.25 * rng.standard_normal((2048, 8, 3))).astype(F32)
+    np.testing.assert_array_equal(live.rollout_cost(x6, U, eps), fresh.rollout_cost(x6, U, eps))
+    with pytest.raises(m.MppiError):
+        m.Handle(k=64, tau=4, s_dim=6, a_dim=3, sigma=np.eye(3)).set_mlp(pm(1))  # not a learned-model handle
+    # the mirror classes: the learner changes the model object, update_model() carries it into the controller
+    model = m.NNAUVModel(weights=nnauv(1))
+    ctl = m.ControllerBase(model=model, cost=m.StaticCost(1.0, 1.0, 1.0, base["sigma"], np.array(base["goal"])[:, None], np.ones(13), diag=True),
+                           k=1024, tau=6, sDim=13, aDim=6, lam=1.0, sigma=base["sigma"], seed=4)
+    w2 = nnauv(2)
+    model.update_weights([v for pair in zip(w2["W"], w2["b"]) for v in pair])
+    ctl.update_model()
+    model2 = m.NNAUVModel(weights=w2)
+    ctl2 = m.ControllerBase(model=model2, cost=m.StaticCost(1.0, 1.0, 1.0, base["sigma"], np.array(base["goal"])[:, None], np.ones(13), diag=True),
+                            k=1024, tau=6, sDim=13, aDim=6, lam=1.0, sigma=base["sigma"], seed=4)
+    np.testing.assert_array_equal(ctl.next(x13[:, None]), ctl2.next(x13[:, None]))
