@@ -83,8 +83,12 @@ def get_model(model_dict, samples, dt, state_dim, action_dim, name="model"):  # 
     if kind == "auv":  # model.py:41-49
         return m.AUVModel(modelDict=model_dict, inertialFrameId=model_dict.get("frame_id", "world"), actionDim=action_dim, name=name, k=samples,
                           dt=dt, parameters=model_dict)
-    raise NotImplementedError("model types of this entry point: point_mass, auv (auv_nn needs a Keras weight file: build NNAUVModel from "
-                              "LearnerBase-trained weights instead, tests/test_learner_gpu.py)")
+    if kind in ("auv_nn", "auv_nn_speed"):  # model.py:16-32: random initial weights (no Keras weight file here): --train makes them useful
+        cls = m.NNAUVModel if kind == "auv_nn" else m.NNAUVModelSpeed
+        return cls(modelDict=model_dict, k=samples, stateDim=state_dim, actionDim=action_dim, mask=np.array(model_dict["mask"]) if "mask" in model_dict else None,
+                   dt=dt)
+    raise NotImplementedError("model types of this entry point: point_mass, auv, auv_nn, auv_nn_speed (neural_net: NNModel.build_step_graph "
+                              "is NotImplemented in the reference, nn_model.py:101-117)")
 
 
 class AUVSimulation:
@@ -120,6 +124,10 @@ def main():
                                                               "default: the point mass of --config")
     ap.add_argument("-l", "--log", action="store_true", help="leave config.yaml / task.yaml (and the CSV) in the log dir")
     ap.add_argument("-s", "--steps", type=int, default=200)
+    ap.add_argument("--plant", type=str, default=None, help="model description of the PLANT when --model is a learned one (type auv); "
+                                                              "the controller then learns it online")
+    ap.add_argument("-t", "--train", type=int, default=0, help="train the learned model on the replay buffer every this many steps "
+                                                               "(main.py:51-52, 104-105) and push the weights into the controller; 0: never")
     ap.add_argument("--csv", type=str, default=None, help="write the (x, u, x_next) log here (DataBase::toCSV's bytes)")
     args = ap.parse_args()
     if args.new:
@@ -140,22 +148,35 @@ def main():
     if args.log and args.model:
         conf = dict(conf, model=model_dict)  # a replay finds the model in the dumped config
         write_log_dir(args.log_dir, conf, parse_config(args.task))
-    auv = model_dict["type"] == "auv"
+    learned = model_dict["type"] in ("auv_nn", "auv_nn_speed")
+    auv = model_dict["type"] == "auv" or learned
     s_dim, a_dim = conf.get("state-dim", 13 if auv else None), conf.get("action-dim", 6 if auv else None)
     model = get_model(model_dict, conf["samples"], conf["dt"], s_dim, a_dim)
-    sim = AUVSimulation(model, conf.get("x0"), conf["dt"]) if auv else Simulation(conf.get("env"), s_dim, a_dim, None, False, dt=conf["dt"],
-                                                                                  mass=model_dict.get("mass", 1.0))
+    if learned:
+        if not args.plant:
+            ap.error("a learned model needs --plant (the system it controls and learns)")
+        plant = get_model(parse_config(args.plant), 1, conf["dt"], s_dim, a_dim, name="plant")
+        learner = m.LearnerBase(model, bufferSize=max(args.steps, 1))
+    sim = AUVSimulation(plant if learned else model, conf.get("x0"), conf["dt"]) if auv else Simulation(conf.get("env"), s_dim, a_dim, None, False,
+                                                                                                         dt=conf["dt"], mass=model_dict.get("mass", 1.0))
     cost = get_cost(args.task, conf["lambda"], conf.get("gamma", 1.0), conf.get("upsilon", 1.0), conf["noise"])
     cont = m.ControllerBase(model, cost, k=conf["samples"], tau=conf["horizon"], sDim=s_dim, aDim=a_dim,
                             lam=conf["lambda"], upsilon=conf.get("upsilon", 1.0), sigma=np.asarray(conf["noise"], np.float32))
     ts = []
-    for _ in range(args.steps):
+    for step in range(args.steps):
         x = sim.getState()
         t0 = time.perf_counter()
         u = cont.next(x)
         ts.append(time.perf_counter() - t0)
         x_next = sim.step(u)
         cont.save(x, u, x_next)
+        if learned:
+            learner.add_rb(x[None], np.asarray(u, np.float32).reshape(1, -1, 1), x_next[None])
+            if args.train and (step + 1) % args.train == 0:  # main.py:104-105; the weights then travel into the live controller
+                learner.stats()
+                first, last = learner.train_all(learningRate=3e-3, epoch=200)
+                cont.update_model()
+                print("step %d: trained on %d transitions, normalised loss %.4f -> %.4f" % (step + 1, step + 1, first, last))
     steady = np.sort(ts[min(5, len(ts) - 1):])  # the first calls load the code objects
     goal_of = getattr(cost, "getGoal", None) or getattr(cost, "get_goal", None)
     if goal_of is not None and auv:  # StaticCost on 13 states / StaticQuatCost: distance in position
