@@ -644,6 +644,35 @@ def test_mlp_next_matches_oracle(m, name, kw, u_bar, factor):
     np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=u_bar)
 
 
+@pytest.mark.parametrize("a,dense", [(1, False), (2, False), (4, False), (3, True), (2, True)])
+@pytest.mark.parametrize("hid,n_hidden", [(256, 2), (32, 3)], ids=["2x256", "32x3"])
+def test_split_bf16_fused_philox_step_every_action_dim(m, a, dense, hid, n_hidden):
+    """The split-bf16 kernels (k_rollout_mlp_bx3, k_rollout_mlp32_bx3) on the fused Philox path for the action dimensions and the dense
+    Sigma that the a = 3 / diagonal tests above do not reach: the exported noise is the CPU restatement's Philox stream, costs within
+    2e-5 and U' within the split-bf16 bar of the fp64 evaluation on that noise; ragged K."""
+    K, H, s = 2000, 13, 2 * a
+    mlp = make_mlp(s, a, seed=40 + a, hid=hid, n_hidden=n_hidden)
+    rng = np.random.default_rng(a)
+    sigma = 0.25 * np.eye(a)
+    if dense:
+        L = 0.25 * np.eye(a) + 0.05 * np.tril(rng.standard_normal((a, a)), -1)
+        sigma = (L + L.T) / 2 + 0.1 * np.eye(a)
+    goal = (GOAL3 + [0.25, 0])[:s]
+    h = m.Handle(k=K, tau=H, s_dim=s, a_dim=a, lam=1.0, sigma=sigma, goal=goal, mlp=mlp, mlp_bf16x3=True, seed=3)
+    assert ("k_rollout_mlp_bx3" if hid == 256 else "k_rollout_mlp32_bx3") in h.rollout_kernel_name()
+    p64 = orc.Problem(tau=H, s=s, a=a, lam=1.0, sigma=sigma, goal=goal, mlp=mlp, threads=0, dtype=np.float64)
+    U = (0.1 * rng.standard_normal((H, a))).astype(F32)
+    h.set_action_sequence(U)
+    x = (0.2 * rng.standard_normal(s)).astype(F32)
+    u = h.next(x)
+    eps = h.debug_get(m.DBG_NOISE)
+    np.testing.assert_allclose(eps, orc.noise(3, 0, 0, K, H, a, sigma), rtol=0, atol=5e-6)
+    u_ref, U_ref, c_ref = p64.next_with_noise(x, U, eps)
+    np.testing.assert_allclose(h.debug_get(m.DBG_COSTS), c_ref, rtol=2e-5)
+    np.testing.assert_allclose(u, u_ref, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=2e-5)
+
+
 @pytest.mark.parametrize("name,kw,u_bar,factor", MLP_VARIANTS, ids=MLP_IDS)
 @pytest.mark.parametrize("K,H,lam,cond", [(65536, 8, 1.0, True), (8192, 128, 1.0, True), (512, 128, 1.0, False), (1000, 130, 8.0, True)],
                          ids=["K65536_H8", "K8192_H128", "K512_H128_illconditioned", "K1000_H130_lam8"])
