@@ -29,7 +29,8 @@
 #define MPPI_BX3_CUT 1000 // timing only: the pieces behind MFMA m >= CUT are left out (the cumulative cost of a half-step's pieces)
 #endif
 #ifndef MPPI_BX3_ABL
-#define MPPI_BX3_ABL 0 // timing-only ablations (wrong results): 1 no layer 3 / finish, 2 no preparation, 4 no barriers, 8 no layer-3 pieces, 16 no relu/split pieces
+#define MPPI_BX3_ABL 0 // timing-only ablations (wrong results): 1 no layer 3 / finish, 2 no preparation, 4 no barriers, 8 no layer-3 pieces, 16 no relu/split
+                       // pieces, 32 no B-fragment reads in the stream; -DMPPI_BX3_STAMP prints the shader clock workgroup 0 ran at (profiles/r03_bx3_pieces.txt)
 #endif
 
 namespace mppi {
