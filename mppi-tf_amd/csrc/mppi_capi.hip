@@ -122,6 +122,7 @@ static bool invert(const float *S, int n, float *out)
 static mppi_status upload_consts(mppi_handle *h)
 {
     HIP_TRY(h, hipMemcpyAsync(h->dC, &h->hc, sizeof(DevConsts), hipMemcpyHostToDevice, h->stream));
+    if (h->dCn) HIP_TRY(h, hipMemcpyAsync(h->dCn, &h->hc, sizeof(DevConsts), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MPPI_OK;
 }
@@ -139,6 +140,7 @@ extern "C" void mppi_destroy(mppi_handle *h)
     if (h->dM) (void)hipFree(h->dM);
     if (h->d_mlp_w) (void)hipFree(h->d_mlp_w);
     if (h->dC) (void)hipFree(h->dC);
+    if (h->dCn) (void)hipFree(h->dCn);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->d_clip) (void)hipFree(h->d_clip);
     if (h->d_sg_rows) (void)hipFree(h->d_sg_rows);
@@ -351,6 +353,7 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         HIP_TRY(h, hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
         HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_TRY(h, hipMalloc((void **)&h->dC, sizeof(DevConsts)));
+        if (h->normalize) HIP_TRY(h, hipMalloc((void **)&h->dCn, sizeof(DevConsts)));
         HIP_TRY(h, hipMalloc((void **)&h->d_x, sizeof(float) * kMaxS));
         for (int i = 0; i < 2; ++i) {
             HIP_TRY(h, hipMalloc((void **)&h->d_Ubuf[i], sizeof(float) * (h->HA + h->a)));
@@ -372,7 +375,7 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         }
         HIP_TRY(h, hipMalloc((void **)&h->d_record, sizeof(float) * (2 + h->HA)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dbg, sizeof(float) * 8));
-        HIP_TRY(h, hipMalloc((void **)&h->d_mm, sizeof(float) * 2));
+        HIP_TRY(h, hipMalloc((void **)&h->d_mm, sizeof(float) * 4));
         HIP_TRY(h, hipMalloc((void **)&h->d_step, sizeof(unsigned long long)));
         HIP_TRY(h, hipHostMalloc((void **)&h->h_pin, sizeof(float) * (2 * kMaxS + kMaxA), hipHostMallocMapped));
         HIP_TRY(h, hipHostGetDevicePointer((void **)&h->d_pin, h->h_pin, 0));
@@ -443,10 +446,11 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
 {
     // a profiled step = the rollout kernel + the finish that applies the update
     const bool prof = apply && h->prof_n < h->prof_cap;
+    const float *nil_dev = h->norm_two_pass ? h->d_mm + 2 : nullptr; // this step's records were made at the temperature k_cost_minmax left there
     float *out = h->d_part2;
     while (nb > 1024) {
         const int ng = (nb + kGroup - 1) / kGroup;
-        hipLaunchKernelGGL(k_combine_group, dim3(ng), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->hc.neg_inv_lambda, out);
+        hipLaunchKernelGGL(k_combine_group, dim3(ng), dim3(kThreads), 0, st, recs, sb, sc, nb, h->HA, h->hc.neg_inv_lambda, out, nil_dev);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         recs = out; sb = 2 + h->HA; sc = 1; nb = ng;
@@ -460,7 +464,7 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
                               h->xchg_timeout_ticks, h->d_xchg_status, h->d_xchg_dead, (const float *)h->d_clip);
     else
         hipExtLaunchKernelGGL(k_finish_cols, dim3(h->HA), dim3(kThreads), 0, st, f0, f1, 0, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
-                              U_in, U_out, u_out, record_out, apply, h->d_step, h->d_dbg, (const float *)h->d_clip);
+                              U_in, U_out, u_out, record_out, apply, h->d_step, h->d_dbg, (const float *)h->d_clip, nil_dev);
     hipError_t e = hipGetLastError();
     if (prof && e == hipSuccess) { h->prof_stream = st; h->prof_n++; }
     return e;
@@ -591,6 +595,7 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
     const bool mlp = h->hc.model_kind == MPPI_MODEL_MLP;
     const bool gen = h->is_gen != 0;
     *nrec = h->nbp; // every slot: those no tile owns hold neutral records
+    h->norm_two_pass = 0;
     HIP_TRY(h, ensure_record_layout(h, st, (mlp && !h->normalize) ? h->nb_mlp : h->nb)); // (normalizeCost: the tile kernel writes the records)
     if (!h->normalize) {
         const bool prof = h->prof_n < h->prof_cap;
@@ -611,13 +616,34 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
     if (h->shard_count != 1) return fail(h, MPPI_ERR_UNSUPPORTED, "normalize_cost needs the global max cost: unsharded handles only");
     // Py normalizeCost (controller_base.py:468-474): costs, global min/max, then the update on
     // c' = (c-min)/(max-min) with the SAME noise (regenerated from the same Philox counters).
+    if (!mlp && !gen && src == SRC_PHILOX && noise_out == nullptr && pc_eligible(h)) {
+        // Fast form on the producer/consumer kernel (r03): exp(-(c' - min c')/lambda) = exp(-(c - min c)/(lambda (max - min))), so the
+        // normalised update is the plain one at another temperature. Pass 1 at lambda for the costs; k_cost_minmax leaves
+        // -1/(lambda (max-min)) in the second DevConsts copy; pass 2 (same Philox counters: the same rollouts) makes the records at that
+        // temperature and the finish combines them at it. 2 x 16 us + 5 instead of the tile kernel's cost pass + record pass (76 -> 40 us at C3).
+        const bool prof2 = h->prof_n < h->prof_cap;
+        h->kev0 = h->kev1 = nullptr;
+        HIP_TRY(h, launch_pc(h, st, x_dev));
+        hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(1024), 0, st, h->d_cost, h->K_local, h->d_mm, h->hc.neg_inv_lambda, &h->dCn->neg_inv_lambda);
+        HIP_TRY(h, hipGetLastError());
+        h->kev0 = prof2 ? h->ev[4 * h->prof_n + 0] : nullptr; // a profiled step reports the second pass (the one whose records are used)
+        h->kev1 = prof2 ? h->ev[4 * h->prof_n + 1] : nullptr;
+        DevConsts *plain = h->dC;
+        h->dC = h->dCn;
+        const hipError_t le = launch_pc(h, st, x_dev);
+        h->dC = plain;
+        h->kev0 = h->kev1 = nullptr;
+        HIP_TRY(h, le);
+        h->norm_two_pass = 1;
+        return MPPI_OK;
+    }
     const bool prof_n = h->prof_n < h->prof_cap; // a profiled step brackets the cost pass (the dominant launch) here
     if (prof_n) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 0], st));
     if (gen) HIP_TRY(h, mppi_launch_gen(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out));
     else if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost));
     else HIP_TRY(h, launch_tile(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out));
     if (prof_n) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 1], st));
-    hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(kFinishThreads), 0, st, h->d_cost, h->K_local, h->d_mm);
+    hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(1024), 0, st, h->d_cost, h->K_local, h->d_mm, 0.0f, (float *)nullptr);
     HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(k_cost_normalize, dim3((h->K_local + 255) / 256), dim3(256), 0, st, h->d_cost, h->K_local, h->d_mm, h->d_cost2);
     HIP_TRY(h, hipGetLastError());
@@ -660,7 +686,7 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
         else if (h->mlp_v2 && !h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp2<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
         else if (h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp_bx3<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
         else std::snprintf(buf, n, "mppi::k_rollout_mlp<%d, %s>", h->a, h->sigma_diag ? "true" : "false");
-    else if (!h->normalize && pc_eligible(h))
+    else if (pc_eligible(h)) // (normalizeCost: two passes of it on the fused path; injected noise runs the tile kernel)
         std::snprintf(buf, n, "mppi::k_rollout_pc<%d, %d, %d, %s>", h->a, h->pc_np,
                       h->pc_np == 3 ? (NG <= 18 ? 6 : 11) : (NG <= 20 ? 4 : 8), h->sigma_diag ? "true" : "false");
     else
@@ -1111,8 +1137,9 @@ extern "C" mppi_status mppi_debug_get(mppi_handle *h, int what, float *out, size
         need = K;
         if (n != need) return fail(h, MPPI_ERR_INVALID_ARG, "wrong output size");
         HIP_TRY(h, hipMalloc((void **)&tmp, sizeof(float) * K));
-        hipLaunchKernelGGL(k_weights, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, h->stream, h->dC,
-                           h->normalize ? h->d_cost2 : h->d_cost, (int)K, h->d_dbg, (float *)nullptr, (float *)nullptr, tmp);
+        // (two-pass normalizeCost: the raw costs at the step's temperature = the normalised costs at lambda)
+        hipLaunchKernelGGL(k_weights, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, h->stream, h->norm_two_pass ? h->dCn : h->dC,
+                           (h->normalize && !h->norm_two_pass) ? h->d_cost2 : h->d_cost, (int)K, h->d_dbg, (float *)nullptr, (float *)nullptr, tmp);
         src = tmp;
         break;
     }
@@ -1329,6 +1356,7 @@ extern "C" mppi_status mppi_update(mppi_handle *h, const float *cost, const floa
     // record = (beta, eta, V); then U' on a scratch copy of U (apply shifts it, so read U_updated)
     unsigned long long step_before = 0;
     HIP_TRY(h, hipMemcpyAsync(&step_before, h->d_step, sizeof(step_before), hipMemcpyDeviceToHost, h->stream));
+    h->norm_two_pass = 0; // records made from the GIVEN costs at lambda
     HIP_TRY(h, launch_finish(h, h->stream, h->d_part, 1, h->nbp, h->nbp, dU.p, dUn.p, du.p, drec.p, 1));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_step, &step_before, sizeof(step_before), hipMemcpyHostToDevice, h->stream)); // stateless call

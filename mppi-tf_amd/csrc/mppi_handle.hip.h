@@ -18,6 +18,8 @@ struct mppi_handle {
     hipStream_t stream = nullptr;
     DevConsts hc{};
     DevConsts *dC = nullptr;
+    int norm_two_pass = 0;    // this step's records come from the second pass of the two-pass normalizeCost path (set per step)
+    DevConsts *dCn = nullptr; // normalize_cost: a second copy whose neg_inv_lambda k_cost_minmax rewrites every step (the second pass reads it)
     int K_global = 0, K_local = 0, k_offset = 0, shard_rank = 0, shard_count = 1;
     int H = 0, s = 0, a = 0, HA = 0;
     int R = 64, nb = 0;   // tile size / record count of the point-mass tile kernels

@@ -485,8 +485,9 @@ constexpr int kGroup = 16;
 // Input element (b, col) at recs[b*sb + col*sc]; output records are row-major [ng, 2+HA].
 #if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ __launch_bounds__(kThreads) void k_combine_group(
-    const float *__restrict__ recs, int sb, int sc, int nb, int HA, float neg_inv_lambda, float *__restrict__ out)
+    const float *__restrict__ recs, int sb, int sc, int nb, int HA, float neg_inv_lambda, float *__restrict__ out, const float *__restrict__ nil_dev)
 {
+    if (nil_dev != nullptr) neg_inv_lambda = nil_dev[0]; // two-pass normalizeCost: the temperature of this step (k_cost_minmax)
     const int stride = 2 + HA;
     const int b0 = blockIdx.x * kGroup;
     const int n = min(kGroup, nb - b0);
@@ -601,11 +602,12 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols(
     const float *__restrict__ recs, int sb, int sc, int nb, int /*HA*/, int a, float neg_inv_lambda,
     const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
     float *__restrict__ record_out, int apply, unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg,
-    const float *__restrict__ clip)
+    const float *__restrict__ clip, const float *__restrict__ nil_dev)
 {
     __shared__ float red_f[kThreads / 64];
     __shared__ double red_d[2][kThreads / 64];
     const int c = blockIdx.x, tid = threadIdx.x;
+    if (nil_dev != nullptr) neg_inv_lambda = nil_dev[0]; // two-pass normalizeCost: the temperature of this step (k_cost_minmax)
     const float u_old = U_in[c];
     const unsigned long long step_old = step_ctr[0];
     float lo = -INFINITY, hi = INFINITY; // clip_act (controller_base.py:500-504): [a_min | a_max], NULL = off
@@ -1082,18 +1084,30 @@ namespace mppi {
 
 // min / max of the costs (Py normalizeCost, controller_base.py:468-474): out[0]=min, out[1]=max-min
 #if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
-__global__ __launch_bounds__(kFinishThreads) void k_cost_minmax(const float *__restrict__ cost, int K, float *__restrict__ out)
+// nil_out != NULL: also out[2] = *nil_out = neg_inv_lambda / (max - min) — the soft-min temperature at which the RAW costs weigh
+// as the normalised ones do at lambda (exp(-(c'-min c')/lambda) = exp(-(c-min c)/(lambda (max-min)))): the second rollout pass of
+// the two-pass normalizeCost path reads it from a DevConsts copy, the finish from out[2]
+__global__ __launch_bounds__(1024) void k_cost_minmax(const float *__restrict__ cost, int K, float *__restrict__ out,
+                                                      float neg_inv_lambda, float *__restrict__ nil_out)
 {
-    __shared__ float mn_s[kFinishThreads / 64], mx_s[kFinishThreads / 64];
-    const int tid = threadIdx.x;
+    __shared__ float mn_s[16], mx_s[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
     float mn = INFINITY, mx = -INFINITY;
-    for (int i = tid; i < K; i += kFinishThreads) { const float c = cost[i]; mn = fminf(mn, c); mx = fmaxf(mx, c); }
+    const int K4 = K >> 2; // 16-byte loads (hipMalloc'd buffer), the tail one by one
+    const float4 *c4 = reinterpret_cast<const float4 *>(cost);
+    for (int i = tid; i < K4; i += nt) {
+        const float4 v = c4[i];
+        mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+        mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    }
+    for (int i = 4 * K4 + tid; i < K; i += nt) { const float c = cost[i]; mn = fminf(mn, c); mx = fmaxf(mx, c); }
     mn = wave_min(mn); mx = wave_max(mx);
     if ((tid & 63) == 0) { mn_s[tid >> 6] = mn; mx_s[tid >> 6] = mx; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < kFinishThreads / 64; ++w) { mn = fminf(mn, mn_s[w]); mx = fmaxf(mx, mx_s[w]); }
+        for (int w = 1; w < nt / 64; ++w) { mn = fminf(mn, mn_s[w]); mx = fmaxf(mx, mx_s[w]); }
         out[0] = mn; out[1] = mx - mn;
+        if (nil_out != nullptr) { const float v = neg_inv_lambda / (mx - mn); out[2] = v; *nil_out = v; }
     }
 }
 #endif

@@ -218,6 +218,31 @@ def test_next_with_noise_normalize_cost(m):
     np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=U_TOL)
 
 
+@pytest.mark.parametrize("K,H,a,lam", [(2000, 20, 3, 0.05), (65536, 64, 3, 1.0), (4096, 32, 2, 0.2), (300, 7, 1, 0.1), (512, 24, 4, 0.5)])
+def test_normalize_cost_on_the_fused_path(m, K, H, a, lam):
+    """normalizeCost=True on the fused Philox path (what scripts/main.py builds, controller_base.py:468-474). For the point-mass / diagonal-Q
+    configuration this is TWO passes of the producer/consumer kernel: exp(-(c'-min c')/lambda) = exp(-(c-min c)/(lambda (max-min))), so the
+    second pass makes the records of the RAW costs at the temperature the first pass's min / max define. Against the fp64 oracle's normalised
+    update on the exported noise; the weights it reports are the normalised ones; a step without normalisation afterwards (another handle)
+    is unaffected."""
+    h, p = make_pair(m, K, H, a, normalize=True, lam=lam)
+    p64 = orc.Problem(tau=H, s=2 * a, a=a, lam=lam, sigma=0.25 * np.eye(a), goal=(GOAL3 + [0.25, 0])[:2 * a], threads=0, dtype=np.float64)
+    x = (np.array([0.1, 0, -0.2, 0, 0.3, 0, 0.05, 0])[:2 * a]).astype(F32)
+    U_in = h.get_action_sequence()
+    for step in range(2):
+        u = h.next(x)
+        eps = h.debug_get(m.DBG_NOISE)
+        u_ref, U_ref, c_ref = p64.next_with_noise(x, U_in, eps, normalize=True)
+        np.testing.assert_allclose(h.debug_get(m.DBG_COSTS), c_ref, rtol=2e-6)
+        np.testing.assert_allclose(u, u_ref, rtol=0, atol=U_TOL)
+        np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=U_TOL)
+        w = h.debug_get(m.DBG_WEIGHTS).astype(np.float64)
+        cn = (c_ref - c_ref.min()) / (c_ref.max() - c_ref.min())
+        w_ref = np.exp(-cn / lam)
+        np.testing.assert_allclose(w, w_ref / w_ref.sum(), rtol=2e-4, atol=1e-9)
+        U_in = h.get_action_sequence()
+
+
 # =============================================================== A2: on-device noise
 def test_device_noise_matches_oracle_restatement(m):
     """Philox4x32-10 counters are restated bit-exactly by the oracle; Box-Muller differs only through
