@@ -409,11 +409,11 @@ static hipError_t launch_tile(mppi_handle *h, hipStream_t st, int src, int mode,
     return hipErrorInvalidValue;
 }
 
-// diagonal-Q handles only (a dense Q runs the tile kernel); horizon groups per producer must fit the registers
+// the point-mass model with the quadratic (diagonal or dense Q) or the elliptic state cost; horizon groups per producer must fit the registers
 static bool pc_eligible(const mppi_handle *h)
 {
-    return !h->is_gen && h->no_rollout.empty() && h->R == 64 && !h->hc.q_full && !h->force_tile && h->H <= (h->pc_np == 3 ? 132 : 160) &&
-           h->hc.state_cost_kind == MPPI_STATE_COST_QUADRATIC; // other costs run the general tile kernel
+    const bool cost_ok = h->hc.state_cost_kind == MPPI_STATE_COST_QUADRATIC || (h->hc.state_cost_kind == MPPI_STATE_COST_ELLIPSE && h->s >= 4 && !h->hc.q_full);
+    return !h->is_gen && h->no_rollout.empty() && h->R == 64 && !h->force_tile && h->H <= (h->pc_np == 3 ? 132 : 160) && cost_ok;
 }
 
 static hipError_t launch_pc(mppi_handle *h, hipStream_t st, const float *x_dev)
@@ -687,8 +687,15 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
         else if (h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp_bx3<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
         else std::snprintf(buf, n, "mppi::k_rollout_mlp<%d, %s>", h->a, h->sigma_diag ? "true" : "false");
     else if (pc_eligible(h)) // (normalizeCost: two passes of it on the fused path; injected noise runs the tile kernel)
-        std::snprintf(buf, n, "mppi::k_rollout_pc<%d, %d, %d, %s>", h->a, h->pc_np,
-                      h->pc_np == 3 ? (NG <= 18 ? 6 : 11) : (NG <= 20 ? 4 : 8), h->sigma_diag ? "true" : "false");
+    {
+        const int ck = h->hc.state_cost_kind == MPPI_STATE_COST_ELLIPSE ? 1 : (h->hc.q_full ? 2 : 0); // PC_COST_*
+        if (ck == 0)
+            std::snprintf(buf, n, "mppi::k_rollout_pc<%d, %d, %d, %s>", h->a, h->pc_np,
+                          h->pc_np == 3 ? (NG <= 18 ? 6 : 11) : (NG <= 20 ? 4 : 8), h->sigma_diag ? "true" : "false");
+        else
+            std::snprintf(buf, n, "mppi::k_rollout_pc<%d, %d, %d, %s, %d>", h->a, h->pc_np,
+                          h->pc_np == 3 ? (NG <= 18 ? 6 : 11) : (NG <= 20 ? 4 : 8), h->sigma_diag ? "true" : "false", ck);
+    }
     else
         std::snprintf(buf, n, "mppi::k_rollout_tile<%d, %d, %s, 0, %d>", h->a, h->R, h->hc.q_full ? "true" : "false", h->normalize ? 2 : 0);
     return MPPI_OK;

@@ -335,8 +335,8 @@ __device__ __forceinline__ float state_cost(const CT *__restrict__ C, const floa
 // costs/elipse_cost.py:48-85 ElipseCost.state_cost, state = (x, vx, y, vy, ...): in the reference's operation order, every
 // operation rounded on its own (correctly rounded divide and square root: hipcc's default for fp32):
 //   v = sqrt(vx² + vy²) ; dx = (x-cx)/a ; dy = (y-cy)/b ; m_state·|dx² + dy² - 1| + m_vel·(v - speed)²
-template <int S>
-__device__ __forceinline__ float state_cost_ellipse(const DevConsts *__restrict__ C, const float (&x)[S])
+template <int S, class CT = DevConsts>
+__device__ __forceinline__ float state_cost_ellipse(const CT *__restrict__ C, const float (&x)[S])
 {
     static_assert(S >= 4, "the elliptic cost reads (x, vx, y, vy)");
     const float vx2 = x[1] * x[1], vy2 = x[3] * x[3];
@@ -351,6 +351,48 @@ __device__ __forceinline__ float state_cost_ellipse(const DevConsts *__restrict_
     float dv = dvv * dvv;
     dv = C->ell[6] * dv;
     return d + dv;
+}
+
+// Kernel-local constants of the two other cost_base forms the producer/consumer kernel's consumer serves (COST = 1, 2): the
+// elliptic cost's seven numbers; a dense Q, compact [S][S], with the goal. Same arithmetic as state_cost_ellipse / state_cost<S, true>.
+struct PcEllipseConsts {
+    float ell[7];
+    __device__ __forceinline__ void load(const DevConsts *__restrict__ C)
+    {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) ell[i] = C->ell[i];
+    }
+};
+template <int S>
+struct PcDenseQConsts {
+    float goal[S], q[S * S];
+    __device__ __forceinline__ void load(const DevConsts *__restrict__ C)
+    {
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            goal[i] = C->goal[i];
+#pragma unroll
+            for (int j = 0; j < S; ++j) q[i * S + j] = C->qfull[i * kMaxS + j];
+        }
+    }
+};
+template <int S>
+__device__ __forceinline__ float state_cost_dense(const PcDenseQConsts<S> *__restrict__ C, const float (&x)[S])
+{
+    float diff[S], left[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) diff[i] = x[i] - C->goal[i];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < S; ++j) acc = acc + C->q[i * S + j] * diff[j];
+        left[i] = acc;
+    }
+    float acc = diff[0] * left[0];
+#pragma unroll
+    for (int i = 1; i < S; ++i) acc = acc + diff[i] * left[i];
+    return acc;
 }
 
 // the cost_base slot of the tile kernel and the helpers: the state cost the controller was built with (wave-uniform branch)

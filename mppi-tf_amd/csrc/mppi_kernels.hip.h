@@ -239,7 +239,10 @@ __device__ __forceinline__ void pc_set_prio(int i, int n, int gen)
 __host__ __device__ constexpr int pc_slot_floats(int A) { return A == 1 ? 2 : (A == 2 || A == 3) ? 4 : A + 1; }
 __host__ __device__ inline size_t pc_lds_floats(int A, int NP) { return (size_t)2 * 4 * NP * pc_slot_floats(A) * 64; }
 
-template <int A, int NP, int NSLOT, bool DIAG>
+// COST: the cost_base form of the consumer — 0 quadratic with a diagonal Q (the BASELINE configurations), 1 ElipseCost (s >= 4),
+// 2 quadratic with a dense Q. A template parameter, so the instances of the hot configuration are what they were.
+enum { PC_COST_DIAG = 0, PC_COST_ELLIPSE = 1, PC_COST_DENSE = 2 };
+template <int A, int NP, int NSLOT, bool DIAG, int COST = PC_COST_DIAG>
 __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) void k_rollout_pc(
     const DevConsts *__restrict__ C, const float *__restrict__ x_dev, const float *__restrict__ U_dev,
     const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
@@ -400,6 +403,15 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
         PcConsumerConsts<S> ccst;
         ccst.load(C);
         const PcConsumerConsts<S> *CC = &ccst;
+        PcEllipseConsts ecst;
+        PcDenseQConsts<S> qcst;
+        if constexpr (COST == PC_COST_ELLIPSE) ecst.load(C);
+        if constexpr (COST == PC_COST_DENSE) qcst.load(C);
+        auto cost_of = [&](const float (&xs)[S]) {
+            if constexpr (COST == PC_COST_ELLIPSE) return state_cost_ellipse<S>(&ecst, xs);
+            else if constexpr (COST == PC_COST_DENSE) return state_cost_dense<S>(&qcst, xs);
+            else return state_cost<S, false>(CC, xs);
+        };
         float c = 0.0f;
         MPPI_STAMP(0);
         MPPI_STAMP_RT(62);
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
                     ac = cb[(tl * (A + 1) + A) * 64 + lane];
                 }
                 pm_step<A>(CC, x, v);
-                const float sc = state_cost<S, false>(CC, x); // cost on the POST-step state
+                const float sc = cost_of(x);                  // cost on the POST-step state
                 const float tmp = sc + ac;                    // Step_cost_result cost_base.cpp:49
                 c = c + tmp;                                  // path_cost        controller_base.cpp:268
             }
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
             MPPI_STAMP(2 + (ch < 7 ? ch : 6));
             if (ch + 1 < nch) __syncthreads(); // chunk ch consumed / chunk ch+1 published
         }
-        c = c + state_cost<S, false>(CC, x); // terminal: x_H counted a second time, :271-272
+        c = c + cost_of(x); // terminal: x_H counted a second time, :271-272
 #if !defined(MPPI_PC_TIMELINE)
         if (valid) cost[k0 + lane] = c;
 #endif

@@ -5,8 +5,8 @@
 #endif
 
 // the hot configuration: producer/consumer kernel (k_rollout_pc) when the horizon fits its register file
-template <int A, int NP, int NSLOT>
-static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_dev)
+template <int A, int NP, int NSLOT, int COST>
+static hipError_t launch_pc_cost(mppi_handle *h, hipStream_t st, const float *x_dev)
 {
     const size_t lds = std::max(pc_lds_floats(A, NP) * 4, (size_t)h->pc_lds_min);
     const int nb = (h->K_local + 63) / 64;
@@ -17,10 +17,21 @@ static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_
     const DevConsts *dC = h->dC;
     const float *U = h->U_cur();
     const unsigned long long *stp = h->d_step;
-    if (hipError_t e = mppi_raise_lds_ceiling(h->sigma_diag ? reinterpret_cast<const void *>(k_rollout_pc<A, NP, NSLOT, true>) : reinterpret_cast<const void *>(k_rollout_pc<A, NP, NSLOT, false>), h->device, lds); e != hipSuccess) return e;
-    if (h->sigma_diag) hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
-    else hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
+    if (hipError_t e = mppi_raise_lds_ceiling(h->sigma_diag ? reinterpret_cast<const void *>(k_rollout_pc<A, NP, NSLOT, true, COST>) : reinterpret_cast<const void *>(k_rollout_pc<A, NP, NSLOT, false, COST>), h->device, lds); e != hipSuccess) return e;
+    if (h->sigma_diag) hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true, COST>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
+    else hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false, COST>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
     return hipGetLastError();
+}
+
+// the consumer's cost form: diagonal Q (the hot configuration), ElipseCost (elipse_cost.py:9-85; s >= 4), dense Q (static_cost.py:23-63)
+template <int A, int NP, int NSLOT>
+static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_dev)
+{
+    if constexpr (A >= 2) {
+        if (h->hc.state_cost_kind == MPPI_STATE_COST_ELLIPSE) return launch_pc_cost<A, NP, NSLOT, PC_COST_ELLIPSE>(h, st, x_dev);
+    }
+    if (h->hc.q_full) return launch_pc_cost<A, NP, NSLOT, PC_COST_DENSE>(h, st, x_dev);
+    return launch_pc_cost<A, NP, NSLOT, PC_COST_DIAG>(h, st, x_dev);
 }
 
 hipError_t MPPI_CAT(mppi_launch_pc_a, MPPI_UNIT_A)(MPPI_PC_PARAMS)

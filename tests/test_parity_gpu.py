@@ -334,6 +334,47 @@ def test_replay_is_deterministic(m):
     assert not np.array_equal(h2.next(x), make_pair(m, K, H, a, seed=11)[0].next(x))
 
 
+ELL = dict(a=1.5, b=0.8, cx=0.2, cy=-0.1, speed=0.7, m_state=2.0, m_vel=0.5)
+
+
+@pytest.mark.parametrize("K,H,a,kind", [(65536, 64, 3, "dense"), (5000, 24, 3, "dense"), (4096, 64, 2, "dense"), (777, 9, 1, "dense"), (2048, 16, 4, "dense"),
+                                        (65536, 64, 3, "ellipse"), (5000, 24, 2, "ellipse"), (2048, 16, 4, "ellipse")])
+def test_producer_consumer_kernel_with_the_other_cost_forms(m, K, H, a, kind):
+    """k_rollout_pc<..., COST>: the consumer's cost_base form is a template parameter (r03) — a dense Q (static_cost.py:23-63) and ElipseCost
+    (elipse_cost.py:9-85) ride the hot kernel instead of the tile kernel (68 -> 25 us at C3). Costs bit-identical to the tile kernel's and
+    to the fp32 CPU restatement's on the same Philox counters, the update within rounding; normalizeCost on top takes the two-pass form."""
+    s = 2 * a
+    rng = np.random.default_rng(K)
+    x = (0.1 * np.arange(s)).astype(F32)
+    if kind == "dense":
+        B = rng.standard_normal((s, s))
+        kw = dict(Q=(np.eye(s) + 0.05 * (B + B.T)).astype(F32), q_full=True)
+        okw = dict(Q=kw["Q"])
+    else:
+        kw, okw = dict(ellipse=ELL), dict(ellipse=ELL)
+    mk = lambda **t: m.Handle(k=K, tau=H, s_dim=s, a_dim=a, lam=1.0, sigma=0.25 * np.eye(a), goal=(GOAL3 + [0.25, 0])[:s], seed=5,
+                              Q=kw.get("Q"), q_is_full=kw.get("q_full"), ellipse=kw.get("ellipse"), **t)
+    hp, ht = mk(), mk(tuning={"force_tile_kernel": 1})
+    assert hp.rollout_kernel_name().endswith(", 2>" if kind == "dense" else ", 1>") and "k_rollout_tile" in ht.rollout_kernel_name()
+    p32 = orc.Problem(tau=H, s=s, a=a, lam=1.0, sigma=0.25 * np.eye(a), goal=(GOAL3 + [0.25, 0])[:s], threads=0, **okw)
+    for _ in range(2):
+        U_in = hp.get_action_sequence()
+        up, ut = hp.next(x), ht.next(x)
+        cp = hp.debug_get(m.DBG_COSTS)
+        np.testing.assert_array_equal(cp, ht.debug_get(m.DBG_COSTS))
+        np.testing.assert_allclose(up, ut, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(hp.get_action_sequence(), ht.get_action_sequence(), rtol=0, atol=1e-6)
+        eps = hp.debug_get(m.DBG_NOISE)
+        u_ref, U_ref, c_ref = p32.next_with_noise(x, U_in, eps)
+        np.testing.assert_array_equal(cp, c_ref)
+        np.testing.assert_allclose(hp.get_action_sequence(), U_ref, rtol=0, atol=U_TOL)
+        ht.set_action_sequence(hp.get_action_sequence())
+    hn = mk(normalize_cost=True)
+    un = hn.next(x)
+    _, Un_ref, _ = p32.next_with_noise(x, np.zeros((H, a), F32), hn.debug_get(m.DBG_NOISE), normalize=True)
+    np.testing.assert_allclose(hn.get_action_sequence(), Un_ref, rtol=0, atol=2 * U_TOL)
+
+
 # =============================================================== §8e: K-sharding records
 @pytest.mark.parametrize("shards", [2, 8])
 def test_sharded_records_combine_to_the_unsharded_step(m, shards):
