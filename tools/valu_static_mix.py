@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static VALU opcode mix of ONE kernel in libmppi_hip.so, from the gfx950 code objects themselves (llvm-objdump -d):
-   tools/valu_static_mix.py 'k_rollout_pc<3, 3, 6, true>' [out.json]
+   tools/valu_static_mix.py 'k_rollout_pc<3, 3, 6, true, 0>' [out.json]
 Used to price the `other` class of the VALU-issue floor (tools/summarize_profiles.py): the SQ counters give the launch's
 vector instructions by class (add/mul/fma/trans f32, int32, int64, cvt) and lump the rest — moves, v_bitop3_b32, DPP forms,
 lane swaps, selects, bit-field ops — into one number; this script says what that rest is made of. The producer waves of
