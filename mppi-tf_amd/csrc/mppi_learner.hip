@@ -7,7 +7,7 @@
 //                    wave accumulates a 32x32 tile over its slice of the samples (the bias gradient rides along as a second MFMA
 //                    against a row of ones), fixed-order reduction over the waves, one partial tile per workgroup
 //   k_learn_adam     partial tiles summed in fixed order, Adam (Keras form: w -= lr sqrt(1-b2^t)/(1-b1^t) m/(sqrt(v)+eps)),
-//                    the step counter and the loss live on the device: a train loop needs no host round trip
+//                    the step counter (advanced by the forward pass) and the loss live on the device: a train loop needs no host round trip
 // Deterministic: no float atomics anywhere. All dimensions are padded to 32 (zero weights / activations in the padding).
 #include <hip/hip_runtime.h>
 
@@ -22,7 +22,7 @@ namespace {
 
 constexpr int W32 = 32;            // padded width of every layer
 constexpr int kMaxLayers = 4;
-constexpr int kChunk = 4096;       // samples per workgroup of k_learn_grad
+constexpr int kChunk = 512;        // samples per workgroup of k_learn_grad (r03: 4096 left 8 workgroups on 256 CUs: 180 us per step at n = 8192)
 constexpr int kGradThreads = 256;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -35,7 +35,7 @@ struct Net { // device pointers; weights padded: W[l] is [32][32] ([in][out]), b
 // D[l] ([n][32]: dLoss/d(pre-activation of layer l)) are what the gradient GEMMs read. loss_part[block] = sum of squared errors.
 __global__ __launch_bounds__(256) void k_learn_fwd_bwd(const Net net, const float *__restrict__ X, const float *__restrict__ Y, int n,
                                                        float *__restrict__ A, float *__restrict__ D, float *__restrict__ loss_part,
-                                                       float *__restrict__ pred_out)
+                                                       float *__restrict__ pred_out, int *__restrict__ step, int apply)
 {
     __shared__ float w_s[kMaxLayers][W32 * W32];
     __shared__ float b_s[kMaxLayers][W32];
@@ -110,6 +110,8 @@ __global__ __launch_bounds__(256) void k_learn_fwd_bwd(const Net net, const floa
     if ((tid & 63) == 0) red_s[tid >> 6] = se;
     __syncthreads();
     if (tid == 0) loss_part[blockIdx.x] = ((red_s[0] + red_s[1]) + red_s[2]) + red_s[3];
+    // the optimiser step this pass belongs to: advanced HERE, two launches ahead of the Adam kernel whose workgroups all read it
+    if (apply && blockIdx.x == 0 && tid == 0) step[0] = step[0] + 1;
 }
 
 // dW_l = A_l^T D_l and db_l = 1^T D_l over the samples of one chunk: grid (chunks, layers), 4 waves per workgroup.
@@ -151,39 +153,36 @@ struct AdamState { float *m[kMaxLayers], *v[kMaxLayers], *mb[kMaxLayers], *vb[kM
 // loss_out = the loss of THIS step's forward pass (before the update); grads_out optional.
 __global__ __launch_bounds__(256) void k_learn_adam(const Net net, AdamState st, const float *__restrict__ part, int chunks,
                                                     const float *__restrict__ loss_part, int loss_blocks, int n,
-                                                    float lr, float b1, float b2, float eps, int *__restrict__ step, float *__restrict__ loss_out,
+                                                    float lr, float b1, float b2, float eps, const int *__restrict__ step, float *__restrict__ loss_out,
                                                     float *__restrict__ grads_out, int apply)
 {
-    const int L = net.n_layers, tid = threadIdx.x; // ONE workgroup: every thread reads the step before anyone advances it
-    const int t = step[0] + 1;
+    // grid (layers, ceil(33 * 32 / 256)): one thread per weight / bias. The step counter was advanced by this step's forward pass.
+    const int L = net.n_layers, l = blockIdx.x, tid = threadIdx.x, e = blockIdx.y * 256 + tid;
+    const int t = apply ? step[0] : step[0] + 1;
     const float bc1 = 1.0f - powf(b1, (float)t), bc2 = 1.0f - powf(b2, (float)t);
     const float lr_t = lr * sqrtf(bc2) / bc1;
-    for (int l = 0; l < L; ++l) {
-        for (int e = tid; e < 33 * W32; e += 256) {
-            float g = 0.0f;
-            for (int c = 0; c < chunks; ++c) g += part[((size_t)c * L + l) * 33 * W32 + e];
-            const int row = e / W32, col = e % W32;
-            const bool is_b = row == 32;
-            const bool live = col < net.width[l + 1] && (is_b || row < net.width[l]); // padding stays exactly zero
-            if (!live) g = 0.0f;
-            if (grads_out != nullptr) grads_out[(size_t)l * 33 * W32 + e] = g;
-            if (apply && live) {
-                float *w = is_b ? net.b[l] + col : net.W[l] + row * W32 + col;
-                float *m = is_b ? st.mb[l] + col : st.m[l] + row * W32 + col;
-                float *v = is_b ? st.vb[l] + col : st.v[l] + row * W32 + col;
-                const float mn = b1 * *m + (1.0f - b1) * g, vn = b2 * *v + (1.0f - b2) * g * g;
-                *m = mn; *v = vn;
-                *w = *w - lr_t * mn / (sqrtf(vn) + eps);
-            }
+    if (e < 33 * W32) {
+        float g = 0.0f;
+        for (int c = 0; c < chunks; ++c) g += part[((size_t)c * L + l) * 33 * W32 + e]; // fixed order: deterministic
+        const int row = e / W32, col = e % W32;
+        const bool is_b = row == 32;
+        const bool live = col < net.width[l + 1] && (is_b || row < net.width[l]); // padding stays exactly zero
+        if (!live) g = 0.0f;
+        if (grads_out != nullptr) grads_out[(size_t)l * 33 * W32 + e] = g;
+        if (apply && live) {
+            float *w = is_b ? net.b[l] + col : net.W[l] + row * W32 + col;
+            float *m = is_b ? st.mb[l] + col : st.m[l] + row * W32 + col;
+            float *v = is_b ? st.vb[l] + col : st.v[l] + row * W32 + col;
+            const float mn = b1 * *m + (1.0f - b1) * g, vn = b2 * *v + (1.0f - b2) * g * g;
+            *m = mn; *v = vn;
+            *w = *w - lr_t * mn / (sqrtf(vn) + eps);
         }
     }
-    if (tid == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
         float s = 0.0f;
         for (int q = 0; q < loss_blocks; ++q) s += loss_part[q];
         loss_out[0] = s / ((float)n * (float)net.width[L]);
     }
-    __syncthreads();
-    if (tid == 0 && apply) step[0] = t;
 }
 
 } // namespace
@@ -319,12 +318,12 @@ static mppi_status enqueue_step(mppi_learner *l, float lr, float b1, float b2, f
 {
     const int L = l->net.n_layers;
     hipLaunchKernelGGL(k_learn_fwd_bwd, dim3(l->blocks), dim3(256), 0, l->stream, l->net, (const float *)l->dX, (const float *)l->dY, l->n, l->dA, l->dD,
-                       l->d_loss_part, pred_dev);
+                       l->d_loss_part, pred_dev, l->d_step, apply);
     L_TRY(l, hipGetLastError());
     hipLaunchKernelGGL(k_learn_grad, dim3(l->chunks, L), dim3(kGradThreads), 0, l->stream, (const float *)l->dA, (const float *)l->dD, l->n, l->d_part);
     L_TRY(l, hipGetLastError());
-    hipLaunchKernelGGL(k_learn_adam, dim3(1), dim3(256), 0, l->stream, l->net, l->adam, (const float *)l->d_part, l->chunks, (const float *)l->d_loss_part,
-                       l->blocks, l->n, lr, b1, b2, eps, l->d_step, l->d_loss, l->d_grads, apply);
+    hipLaunchKernelGGL(k_learn_adam, dim3(L, (33 * W32 + 255) / 256), dim3(256), 0, l->stream, l->net, l->adam, (const float *)l->d_part, l->chunks,
+                       (const float *)l->d_loss_part, l->blocks, l->n, lr, b1, b2, eps, (const int *)l->d_step, l->d_loss, l->d_grads, apply);
     L_TRY(l, hipGetLastError());
     return MPPI_OK;
 }
