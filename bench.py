@@ -174,10 +174,15 @@ def cpu_baseline(workload, H, K, mlp, budget_s=12.0):
     import numpy as np
     from oracle import oracle as orc
     a = WORKLOADS[workload][0]
-    Kc = K if mlp is None else min(K, 4096)
+    Kc = K if mlp is None and workload not in GEN else min(K, 4096)
     c = cfg_of(workload, H)
-    p = orc.Problem(tau=H, s=2 * a, a=a, dt=0.1, mass=1.0, lam=1.0, sigma=c["sigma"], goal=c["goal"], threads=0, mlp=mlp)
-    x, U = np.zeros(2 * a, np.float32), np.zeros((H, a), np.float32)
+    if workload in GEN:  # the 13-state family: the same task through the CPU restatement's model_base / cost_base slots
+        mkw = {"auv": dict(auv=c.get("auv")), "nnauv": dict(nnauv=mlp), "nnspeed": dict(nnauv_speed=mlp)}[workload]
+        p = orc.Problem(tau=H, s=13, a=a, dt=c["dt"], lam=c["lam"], sigma=c["sigma"], goal=c["goal"], Q=c["Q"], threads=0, **mkw)
+        x, U = np.asarray(c["x0"], np.float32), np.zeros((H, a), np.float32)
+    else:
+        p = orc.Problem(tau=H, s=2 * a, a=a, dt=0.1, mass=1.0, lam=1.0, sigma=c["sigma"], goal=c["goal"], threads=0, mlp=mlp)
+        x, U = np.zeros(2 * a, np.float32), np.zeros((H, a), np.float32)
     eps = orc.noise(1, 0, 0, Kc, H, a, c["sigma"])
     p.next_with_noise(x, U, eps)  # warm-up (page in, spin up the OpenMP team)
     n, t0 = 0, time.perf_counter()
@@ -519,7 +524,7 @@ def main():
         if world == 1:
             med, p95 = sync_latency(m, headline, H, K, r["mlp"])
             out["ms_per_control_step_sync"] = {"median": r4(med), "p95": r4(p95)}
-            if not args.no_cpu_baseline and headline not in GEN:
+            if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(headline, H, K, r["mlp"])
         line = json.dumps(out)
         sys.stdout.flush()

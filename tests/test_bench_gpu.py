@@ -37,7 +37,8 @@ def test_every_workload_prints_the_contract_line(workload, samples, horizon):
     assert out["ms_per_control_step_sync"]["median"] > 0
 
 
-def test_cpu_baseline_rides_along_on_a_small_point_mass_run():
-    out = run_bench("--workload", "pm2d", "--no-subrecords")
+@pytest.mark.parametrize("workload,extra", [("pm2d", []), ("auv", ["--samples", "4096", "--horizon", "8"]), ("nnspeed", ["--samples", "4096", "--horizon", "8"])])
+def test_cpu_baseline_rides_along(workload, extra):
+    out = run_bench("--workload", workload, "--no-subrecords", *extra)
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
