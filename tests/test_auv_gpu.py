@@ -555,3 +555,31 @@ def test_python_entry_point_learns_the_plant_online():
     rounds = re.findall(r"normalised loss ([0-9.e+-]+) -> ([0-9.e+-]+)", r.stdout)
     assert len(rounds) == 3 and all(float(b) < 0.25 * float(a) for a, b in rounds), r.stdout
     assert np.isfinite(float(re.search(r"goal_p\| = ([0-9.]+) m", r.stdout).group(1)))
+
+
+@pytest.mark.parametrize("kind,K,H", [("bf16x3", 300, 7), ("bf16x3", 65, 5), ("speed", 300, 7), ("speed", 1, 3), ("mfma", 65, 5)])
+def test_learned_13_state_kernels_with_ragged_tiles(m, kind, K, H):
+    """K that is no multiple of the 64-rollout tile (partial last tile, a single rollout) and a horizon that is no multiple of the 4-step
+    Philox group, for the learned 13-state kernels: k_rollout_nnauv32(_bx3) and NNAUVModelSpeed's k_rollout_gen<2, .> — the fused step
+    against the fp64 CPU restatement on the exported noise."""
+    sigma = 0.25 * np.eye(6)
+    ck = dict(goal=GOAL13, Q=np.array([10.0] * 3 + [5.0] * 4 + [1.0] * 6))
+    if kind == "speed":
+        mlp = make_nnauv_speed(11, 16, 3)
+        mkw, okw = dict(nnauv_speed=mlp), dict(nnauv_speed=mlp)
+    else:
+        mlp = make_nnauv(11, 32, 3)
+        mkw, okw = dict(nnauv=mlp, mlp_bf16x3=(kind == "bf16x3")), dict(nnauv=mlp)
+    h = m.Handle(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, seed=21, **mkw, **ck)
+    p64 = orc.Problem(tau=H, s=13, a=6, dt=0.1, lam=1.0, sigma=sigma, threads=0, dtype=np.float64, **okw, **ck)
+    x0 = np.array([0.5, -0.5, 0.2, 0.0, 0.0, 0.0, 1.0, 0.3, 0.0, -0.1, 0.0, 0.05, 0.0], F32)
+    U_in = h.get_action_sequence()
+    u = h.next(x0)
+    noise = h.debug_get(m.DBG_NOISE)
+    assert noise.shape == (K, H, 6)
+    np.testing.assert_allclose(noise, orc.noise(21, 0, 0, K, H, 6, sigma), rtol=0, atol=5e-6)
+    u64, U64, c64 = p64.next_with_noise(x0, U_in, noise)
+    bar = 2e-5 if kind == "bf16x3" else 1e-5
+    np.testing.assert_allclose(h.debug_get(m.DBG_COSTS), c64, rtol=2e-5)
+    np.testing.assert_allclose(h.get_action_sequence(), U64, rtol=0, atol=bar)
+    np.testing.assert_allclose(u, u64, rtol=0, atol=bar)
