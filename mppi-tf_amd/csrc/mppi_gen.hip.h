@@ -542,15 +542,14 @@ __device__ __forceinline__ void nnauv_speed_step(const DevConsts *__restrict__ C
 // MODEL: GEN_MODEL_AUV | GEN_MODEL_NNAUV ; HID: hidden width of the NNAUV network (16 | 32; ignored for the AUV model).
 // mode: MODE_ROLLOUT (costs + record) | MODE_COST_ONLY | MODE_COSTS_GIVEN (record from given costs) ; noise_out != NULL
 // additionally exports the noise the step used ([K, H, A], MPPI_DBG_NOISE) — and with MODE_NOISE_ONLY does nothing else.
-template <int MODEL, int HID>
+template <int MODEL, int HID, bool DIAG = false>
 __global__ __launch_bounds__(64) void k_rollout_gen(
     const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const MlpDev *__restrict__ M, const MlpSmallArgs P,
     const float *__restrict__ x_dev, const float *__restrict__ U_dev, const float *__restrict__ eps_hbm,
     const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
     float *__restrict__ noise_out, const int SRC, const int MODE, const int rsb, const int rsc)
 {
-    constexpr int S = kGenS, A = kGenA;
-    constexpr bool DIAG = false;
+    constexpr int S = kGenS, A = kGenA; // DIAG: Sigma and its inverse are exactly diagonal (the off-diagonal products are exact zeros: skipped)
     const int H = C->H, HA = H * A, K = C->K_local;
     const int NG = (H + 3) / 4;
     const int lane = threadIdx.x;
@@ -661,13 +660,13 @@ __global__ void k_gen_costs(const DevConsts *__restrict__ C, const GenConsts *__
 // 64-rollout tile record.
 constexpr int kNnauv32Threads = 128;
 
+template <bool DIAG>
 __global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnauv32(
     const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
     const float *__restrict__ U_dev, const float *__restrict__ eps_hbm, const unsigned long long *__restrict__ step_ctr,
     float *__restrict__ cost, float *__restrict__ partials, const int SRC, const int MODE, const int rsb, const int rsc)
 {
     constexpr int S = kGenS, A = kGenA, NIN = kGenNin, XOFF = 3, SP = (S + 1) / 2, HID = 32, K1H = NIN / 2, W3LD = 16;
-    constexpr bool DIAG = false;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float w3_s[HID * W3LD];   // output-layer rows, padded to 16
@@ -815,6 +814,7 @@ __global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnauv32(
 // kb, and the output layer rides the matrix core too: A row m carries output (m & 3) + 4 (m >> 3) — 13 of the 16 a lane half holds,
 // each output once per half — so register n of EVERY lane is output n of its rollout. The 16 inputs fill layer 1's k-block: its bias
 // is the C operand. Builtin MFMAs (hipcc sees their hazards), compiled in VGPR form.
+template <bool DIAG>
 __global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnauv32_bx3(
     const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
     const float *__restrict__ U_dev, const float *__restrict__ eps_hbm, const unsigned long long *__restrict__ step_ctr,
@@ -822,7 +822,6 @@ __global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnauv32_bx3(
 {
     constexpr int S = kGenS, A = kGenA, NIN = kGenNin, XOFF = 3, HID = 32;
     static_assert(NIN == 16 && S <= 16, "the inputs are exactly one k-block; the outputs fit the 16 registers both lane halves share");
-    constexpr bool DIAG = false;
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     __shared__ float z_s[2][4 * A][32]; // per wave: the normals of one horizon group
     __shared__ float cost_s[64];

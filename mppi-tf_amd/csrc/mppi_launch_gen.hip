@@ -156,20 +156,32 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
     const GenState *g = gs(h);
     const dim3 grid(h->nb), block(64);
 #define MPPI_GEN_L(MODEL, HID)                                                                                                     \
-    hipExtLaunchKernelGGL((k_rollout_gen<MODEL, HID>), grid, block, 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,   \
-                          (const MlpDev *)h->dM, h->small_args, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, noise_out, \
-                          src, mode, 1, h->nbp)
+    do {                                                                                                                           \
+        if (h->sigma_diag)                                                                                                         \
+            hipExtLaunchKernelGGL((k_rollout_gen<MODEL, HID, true>), grid, block, 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG, \
+                                  (const MlpDev *)h->dM, h->small_args, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, noise_out, \
+                                  src, mode, 1, h->nbp);                                                                            \
+        else                                                                                                                       \
+            hipExtLaunchKernelGGL((k_rollout_gen<MODEL, HID, false>), grid, block, 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG, \
+                                  (const MlpDev *)h->dM, h->small_args, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, noise_out, \
+                                  src, mode, 1, h->nbp);                                                                            \
+    } while (0)
+#define MPPI_NNAUV32_L(KERN)                                                                                                       \
+    hipExtLaunchKernelGGL(KERN, grid, dim3(kNnauv32Threads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,        \
+                          (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp)
     // Dense(32) NNAUVModel: the matrix-core kernel (rollouts and cost-only passes; the record-from-given-costs / noise-export modes
     // and MPPI_TUNE_MLP32_VALU stay on the vector-ALU kernel)
     if (h->hc.model_kind == MPPI_MODEL_NN_AUV && h->mlp_small == 32 && !h->mlp32_valu && (mode == MODE_ROLLOUT || mode == MODE_COST_ONLY) && noise_out == nullptr) {
-        if (h->mlp_bx3) // MPPI_FLAG_MLP_BF16X3: the bf16 matrix cores, every operand split in two
-            hipExtLaunchKernelGGL(k_rollout_nnauv32_bx3, grid, dim3(kNnauv32Threads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,
-                                  (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp);
-        else
-            hipExtLaunchKernelGGL(k_rollout_nnauv32, grid, dim3(kNnauv32Threads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,
-                                  (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp);
+        if (h->mlp_bx3) { // MPPI_FLAG_MLP_BF16X3: the bf16 matrix cores, every operand split in two
+            if (h->sigma_diag) MPPI_NNAUV32_L(k_rollout_nnauv32_bx3<true>);
+            else MPPI_NNAUV32_L(k_rollout_nnauv32_bx3<false>);
+        } else {
+            if (h->sigma_diag) MPPI_NNAUV32_L(k_rollout_nnauv32<true>);
+            else MPPI_NNAUV32_L(k_rollout_nnauv32<false>);
+        }
         return hipGetLastError();
     }
+#undef MPPI_NNAUV32_L
     if (h->hc.model_kind == MPPI_MODEL_AUV) MPPI_GEN_L(GEN_MODEL_AUV, 32);
     else if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED) {
         if (h->mlp_small == 16) MPPI_GEN_L(GEN_MODEL_NNAUV_SPEED, 16);
@@ -182,10 +194,16 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
 
 const char *mppi_gen_kernel_name(const mppi_handle *h)
 {
-    if (h->hc.model_kind == MPPI_MODEL_AUV) return "mppi::k_rollout_gen<0, 32>";
-    if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED) return h->mlp_small == 16 ? "mppi::k_rollout_gen<2, 16>" : "mppi::k_rollout_gen<2, 32>";
-    if (h->mlp_small == 32 && !h->mlp32_valu) return h->mlp_bx3 ? "mppi::k_rollout_nnauv32_bx3" : "mppi::k_rollout_nnauv32";
-    return h->mlp_small == 16 ? "mppi::k_rollout_gen<1, 16>" : "mppi::k_rollout_gen<1, 32>";
+    const bool d = h->sigma_diag != 0; // the last template argument: exactly diagonal Sigma (as the profiler spells the instance)
+    if (h->hc.model_kind == MPPI_MODEL_AUV) return d ? "mppi::k_rollout_gen<0, 32, true>" : "mppi::k_rollout_gen<0, 32, false>";
+    if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED)
+        return h->mlp_small == 16 ? (d ? "mppi::k_rollout_gen<2, 16, true>" : "mppi::k_rollout_gen<2, 16, false>")
+                                  : (d ? "mppi::k_rollout_gen<2, 32, true>" : "mppi::k_rollout_gen<2, 32, false>");
+    if (h->mlp_small == 32 && !h->mlp32_valu)
+        return h->mlp_bx3 ? (d ? "mppi::k_rollout_nnauv32_bx3<true>" : "mppi::k_rollout_nnauv32_bx3<false>")
+                          : (d ? "mppi::k_rollout_nnauv32<true>" : "mppi::k_rollout_nnauv32<false>");
+    return h->mlp_small == 16 ? (d ? "mppi::k_rollout_gen<1, 16, true>" : "mppi::k_rollout_gen<1, 16, false>")
+                              : (d ? "mppi::k_rollout_gen<1, 32, true>" : "mppi::k_rollout_gen<1, 32, false>");
 }
 
 // NNAUVModel.build_step_graph in the reference's plain order (mul and add rounded separately, input index ascending, division by

@@ -210,7 +210,7 @@ def test_nnauv_speed_control_step_against_oracle(m, hid, n_hidden, cost):
     ck = dict(goal=GOAL13, Q=np.array([10.0] * 3 + [5.0] * 4 + [1.0] * 6)) if cost == "quadratic" else dict(goal=goal_q, Q=Q10 / 10, quat_cost=True)
     cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv_speed=mlp, seed=9, **ck)
     h = m.Handle(**cfg)
-    assert h.rollout_kernel_name() == "mppi::k_rollout_gen<2, %d>" % hid
+    assert h.rollout_kernel_name() == "mppi::k_rollout_gen<2, %d, true>" % hid  # (true: the diagonal-Sigma instance)
     mk = lambda dt: orc.Problem(tau=H, s=13, a=6, dt=0.1, lam=1.0, sigma=sigma, nnauv_speed=mlp, threads=0, dtype=dt, **ck)
     p32, p64 = mk(F32), mk(np.float64)
     rng = np.random.default_rng(1)
@@ -256,7 +256,7 @@ def test_nnauv_speed_control_step_against_oracle(m, hid, n_hidden, cost):
         nn.set_Ymean_Ystd(mlp["ymean"], mlp["ystd"])
         ctl = m.ControllerBase(model=nn, cost=m.StaticQuatCost(1.0, 1.0, 1.0, sigma, np.array(goal_q)[:, None], Q10 / 10), k=K, tau=H, sDim=13, aDim=6,
                                lam=1.0, sigma=sigma, seed=9)
-        assert ctl._h.rollout_kernel_name() == "mppi::k_rollout_gen<2, %d>" % hid
+        assert ctl._h.rollout_kernel_name() == "mppi::k_rollout_gen<2, %d, true>" % hid
         assert np.isfinite(ctl.next(x0[:, None])).all()
 
 
@@ -336,7 +336,7 @@ def test_auv_rollout_costs_against_oracle(m, G, K, H, cost):
     """mBuildModelGraph with the Fossen model: sample costs bit-identical to the fp32 oracle for the quadratic costs (diagonal and
     dense Q), within 3e-6 relative for the quaternion / 3D-ellipse costs (acos); ragged K and a horizon that is no multiple of 4."""
     h, p32, p64, x0, U, eps = auv_case(m, G, K, H, cost)
-    assert h.rollout_kernel_name() == "mppi::k_rollout_gen<0, 32>"
+    assert h.rollout_kernel_name().startswith("mppi::k_rollout_gen<0, 32, ")
     got = h.rollout_cost(x0, U, eps)
     ref = p32.rollout_cost(x0, U, eps)
     if cost in ("quadratic", "dense"):
@@ -434,7 +434,7 @@ def test_nnauv_control_step_against_oracle(m, hid, n_hidden, tuning, cost):
     cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv=mlp, seed=9, tuning=None if bx3 else tuning, mlp_bf16x3=bx3, **ck)
     h = m.Handle(**cfg)
     # Dense(32): the matrix cores (k_rollout_nnauv32, the accumulators of one layer are the next layer's B operands) unless tuned onto the vector ALU
-    assert h.rollout_kernel_name() == ("mppi::k_rollout_nnauv32_bx3" if bx3 else "mppi::k_rollout_nnauv32" if hid == 32 and not tuning else "mppi::k_rollout_gen<1, %d>" % hid)
+    assert h.rollout_kernel_name() == ("mppi::k_rollout_nnauv32_bx3<true>" if bx3 else "mppi::k_rollout_nnauv32<true>" if hid == 32 and not tuning else "mppi::k_rollout_gen<1, %d, true>" % hid)
     mk = lambda dt: orc.Problem(tau=H, s=13, a=6, lam=1.0, sigma=sigma, nnauv=mlp, threads=0, dtype=dt, **ck)
     p32, p64 = mk(F32), mk(np.float64)
     rng = np.random.default_rng(1)
@@ -581,5 +581,44 @@ def test_learned_13_state_kernels_with_ragged_tiles(m, kind, K, H):
     u64, U64, c64 = p64.next_with_noise(x0, U_in, noise)
     bar = 2e-5 if kind == "bf16x3" else 1e-5
     np.testing.assert_allclose(h.debug_get(m.DBG_COSTS), c64, rtol=2e-5)
+    np.testing.assert_allclose(h.get_action_sequence(), U64, rtol=0, atol=bar)
+    np.testing.assert_allclose(u, u64, rtol=0, atol=bar)
+
+
+DENSE_SIGMA6 = (0.25 * np.eye(6) + 0.03 * np.add.outer(np.arange(6), np.arange(6)) / 5.0).astype(F32)
+
+
+@pytest.mark.parametrize("kind", ["auv", "mfma", "bf16x3", "valu16", "speed"])
+def test_13_state_kernels_with_a_dense_sigma(m, G, kind):
+    """The 13-state kernels are instantiated for an exactly diagonal Sigma (off-diagonal products skipped: exact zeros) and for a dense
+    one; every other test here uses a diagonal Sigma, this one the dense instances: noise = the CPU restatement's Philox stream scaled by
+    the dense matrix, the fused step against the fp64 evaluation on it; the Fossen model's costs bit-identical to the fp32 one."""
+    K, H = 1500, 9
+    ck = dict(goal=GOAL13, Q=np.array([10.0] * 3 + [5.0] * 4 + [1.0] * 6))
+    scale = 200.0 if kind == "auv" else 1.0
+    sigma = (scale * DENSE_SIGMA6).astype(F32)
+    if kind == "auv":
+        mkw, okw = dict(auv=G["params"]), dict(auv=G["params"])
+    elif kind == "speed":
+        mlp = make_nnauv_speed(5, 16, 3)
+        mkw, okw = dict(nnauv_speed=mlp), dict(nnauv_speed=mlp)
+    else:
+        mlp = make_nnauv(5, 16 if kind == "valu16" else 32, 3)
+        mkw, okw = dict(nnauv=mlp, mlp_bf16x3=(kind == "bf16x3")), dict(nnauv=mlp)
+    h = m.Handle(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, seed=8, **mkw, **ck)
+    assert h.rollout_kernel_name().endswith("false>")
+    mk = lambda dt: orc.Problem(tau=H, s=13, a=6, dt=0.1, lam=1.0, sigma=sigma, threads=0, dtype=dt, **okw, **ck)
+    p32, p64 = mk(F32), mk(np.float64)
+    x0 = np.array([0.5, -0.5, 0.2, 0.0, 0.0, 0.0, 1.0, 0.3, 0.0, -0.1, 0.0, 0.05, 0.0], F32)
+    U_in = h.get_action_sequence()
+    u = h.next(x0)
+    noise = h.debug_get(m.DBG_NOISE)
+    np.testing.assert_allclose(noise, orc.noise(8, 0, 0, K, H, 6, sigma), rtol=0, atol=5e-6 * scale)
+    u64, U64, c64 = p64.next_with_noise(x0, U_in, noise)
+    c = h.debug_get(m.DBG_COSTS)
+    if kind == "auv":
+        np.testing.assert_array_equal(c, p32.next_with_noise(x0, U_in, noise)[2])
+    np.testing.assert_allclose(c, c64, rtol=2e-5)
+    bar = (2e-5 if kind == "bf16x3" else 1e-5) * scale
     np.testing.assert_allclose(h.get_action_sequence(), U64, rtol=0, atol=bar)
     np.testing.assert_allclose(u, u64, rtol=0, atol=bar)
