@@ -420,7 +420,7 @@ def sub_record(s):
     keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "kernel_us", "floor_us", "valu_busy_us", "dispatch_fixed_us",
             "mfma_busy_frac", "algorithmic_TFLOP_per_s", "traffic")
     d = {"config": name, "K": s["K_per_gpu"], "H": s["H"], "value": r4(s["rollouts_per_s"]), "ms_per_step": r4(s["ms_per_step"]),
-         "roofline": {k: rf[k] for k in keep if rf.get(k) is not None}}
+         "roofline": {k: rf[k] for k in keep if rf.get(k) is not None and not (k == "unit" and rf[k] == "TFLOP/s")}}  # (TFLOP/s unless it says otherwise)
     if s["workload"] == "nnauv" and "bx3" not in s["kernel"]:
         d["weights"] = trained_nnauv()[1]
     return d
@@ -517,6 +517,7 @@ def main():
             out["rank_ms_per_step"] = [r4(q) for q in r["rank_ms_per_step"]]
         if subs:
             out["sub_records"] = [sub_record(s) for s in subs]
+            out["sub_roofline_unit"] = "TFLOP/s unless stated"
             if world > 1:
                 out["sub_records"][0]["config"] = "configs[4]" if world == 8 else "configs[4] per-GPU shape, K=%d over %d GPUs" % (65536 * world, world)
                 out["sub_records"][0]["exchange"] = subs[0]["exchange"]
