@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Soak run on the GPU box: thousands of consecutive control steps of every rollout-kernel family (point mass with its option paths,
+the 2x256 and Dense(32) networks in both precisions, the 13-state family); checks the step counter and finite action sequences.
+   python tools/soak.py"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import mppi_tf_amd as m
+from mppi_tf_amd.auv import auv_task
+rng = np.random.default_rng(0)
+def mlp(dims, seed=0):
+    r = np.random.default_rng(seed)
+    n = len(dims) - 1
+    return dict(W=[(r.uniform(-1, 1, (dims[i], dims[i+1])) / np.sqrt(dims[i]) * (0.1 if i == n-1 else 1)).astype(np.float32) for i in range(n)],
+                b=[(r.uniform(-1, 1, dims[i+1]) / np.sqrt(dims[i]) * (0.1 if i == n-1 else 1)).astype(np.float32) for i in range(n)])
+pm = dict(tau=64, s_dim=6, a_dim=3, dt=0.1, lam=1.0, sigma=0.25*np.eye(3), goal=[1,0,.5,0,.75,0])
+at = auv_task(64, learned=True); x13 = np.asarray(at.pop("x0"), np.float32)
+cases = [
+ ("pm3d", dict(k=65536, **pm), np.zeros(6, np.float32), 4000),
+ ("pm3d normalize", dict(k=65536, normalize_cost=True, **pm), np.zeros(6, np.float32), 2000),
+ ("pm3d ellipse", dict(k=65536, ellipse=dict(a=1.5,b=.8,cx=.2,cy=-.1,speed=.7,m_state=2.,m_vel=.5), **pm), np.zeros(6, np.float32), 2000),
+ ("mlp 2x256 bx3", dict(k=65536, mlp=mlp([9,256,256,6]), mlp_bf16x3=True, **pm), np.zeros(6, np.float32), 1500),
+ ("mlp 2x256", dict(k=65536, mlp=mlp([9,256,256,6]), **pm), np.zeros(6, np.float32), 300),
+ ("mlp32 bx3", dict(k=65536, mlp=mlp([9,32,32,32,6]), mlp_bf16x3=True, **pm), np.zeros(6, np.float32), 3000),
+ ("nnauv32 bx3", dict(k=65536, nnauv=mlp([16,32,32,32,13]), mlp_bf16x3=True, **at), x13, 2000),
+ ("nnauv32", dict(k=65536, nnauv=mlp([16,32,32,32,13]), **at), x13, 1500),
+ ("nnspeed", dict(k=65536, nnauv_speed=mlp([15,16,16,16,6]), **at), x13, 1500),
+ ("auv", dict(k=65536, **auv_task(64)), x13, 2000),
+]
+for name, kw, x0, n in cases:
+    kw = dict(kw); kw.pop("x0", None)
+    h = m.Handle(**kw)
+    x = torch.tensor(x0, device="cuda"); u = torch.zeros(kw["a_dim"], device="cuda")
+    t0 = time.perf_counter()
+    for i in range(n):
+        h.next_device(x.data_ptr(), u.data_ptr())
+    h.synchronize()
+    el = time.perf_counter() - t0
+    U = h.get_action_sequence()
+    print("%-16s %5d steps  %.3f ms/step  step counter %d  U finite %s  |U|max %.3g" % (name, n, 1e3 * el / n, h.get_step_counter(), bool(np.isfinite(U).all()), float(np.abs(U).max())), flush=True)
+    assert h.get_step_counter() == n and np.isfinite(U).all()
+    h.close()
+print("soak ok")
