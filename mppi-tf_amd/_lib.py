@@ -101,6 +101,8 @@ SIGNATURES = {
     "mppi_next_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mppi_shard_partial": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mppi_shard_finish": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mppi_shard_cost_range": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mppi_shard_partial_normalized": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mppi_synchronize": (C.c_int, [_H]),
     "mppi_set_action_limits": (C.c_int, [_H, FP, FP, C.c_int]),
     "mppi_set_sequence_filter": (C.c_int, [_H, C.c_int, C.c_int]),
@@ -458,6 +460,14 @@ class Handle:
 
     def shard_finish(self, records_ptr, n_records, u_ptr, stream=0):
         self._check(self.lib.mppi_shard_finish(self.h, records_ptr, n_records, u_ptr, stream))
+
+    def shard_cost_range(self, x_ptr, range_ptr, stream=0):
+        """normalize_cost on a sharded handle, first half: {min, max} of this shard's sample costs -> range_ptr[2]"""
+        self._check(self.lib.mppi_shard_cost_range(self.h, x_ptr, range_ptr, stream))
+
+    def shard_partial_normalized(self, x_ptr, range_ptr, record_ptr, stream=0):
+        """... second half: range_ptr[2] = the {min, max} all ranks agreed on -> this shard's record"""
+        self._check(self.lib.mppi_shard_partial_normalized(self.h, x_ptr, range_ptr, record_ptr, stream))
 
     # ---- options of the Python reference's update ---------------------------------------------
     def set_action_limits(self, a_min=None, a_max=None):

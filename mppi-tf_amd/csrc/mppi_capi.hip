@@ -613,7 +613,7 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
         if (prof && !kernel_events) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 1], st));
         return MPPI_OK;
     }
-    if (h->shard_count != 1) return fail(h, MPPI_ERR_UNSUPPORTED, "normalize_cost needs the global max cost: unsharded handles only");
+    if (h->shard_count != 1) return fail(h, MPPI_ERR_UNSUPPORTED, "normalize_cost on a sharded handle: mppi_shard_cost_range, reduce the ranges over the ranks, mppi_shard_partial_normalized");
     // Py normalizeCost (controller_base.py:468-474): costs, global min/max, then the update on
     // c' = (c-min)/(max-min) with the SAME noise (regenerated from the same Philox counters).
     if (!mlp && !gen && src == SRC_PHILOX && noise_out == nullptr && pc_eligible(h)) {
@@ -624,7 +624,7 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
         const bool prof2 = h->prof_n < h->prof_cap;
         h->kev0 = h->kev1 = nullptr;
         HIP_TRY(h, launch_pc(h, st, x_dev));
-        hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(1024), 0, st, h->d_cost, h->K_local, h->d_mm, h->hc.neg_inv_lambda, &h->dCn->neg_inv_lambda);
+        hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(1024), 0, st, h->d_cost, h->K_local, h->d_mm, h->hc.neg_inv_lambda, &h->dCn->neg_inv_lambda, (float *)nullptr);
         HIP_TRY(h, hipGetLastError());
         h->kev0 = prof2 ? h->ev[4 * h->prof_n + 0] : nullptr; // a profiled step reports the second pass (the one whose records are used)
         h->kev1 = prof2 ? h->ev[4 * h->prof_n + 1] : nullptr;
@@ -643,7 +643,7 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
     else if (mlp) HIP_TRY(h, launch_mlp(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost));
     else HIP_TRY(h, launch_tile(h, st, src, MODE_COST_ONLY, x_dev, h->U_cur(), eps, h->d_cost, h->d_part, noise_out));
     if (prof_n) HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 1], st));
-    hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(1024), 0, st, h->d_cost, h->K_local, h->d_mm, 0.0f, (float *)nullptr);
+    hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(1024), 0, st, h->d_cost, h->K_local, h->d_mm, 0.0f, (float *)nullptr, (float *)nullptr);
     HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(k_cost_normalize, dim3((h->K_local + 255) / 256), dim3(256), 0, st, h->d_cost, h->K_local, h->d_mm, h->d_cost2);
     HIP_TRY(h, hipGetLastError());
@@ -783,6 +783,61 @@ extern "C" mppi_status mppi_shard_partial(mppi_handle *h, const float *x_dev, fl
     mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr, &nrec);
     if (s != MPPI_OK) return s;
     HIP_TRY(h, launch_finish(h, st, h->d_part, 1, nrec, nrec, h->U_cur(), h->U_other(), h->d_u, record_dev, 0));
+    return MPPI_OK;
+}
+
+// ---- normalizeCost on a K-sharded controller -----------------------------------------------------
+// c' = (c - min)/(max - min) needs the min and max over ALL samples (controller_base.py:468-474): each shard rolls its samples and
+// reports its own range; the ranks reduce the ranges (min of the minima, max of the maxima: one 2-float collective); each shard then
+// makes its record from costs normalised with the agreed range. Both halves take the path enqueue_partials takes on an unsharded
+// handle — two passes of k_rollout_pc where it serves the configuration, else cost pass + normalise + record pass; which of the two
+// depends on the configuration only, never on the shard's size: all ranks make their records in the same units.
+static bool norm_fast(const mppi_handle *h) { return h->hc.model_kind != MPPI_MODEL_MLP && !h->is_gen && pc_eligible(h); }
+
+extern "C" mppi_status mppi_shard_cost_range(mppi_handle *h, const float *x_dev, float *range_dev, void *stream)
+{
+    if (!h || !x_dev || !range_dev) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL device pointer") : MPPI_ERR_INVALID_ARG;
+    if (!h->normalize) return fail(h, MPPI_ERR_INVALID_ARG, "mppi_shard_cost_range: the handle was created without normalize_cost");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const bool mlp = h->hc.model_kind == MPPI_MODEL_MLP;
+    h->norm_two_pass = 0;
+    h->kev0 = h->kev1 = nullptr;
+    HIP_TRY(h, ensure_record_layout(h, st, h->nb));
+    if (norm_fast(h)) HIP_TRY(h, launch_pc(h, st, x_dev)); // its records (at lambda) are overwritten by the second pass
+    else if (h->is_gen) HIP_TRY(h, mppi_launch_gen(h, st, SRC_PHILOX, MODE_COST_ONLY, x_dev, h->U_cur(), nullptr, h->d_cost, h->d_part, nullptr));
+    else if (mlp) HIP_TRY(h, launch_mlp(h, st, SRC_PHILOX, MODE_COST_ONLY, x_dev, h->U_cur(), nullptr, h->d_cost));
+    else HIP_TRY(h, launch_tile(h, st, SRC_PHILOX, MODE_COST_ONLY, x_dev, h->U_cur(), nullptr, h->d_cost, h->d_part, nullptr));
+    hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(1024), 0, st, h->d_cost, h->K_local, h->d_mm, 0.0f, (float *)nullptr, range_dev);
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_shard_partial_normalized(mppi_handle *h, const float *x_dev, const float *range_dev, float *record_dev, void *stream)
+{
+    if (!h || !x_dev || !range_dev || !record_dev) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL device pointer") : MPPI_ERR_INVALID_ARG;
+    if (!h->normalize) return fail(h, MPPI_ERR_INVALID_ARG, "mppi_shard_partial_normalized: the handle was created without normalize_cost");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const bool fast = norm_fast(h);
+    h->kev0 = h->kev1 = nullptr;
+    hipLaunchKernelGGL(k_range_apply, dim3(1), dim3(64), 0, st, range_dev, h->d_mm, h->hc.neg_inv_lambda, fast ? &h->dCn->neg_inv_lambda : (float *)nullptr);
+    HIP_TRY(h, hipGetLastError());
+    if (fast) { // the same rollouts again (same Philox counters), records of the raw costs at the temperature of the agreed range
+        DevConsts *plain = h->dC;
+        h->dC = h->dCn;
+        const hipError_t le = launch_pc(h, st, x_dev);
+        h->dC = plain;
+        HIP_TRY(h, le);
+        h->norm_two_pass = 1;
+    } else { // d_cost still holds this step's costs (mppi_shard_cost_range)
+        hipLaunchKernelGGL(k_cost_normalize, dim3((h->K_local + 255) / 256), dim3(256), 0, st, h->d_cost, h->K_local, h->d_mm, h->d_cost2);
+        HIP_TRY(h, hipGetLastError());
+        if (h->is_gen) HIP_TRY(h, mppi_launch_gen(h, st, SRC_PHILOX, MODE_COSTS_GIVEN, x_dev, h->U_cur(), nullptr, h->d_cost2, h->d_part, nullptr));
+        else HIP_TRY(h, launch_tile(h, st, SRC_PHILOX, MODE_COSTS_GIVEN, x_dev, h->U_cur(), nullptr, h->d_cost2, h->d_part, nullptr));
+        h->norm_two_pass = 0;
+    }
+    HIP_TRY(h, launch_finish(h, st, h->d_part, 1, h->nbp, h->nbp, h->U_cur(), h->U_other(), h->d_u, record_dev, 0));
     return MPPI_OK;
 }
 

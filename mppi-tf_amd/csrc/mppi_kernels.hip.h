@@ -1100,7 +1100,7 @@ namespace mppi {
 // as the normalised ones do at lambda (exp(-(c'-min c')/lambda) = exp(-(c-min c)/(lambda (max-min)))): the second rollout pass of
 // the two-pass normalizeCost path reads it from a DevConsts copy, the finish from out[2]
 __global__ __launch_bounds__(1024) void k_cost_minmax(const float *__restrict__ cost, int K, float *__restrict__ out,
-                                                      float neg_inv_lambda, float *__restrict__ nil_out)
+                                                      float neg_inv_lambda, float *__restrict__ nil_out, float *__restrict__ range_out)
 {
     __shared__ float mn_s[16], mx_s[16];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1120,6 +1120,20 @@ __global__ __launch_bounds__(1024) void k_cost_minmax(const float *__restrict__ 
         for (int w = 1; w < nt / 64; ++w) { mn = fminf(mn, mn_s[w]); mx = fmaxf(mx, mx_s[w]); }
         out[0] = mn; out[1] = mx - mn;
         if (nil_out != nullptr) { const float v = neg_inv_lambda / (mx - mn); out[2] = v; *nil_out = v; }
+        if (range_out != nullptr) { range_out[0] = mn; range_out[1] = mx; } // a shard's own range: reduced over the ranks by the caller
+    }
+}
+
+// K-sharded normalizeCost (mppi_shard_partial_normalized): the GLOBAL {min, max} the ranks agreed on becomes this handle's
+// {min, max - min, -1/(lambda (max - min))}, exactly what k_cost_minmax leaves on an unsharded handle
+__global__ void k_range_apply(const float *__restrict__ range, float *__restrict__ out, float neg_inv_lambda, float *__restrict__ nil_out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float mn = range[0], mx = range[1];
+        out[0] = mn; out[1] = mx - mn;
+        const float v = neg_inv_lambda / (mx - mn);
+        out[2] = v;
+        if (nil_out != nullptr) *nil_out = v;
     }
 }
 #endif

@@ -13,6 +13,9 @@ direct exchange of include/mppi_c.h (mppi_shard_p2p_*): the finish kernel itself
 peer's inbox over xGMI and spins for theirs — no collective launch on the critical path of a ~25 µs step.
 (ii) is brought up with a self-test and a vote over all ranks; if any rank cannot map a peer, or a probe
 packet does not arrive, every rank uses (i).  MPPI_EXCHANGE=rccl|p2p|auto (default auto) picks.
+normalizeCost=True (controller_base.py:468-474) needs the min and max cost over ALL samples: such a controller runs a second,
+2-float collective per step (ONE all-reduce(MAX) of {-min, max}) between mppi_shard_cost_range and mppi_shard_partial_normalized,
+and always exchanges its records by all-gather.
 torch is plumbing here: device buffers, the current stream, and torch.distributed (backend
 "nccl" is RCCL on ROCm; "gloo" drives the CPU test of this file's logic with a test backend).
 """
@@ -36,6 +39,7 @@ class HipShardBackend:
         torch.cuda.set_device(self.device)
         self.h = Handle(shard_rank=rank, shard_count=world, device=device_index, **cfg)
         self.record_size, self.a = self.h.record_size, self.h.a
+        self.normalize = bool(cfg.get("normalize_cost", False))
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -45,6 +49,13 @@ class HipShardBackend:
 
     def finish(self, records, n_records, u):
         self.h.shard_finish(records.data_ptr(), n_records, u.data_ptr(), self._stream())
+
+    # normalizeCost: the global min / max cost is a second, 2-float exchange (mppi_shard_cost_range / _partial_normalized)
+    def cost_range(self, x, rng):
+        self.h.shard_cost_range(x.data_ptr(), rng.data_ptr(), self._stream())
+
+    def partial_normalized(self, x, rng, record):
+        self.h.shard_partial_normalized(x.data_ptr(), rng.data_ptr(), record.data_ptr(), self._stream())
 
     def step(self, x, u):
         """unsharded whole step (mppi_next_device): no record round trip"""
@@ -103,6 +114,9 @@ class ShardedController:
         self.record = torch.zeros(n, dtype=torch.float32, device=dev)
         self.records = torch.zeros(self.world * n, dtype=torch.float32, device=dev)
         self.u = torch.zeros(self.backend.a, dtype=torch.float32, device=dev)
+        # normalizeCost (controller_base.py:468-474) needs the min and max cost over ALL ranks' samples: a second collective per step
+        self.normalize = bool(getattr(self.backend, "normalize", False))
+        self.range = torch.zeros(2, dtype=torch.float32, device=dev)
         # MPPI_FORCE_EXCHANGE=1: take the sharded path (records -> exchange -> finish) even with one rank
         # (exercises the N>1 code path on a single-GPU box)
         self.force_exchange = os.environ.get("MPPI_FORCE_EXCHANGE") == "1"
@@ -111,7 +125,9 @@ class ShardedController:
             raise ValueError("exchange must be auto, p2p or rccl")
         self.p2p, self.p2p_note = False, "not requested"
         sharded = self.world > 1 or self.force_exchange
-        if sharded and exchange != "rccl" and hasattr(self.backend, "p2p_export"):
+        if self.normalize and exchange == "p2p":
+            raise RuntimeError("normalize_cost: the direct exchange carries the records only; use exchange='rccl' or 'auto'")
+        if sharded and exchange != "rccl" and hasattr(self.backend, "p2p_export") and not self.normalize:
             self.p2p, self.p2p_note = self._bring_up_p2p(p2p_timeout_ms)
             if exchange == "p2p" and not self.p2p:
                 raise RuntimeError("direct exchange requested but unavailable: " + self.p2p_note)
@@ -176,8 +192,17 @@ class ShardedController:
                     raise ExchangeTimeout(str(e)) from None
                 raise
             return self.u
-        self.backend.partial(x, self.record)
-        if self.world > 1 or (self.force_exchange and dist.is_initialized()):
+        collective = self.world > 1 or (self.force_exchange and dist.is_initialized())
+        if self.normalize:
+            self.backend.cost_range(x, self.range)  # {min, max} of this rank's costs
+            if collective:  # min of the minima and max of the maxima in ONE all-reduce: MAX over {-min, max}
+                self.range[0].neg_()
+                dist.all_reduce(self.range, op=dist.ReduceOp.MAX, group=self.group)
+                self.range[0].neg_()
+            self.backend.partial_normalized(x, self.range, self.record)
+        else:
+            self.backend.partial(x, self.record)
+        if collective:
             dist.all_gather_into_tensor(self.records, self.record, group=self.group)
             self.backend.finish(self.records, self.world, self.u)
         else:

@@ -20,7 +20,8 @@ from oracle import oracle as orc  # noqa: E402
 class OracleShardBackend:
     device = torch.device("cpu")
 
-    def __init__(self, rank, world, k, tau, s_dim, a_dim, sigma, goal, lam, seed, dt=0.1, mass=1.0):
+    def __init__(self, rank, world, k, tau, s_dim, a_dim, sigma, goal, lam, seed, dt=0.1, mass=1.0, normalize_cost=False):
+        self.normalize = bool(normalize_cost)
         from mppi_tf_amd.distributed import shard_bounds
         self.lo, self.hi = shard_bounds(k, rank, world)
         self.tau, self.a, self.s, self.lam, self.seed = tau, a_dim, s_dim, lam, seed
@@ -36,6 +37,20 @@ class OracleShardBackend:
         beta = c.min()
         e = np.exp(-(c - beta) / self.lam)
         V = np.tensordot(e, eps.astype(np.float64), axes=(0, 0)).ravel()
+        record.copy_(torch.from_numpy(np.concatenate([[beta, e.sum()], V]).astype(np.float32)))
+
+    # normalizeCost (controller_base.py:468-474): this shard's cost range, then the record of the costs normalised with the agreed one
+    def cost_range(self, x, rng):
+        self.eps_n = orc.noise(self.seed, self.step_no, self.lo, self.hi - self.lo, self.tau, self.a, self.sigma)
+        self.c_n = self.p.rollout_cost(x.numpy(), self.U, self.eps_n)
+        rng.copy_(torch.tensor([self.c_n.min(), self.c_n.max()], dtype=torch.float32))
+
+    def partial_normalized(self, x, rng, record):
+        mn, mx = (np.float32(v) for v in rng.numpy())
+        c = ((self.c_n - mn) / (mx - mn)).astype(np.float64)
+        beta = c.min()
+        e = np.exp(-(c - beta) / self.lam)
+        V = np.tensordot(e, self.eps_n.astype(np.float64), axes=(0, 0)).ravel()
         record.copy_(torch.from_numpy(np.concatenate([[beta, e.sum()], V]).astype(np.float32)))
 
     def finish(self, records, n_records, u):

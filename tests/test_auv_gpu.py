@@ -409,6 +409,37 @@ def test_auv_sharded_equals_unsharded_and_normalize(m, G):
     assert np.abs(un - u_ref).max() / 200.0 < 1e-5
 
 
+def test_auv_sharded_normalize_cost(m, G):
+    """normalizeCost on a K-sharded 13-state controller (mppi_shard_cost_range / mppi_shard_partial_normalized): four shards agree on
+    the global cost range and give the unsharded normalised step's control, replicated bit-identically."""
+    import torch
+    K, H, shards = 2048, 8, 4
+    full, _, _, x0, U, _ = auv_case(m, G, K, H, "quat", seed=7, normalize_cost=True)
+    hs = [auv_case(m, G, K, H, "quat", seed=7, normalize_cost=True, shard_rank=g, shard_count=shards)[0] for g in range(shards)]
+    full.set_action_sequence(U)
+    u_full = full.next(x0)
+    c = full.debug_get(m.DBG_COSTS)
+    xd = torch.tensor(x0, device="cuda")
+    n = hs[0].record_size
+    recs, rng = torch.zeros(shards * n, device="cuda"), torch.zeros(shards, 2, device="cuda")
+    us = [torch.zeros(6, device="cuda") for _ in range(shards)]
+    for g, hg in enumerate(hs):
+        hg.set_action_sequence(U)
+        hg.shard_cost_range(xd.data_ptr(), rng[g].data_ptr())
+        hg.synchronize()
+    agreed = torch.stack([rng[:, 0].min(), rng[:, 1].max()]).contiguous()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(agreed.cpu().numpy(), np.array([c.min(), c.max()], F32))
+    for g, hg in enumerate(hs):
+        hg.shard_partial_normalized(xd.data_ptr(), agreed.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
+        hg.synchronize()
+    for g, hg in enumerate(hs):
+        hg.shard_finish(recs.data_ptr(), shards, us[g].data_ptr())
+        hg.synchronize()
+        np.testing.assert_array_equal(us[g].cpu().numpy(), us[0].cpu().numpy())
+        np.testing.assert_allclose(us[g].cpu().numpy() / 200.0, u_full / 200.0, rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize("hid,n_hidden,tuning", [(32, 3, None), (32, 3, {"mlp32_valu": 1}), (16, 2, None), (32, 1, None), (32, 2, None),
                                                  (32, 3, "bf16x3"), (32, 1, "bf16x3")],
                          ids=["32x3-mfma", "32x3-valu", "16x2", "32x1-mfma", "32x2-mfma", "32x3-bf16x3", "32x1-bf16x3"])

@@ -27,7 +27,7 @@ def test_header_declares_the_reference_surface():
     names = declared_functions()
     for must in ("mppi_create", "mppi_destroy", "mppi_next", "mppi_next_with_noise", "mppi_set_goal",
                  "mppi_save_next", "mppi_to_csv", "mppi_rollout_cost", "mppi_update", "mppi_shard_partial",
-                 "mppi_shard_finish"):
+                 "mppi_shard_finish", "mppi_shard_cost_range", "mppi_shard_partial_normalized", "mppi_set_mlp"):
         assert must in names
     assert len(names) >= 30
 

@@ -52,6 +52,38 @@ def test_sharded_control_loop_matches_unsharded(world, tmp_path, unsharded):
     np.testing.assert_allclose(res[0]["U"], unsharded["U"], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_normalize_cost_agrees_on_the_global_cost_range(world, tmp_path):
+    """normalizeCost=True (controller_base.py:468-474) over shards: ShardedController reduces the ranks' {min, max} cost with one
+    all-reduce before the records are made. Against the UNSHARDED normalised update computed here from the oracle's pieces."""
+    cfg = dict(CFG, normalize_cost=True, lam=0.3)
+    env_cfg, steps = json.dumps(cfg), 3
+    out = str(tmp_path / ("resn_w%d" % world))
+    env = dict(os.environ, MPPI_TEST_CFG=env_cfg, MPPI_TEST_OUT=out, MPPI_TEST_STEPS=str(steps), OMP_NUM_THREADS="2", MPPI_TEST_P2P="")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = [json.load(open("%s.%d" % (out, g))) for g in range(world)]
+    assert [r["exchange"] for r in res] == ["rccl"] * world
+    for r in res[1:]:
+        assert r["u"] == res[0]["u"] and r["U"] == res[0]["U"]
+    from oracle import oracle as orc
+    p = orc.Problem(tau=cfg["tau"], s=cfg["s_dim"], a=cfg["a_dim"], lam=cfg["lam"], sigma=cfg["sigma"], goal=cfg["goal"])
+    A, B = orc.pm_matrices(0.1, 1.0, cfg["s_dim"], cfg["a_dim"])
+    x, U, us = np.zeros(cfg["s_dim"], np.float32), np.zeros((cfg["tau"], cfg["a_dim"]), np.float32), []
+    for step in range(steps):
+        eps = orc.noise(cfg["seed"], step, 0, cfg["k"], cfg["tau"], cfg["a_dim"], np.asarray(cfg["sigma"], np.float32))
+        Unew = orc.update(p.rollout_cost(x, U, eps), eps, U, cfg["lam"], normalize=True)["Unew"]
+        us.append(Unew[0].copy())
+        U = np.vstack([Unew[1:], np.zeros((1, cfg["a_dim"]), np.float32)])
+        x = orc.model_step(A, B, x[None], us[-1][None])[0]
+    np.testing.assert_allclose(res[0]["u"], us, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(res[0]["U"], U, rtol=0, atol=2e-6)
+    # and it differs from the plain update: the option is really on
+    assert np.abs(np.asarray(res[0]["u"]) - np.asarray(launch(world, tmp_path)[0]["u"])).max() > 1e-4
+
+
 @pytest.mark.parametrize("mode", ["ok", "open_fails", "probe_fails"])
 def test_direct_exchange_bring_up_votes_and_falls_back(mode, tmp_path, unsharded):
     """ShardedController's direct-exchange bring-up on CPU with a test double: when mapping a peer or a probe fails on

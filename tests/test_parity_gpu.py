@@ -408,6 +408,94 @@ def test_sharded_records_combine_to_the_unsharded_step(m, shards):
                 np.testing.assert_array_equal(h.debug_get(m.DBG_COSTS), c_full[h.k_offset:h.k_offset + h.k_local])
 
 
+def run_sharded_normalized(m, make, shards, x, steps=2):
+    """The K-sharded normalizeCost step on ONE GPU: every shard reports its cost range, the ranges are reduced the way
+    ShardedController reduces them (min of the minima, max of the maxima), every shard makes its record with the agreed range, the
+    records are combined on every shard. Returns per step (u of every shard, the agreed range)."""
+    import torch
+    hs = [make(shard_rank=g, shard_count=shards) for g in range(shards)]
+    n, a = hs[0].record_size, hs[0].a
+    xd = torch.tensor(x, device="cuda")
+    recs = torch.zeros(shards * n, device="cuda")
+    rng = torch.zeros(shards, 2, device="cuda")
+    us = [torch.zeros(a, device="cuda") for _ in range(shards)]
+    out = []
+    for step in range(steps):
+        for g, h in enumerate(hs):
+            h.shard_cost_range(xd.data_ptr(), rng[g].data_ptr())
+            h.synchronize()
+        agreed = torch.stack([rng[:, 0].min(), rng[:, 1].max()]).contiguous()
+        torch.cuda.synchronize()
+        for g, h in enumerate(hs):
+            h.shard_partial_normalized(xd.data_ptr(), agreed.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
+            h.synchronize()
+        for g, h in enumerate(hs):
+            h.shard_finish(recs.data_ptr(), shards, us[g].data_ptr())
+            h.synchronize()
+        out.append(([u.cpu().numpy().copy() for u in us], agreed.cpu().numpy().copy()))
+    return hs, out
+
+
+@pytest.mark.parametrize("path", ["two_pass", "tile", "mlp32"])
+@pytest.mark.parametrize("shards", [1, 3])
+def test_sharded_normalize_cost_equals_the_unsharded_normalised_step(m, path, shards):
+    """normalizeCost=True (controller_base.py:468-474) on a K-sharded controller: mppi_shard_cost_range -> the ranks agree on the
+    global {min, max} -> mppi_shard_partial_normalized -> mppi_shard_finish. On the two-pass producer/consumer path, on the tile kernel
+    (cost pass, normalise, record pass) and on a learned model. One shard holding everything and three shards (ragged: K is no
+    multiple of 3) give mppi_next's controls to 2e-6 (the float rounding of the records), replicated bit-identically; the agreed range IS the range of the
+    unsharded handle's costs."""
+    K, H, a, lam = (5000, 24, 3, 0.3) if path != "mlp32" else (2048, 8, 3, 0.3)
+    if path == "mlp32":
+        mlp = make_mlp(6, 3, seed=4, hid=32, n_hidden=3)
+        make = lambda **kw: make_mlp_pair(m, K, H, a, mlp, lam=lam, normalize_cost=True, seed=31, **kw)[0]
+    else:
+        tun = {"force_tile_kernel": 1} if path == "tile" else None
+        make = lambda **kw: make_pair(m, K, H, a, lam=lam, normalize=True, seed=31, tuning=tun, **kw)[0]
+    full = make()
+    name = full.rollout_kernel_name()
+    assert ("k_rollout_pc" in name) == (path == "two_pass"), name
+    x = np.array([0.2, 0.1, -0.3, 0, 0.5, -0.1], F32)
+    hs, out = run_sharded_normalized(m, make, shards, x)
+    for step, (us, agreed) in enumerate(out):
+        u_full = full.next(x)
+        c = full.debug_get(m.DBG_COSTS)
+        np.testing.assert_array_equal(agreed, np.array([c.min(), c.max()], F32))
+        for u in us[1:]:
+            np.testing.assert_array_equal(u, us[0])
+        np.testing.assert_allclose(us[0], u_full, rtol=0, atol=2e-6)
+    for h in hs:
+        np.testing.assert_allclose(h.get_action_sequence(), full.get_action_sequence(), rtol=0, atol=2e-6)
+        assert h.get_step_counter() == 2
+    # the plain phase 1 refuses a sharded normalising handle, and the normalising calls refuse a plain handle
+    import torch
+    if shards > 1:
+        with pytest.raises(m.MppiError):
+            hs[0].shard_partial(torch.zeros(6, device="cuda").data_ptr(), torch.zeros(hs[0].record_size, device="cuda").data_ptr())
+    plain = make_pair(m, 256, 8, 3)[0]
+    with pytest.raises(m.MppiError):
+        plain.shard_cost_range(torch.zeros(6, device="cuda").data_ptr(), torch.zeros(2, device="cuda").data_ptr())
+
+
+def test_sharded_controller_with_normalize_cost(m, monkeypatch):
+    """ShardedController(normalize_cost=True) on the real backend, exchange forced on one rank: the range / record / finish sequence
+    gives the unsharded handle's controls (2e-6); the direct exchange is not brought up for it (it carries the records only)."""
+    import torch
+    from mppi_tf_amd.distributed import ShardedController
+    monkeypatch.setenv("MPPI_FORCE_EXCHANGE", "1")
+    monkeypatch.delenv("MPPI_EXCHANGE", raising=False)
+    cfg = dict(k=4096, tau=32, s_dim=6, a_dim=3, sigma=0.25 * np.eye(3), goal=GOAL3, seed=11, lam=0.5, normalize_cost=True)
+    ctl = ShardedController(**cfg)
+    assert ctl.exchange == "rccl" and ctl.normalize
+    ref = m.Handle(**cfg)
+    x = torch.tensor([0.2, 0.1, -0.3, 0, 0.5, -0.1], device="cuda")
+    for _ in range(3):
+        u = ctl.next(x)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(u.cpu().numpy(), ref.next(x.cpu().numpy()), rtol=0, atol=2e-6)
+    with pytest.raises(RuntimeError):
+        ShardedController(exchange="p2p", **cfg)
+
+
 # =============================================================== full-size properties (C3)
 def test_full_size_properties_point_mass3d(m):
     K, H, a = 65536, 64, 3
