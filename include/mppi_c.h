@@ -273,9 +273,9 @@ mppi_status mppi_shard_partial(mppi_handle *h, const float *x_dev, float *record
 mppi_status mppi_shard_finish(mppi_handle *h, const float *records_dev, int n_records, float *u_dev, void *stream);
 /* normalize_cost on a sharded handle (controller_base.py:468-474: c' = (c - min c)/(max c - min c) over ALL K samples). Phase 1
  * splits in two around a second, 2-float exchange:
- *   mppi_shard_cost_range          rollouts of this shard; range_dev[2] = {min, max} of ITS sample costs
- *   (the ranks reduce the ranges: min of the minima, max of the maxima — e.g. ONE all-reduce(MAX) of {-min, max})
- *   mppi_shard_partial_normalized  range_dev[2] = the agreed {min, max}: this shard's record from the costs normalised with it
+ *   mppi_shard_cost_range          rollouts of this shard; range_dev[2] = {-min, max} of ITS sample costs
+ *   (the ranks reduce the pairs with ONE all-reduce(MAX): max of the -minima = -(global min), max of the maxima)
+ *   mppi_shard_partial_normalized  range_dev[2] = the agreed {-min, max}: this shard's record from the costs normalised with it
  * then mppi_shard_finish as always. Same x_dev in both calls of a step; mppi_shard_partial and the direct exchange refuse such
  * a handle (MPPI_ERR_UNSUPPORTED). The result is the unsharded normalised step's up to the float rounding of the records (2e-6). */
 mppi_status mppi_shard_cost_range(mppi_handle *h, const float *x_dev, float *range_dev, void *stream);

@@ -462,11 +462,11 @@ class Handle:
         self._check(self.lib.mppi_shard_finish(self.h, records_ptr, n_records, u_ptr, stream))
 
     def shard_cost_range(self, x_ptr, range_ptr, stream=0):
-        """normalize_cost on a sharded handle, first half: {min, max} of this shard's sample costs -> range_ptr[2]"""
+        """normalize_cost on a sharded handle, first half: {-min, max} of this shard's sample costs -> range_ptr[2]"""
         self._check(self.lib.mppi_shard_cost_range(self.h, x_ptr, range_ptr, stream))
 
     def shard_partial_normalized(self, x_ptr, range_ptr, record_ptr, stream=0):
-        """... second half: range_ptr[2] = the {min, max} all ranks agreed on -> this shard's record"""
+        """... second half: range_ptr[2] = the {-min, max} all ranks agreed on (all-reduce MAX) -> this shard's record"""
         self._check(self.lib.mppi_shard_partial_normalized(self.h, x_ptr, range_ptr, record_ptr, stream))
 
     # ---- options of the Python reference's update ---------------------------------------------

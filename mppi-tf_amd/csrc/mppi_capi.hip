@@ -788,7 +788,7 @@ extern "C" mppi_status mppi_shard_partial(mppi_handle *h, const float *x_dev, fl
 
 // ---- normalizeCost on a K-sharded controller -----------------------------------------------------
 // c' = (c - min)/(max - min) needs the min and max over ALL samples (controller_base.py:468-474): each shard rolls its samples and
-// reports its own range; the ranks reduce the ranges (min of the minima, max of the maxima: one 2-float collective); each shard then
+// reports its own {-min, max}; the ranks reduce the pairs (ONE 2-float all-reduce(MAX)); each shard then
 // makes its record from costs normalised with the agreed range. Both halves take the path enqueue_partials takes on an unsharded
 // handle — two passes of k_rollout_pc where it serves the configuration, else cost pass + normalise + record pass; which of the two
 // depends on the configuration only, never on the shard's size: all ranks make their records in the same units.

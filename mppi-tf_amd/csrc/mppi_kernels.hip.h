@@ -1120,16 +1120,16 @@ __global__ __launch_bounds__(1024) void k_cost_minmax(const float *__restrict__ 
         for (int w = 1; w < nt / 64; ++w) { mn = fminf(mn, mn_s[w]); mx = fmaxf(mx, mx_s[w]); }
         out[0] = mn; out[1] = mx - mn;
         if (nil_out != nullptr) { const float v = neg_inv_lambda / (mx - mn); out[2] = v; *nil_out = v; }
-        if (range_out != nullptr) { range_out[0] = mn; range_out[1] = mx; } // a shard's own range: reduced over the ranks by the caller
+        if (range_out != nullptr) { range_out[0] = -mn; range_out[1] = mx; } // a shard's own {-min, max}: both reduce over the ranks with MAX
     }
 }
 
-// K-sharded normalizeCost (mppi_shard_partial_normalized): the GLOBAL {min, max} the ranks agreed on becomes this handle's
+// K-sharded normalizeCost (mppi_shard_partial_normalized): the GLOBAL {-min, max} the ranks agreed on becomes this handle's
 // {min, max - min, -1/(lambda (max - min))}, exactly what k_cost_minmax leaves on an unsharded handle
 __global__ void k_range_apply(const float *__restrict__ range, float *__restrict__ out, float neg_inv_lambda, float *__restrict__ nil_out)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const float mn = range[0], mx = range[1];
+        const float mn = -range[0], mx = range[1];
         out[0] = mn; out[1] = mx - mn;
         const float v = neg_inv_lambda / (mx - mn);
         out[2] = v;

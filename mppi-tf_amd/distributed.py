@@ -194,11 +194,9 @@ class ShardedController:
             return self.u
         collective = self.world > 1 or (self.force_exchange and dist.is_initialized())
         if self.normalize:
-            self.backend.cost_range(x, self.range)  # {min, max} of this rank's costs
-            if collective:  # min of the minima and max of the maxima in ONE all-reduce: MAX over {-min, max}
-                self.range[0].neg_()
+            self.backend.cost_range(x, self.range)  # {-min, max} of this rank's costs
+            if collective:  # the global min and max in ONE all-reduce: MAX over {-min, max}
                 dist.all_reduce(self.range, op=dist.ReduceOp.MAX, group=self.group)
-                self.range[0].neg_()
             self.backend.partial_normalized(x, self.range, self.record)
         else:
             self.backend.partial(x, self.record)

@@ -43,10 +43,10 @@ class OracleShardBackend:
     def cost_range(self, x, rng):
         self.eps_n = orc.noise(self.seed, self.step_no, self.lo, self.hi - self.lo, self.tau, self.a, self.sigma)
         self.c_n = self.p.rollout_cost(x.numpy(), self.U, self.eps_n)
-        rng.copy_(torch.tensor([self.c_n.min(), self.c_n.max()], dtype=torch.float32))
+        rng.copy_(torch.tensor([-self.c_n.min(), self.c_n.max()], dtype=torch.float32))  # {-min, max}: both reduce with MAX
 
     def partial_normalized(self, x, rng, record):
-        mn, mx = (np.float32(v) for v in rng.numpy())
+        mn, mx = -np.float32(rng[0].item()), np.float32(rng[1].item())
         c = ((self.c_n - mn) / (mx - mn)).astype(np.float64)
         beta = c.min()
         e = np.exp(-(c - beta) / self.lam)

@@ -427,9 +427,9 @@ def test_auv_sharded_normalize_cost(m, G):
         hg.set_action_sequence(U)
         hg.shard_cost_range(xd.data_ptr(), rng[g].data_ptr())
         hg.synchronize()
-    agreed = torch.stack([rng[:, 0].min(), rng[:, 1].max()]).contiguous()
+    agreed = rng.max(dim=0).values.contiguous()
     torch.cuda.synchronize()
-    np.testing.assert_array_equal(agreed.cpu().numpy(), np.array([c.min(), c.max()], F32))
+    np.testing.assert_array_equal(agreed.cpu().numpy(), np.array([-c.min(), c.max()], F32))
     for g, hg in enumerate(hs):
         hg.shard_partial_normalized(xd.data_ptr(), agreed.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
         hg.synchronize()

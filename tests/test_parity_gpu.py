@@ -410,7 +410,7 @@ def test_sharded_records_combine_to_the_unsharded_step(m, shards):
 
 def run_sharded_normalized(m, make, shards, x, steps=2):
     """The K-sharded normalizeCost step on ONE GPU: every shard reports its cost range, the ranges are reduced the way
-    ShardedController reduces them (min of the minima, max of the maxima), every shard makes its record with the agreed range, the
+    ShardedController reduces them (MAX over the {-min, max} pairs), every shard makes its record with the agreed range, the
     records are combined on every shard. Returns per step (u of every shard, the agreed range)."""
     import torch
     hs = [make(shard_rank=g, shard_count=shards) for g in range(shards)]
@@ -424,7 +424,7 @@ def run_sharded_normalized(m, make, shards, x, steps=2):
         for g, h in enumerate(hs):
             h.shard_cost_range(xd.data_ptr(), rng[g].data_ptr())
             h.synchronize()
-        agreed = torch.stack([rng[:, 0].min(), rng[:, 1].max()]).contiguous()
+        agreed = rng.max(dim=0).values.contiguous()
         torch.cuda.synchronize()
         for g, h in enumerate(hs):
             h.shard_partial_normalized(xd.data_ptr(), agreed.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
@@ -459,7 +459,7 @@ def test_sharded_normalize_cost_equals_the_unsharded_normalised_step(m, path, sh
     for step, (us, agreed) in enumerate(out):
         u_full = full.next(x)
         c = full.debug_get(m.DBG_COSTS)
-        np.testing.assert_array_equal(agreed, np.array([c.min(), c.max()], F32))
+        np.testing.assert_array_equal(agreed, np.array([-c.min(), c.max()], F32))
         for u in us[1:]:
             np.testing.assert_array_equal(u, us[0])
         np.testing.assert_allclose(us[0], u_full, rtol=0, atol=2e-6)

@@ -41,5 +41,10 @@ out["unsharded_us"] = run(ShardedController(**cfg), steps)
 os.environ["MPPI_FORCE_EXCHANGE"] = "1"
 c = ShardedController(exchange="rccl", **cfg)
 out["rccl_one_rank_us"] = run(c, steps)
+# normalizeCost: unsharded (two passes of the rollout kernel) against the sharded form with its second, 2-float collective
+os.environ.pop("MPPI_FORCE_EXCHANGE")
+out["normalize_unsharded_us"] = run(ShardedController(normalize_cost=True, **cfg), steps)
+os.environ["MPPI_FORCE_EXCHANGE"] = "1"
+out["normalize_rccl_one_rank_us"] = run(ShardedController(normalize_cost=True, **cfg), steps)
 print(json.dumps(out))
 dist.destroy_process_group()
