@@ -60,31 +60,120 @@ def parse_args():
                     help="default: pm3d (BASELINE configs[2], the metric's config) plus sub-records of the other configs")
     ap.add_argument("--horizon", type=int, default=None, help="H (default 64; 32 for pm1d)")
     ap.add_argument("--samples", type=int, default=None, help="rollouts PER GPU (default 65536; 4096 for pm2d, 128 for pm1d)")
-    ap.add_argument("--min-time", type=float, default=0.2, help="repeat the K-step batch until this many seconds are timed")
+    ap.add_argument("--min-time", type=float, default=1.0, help="repeat the K-step batch until this many seconds are timed (headline only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true")
     return ap.parse_args()
 
 
-def self_launch(args):
-    """`python bench.py --gpus N` typed directly: run the N ranks as a child job and relay its line and exit code.
-    Nothing in this process has touched a GPU (torch is not even imported yet)."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+def run_ranks(args, exchange, timeout_s, extra=()):
+    """One child job: N ranks under torch.distributed.run with MPPI_EXCHANGE=exchange, at most timeout_s seconds.
+    -> (parsed JSON line or None, outcome text). The child is its own process group: on a timeout exactly that group is
+    killed (SIGTERM, then SIGKILL after 10 s). Nothing is ever re-exec'd and this process never touches a GPU."""
+    import signal
+    import tempfile
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL and the hipIpc inboxes need on this pool
+    env["MPPI_EXCHANGE"] = exchange
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
-    lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{") and '"metric"' in l]
-    if lines:
-        sys.stdout.write(lines[-1] + "\n")
-        sys.stdout.flush()
-    elif p.returncode == 0:
-        sys.stderr.write("bench.py: the ranks exited 0 without a JSON line\n")
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + list(extra)
+    sys.stderr.write("bench.py: %d ranks, MPPI_EXCHANGE=%s, limit %d s\n" % (args.gpus, exchange, timeout_s))
+    sys.stderr.flush()
+    with tempfile.TemporaryFile() as err:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=err, env=env, start_new_session=True)
+        timed_out = False
+        try:
+            out, _ = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            for sig, wait in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
+                try:
+                    os.killpg(p.pid, sig)  # the group this call started, nothing else
+                except ProcessLookupError:
+                    pass
+                try:
+                    out, _ = p.communicate(timeout=wait)
+                    break
+                except subprocess.TimeoutExpired:
+                    out = b""
+        err.seek(0)
+        etxt = err.read().decode(errors="replace")
+    sys.stderr.write(etxt)
+    sys.stderr.flush()
+    lines = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{") and '"metric"' in l]
+    tail = " | ".join(l.strip() for l in etxt.splitlines()[-6:] if l.strip())[-400:]
+    if timed_out:
+        return None, "failed: no line within %d s (ranks killed); %s" % (timeout_s, tail)
+    if not lines:
+        return None, "failed: rc=%d; %s" % (p.returncode, tail)
+    try:
+        return json.loads(lines[-1]), "ok"
+    except ValueError:
+        return None, "failed: unparsable line"
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` typed directly (what the driver's scaling run does): run the N ranks as CHILD jobs and relay one
+    line. Nothing in this process has touched a GPU (torch is not even imported yet).
+
+    VERDICT r03: the first multi-GPU lease must not come back empty. So TWO jobs, one after the other: MPPI_EXCHANGE=rccl first —
+    the all-gather path, nothing but RCCL between the devices; its line is kept — then `auto`, which tries the direct record
+    exchange (peer stores over xGMI inside the finish kernel, never run between two real devices so far). A fault, hang or bad
+    exit of the second job costs a field of the line, not the line. Each job has a time limit well inside the driver's 600 s
+    (MPPI_BENCH_BUDGET_S, default 540 s in all). The better line is printed, with both outcomes under `exchange`."""
+    t_start = time.time()
+    budget = float(os.environ.get("MPPI_BENCH_BUDGET_S", "540"))
+    if os.environ.get("MPPI_BENCH_ONE_GPU") == "1":
+        modes = ["p2p"]   # the one-GPU rehearsal: RCCL refuses two ranks on one device
+    elif os.environ.get("MPPI_EXCHANGE"):
+        modes = [os.environ["MPPI_EXCHANGE"]]
+    else:
+        modes = ["rccl", "auto"]
+    got, outcome = {}, {}
+    for i, mode in enumerate(modes):
+        left = budget - (time.time() - t_start)
+        last = i == len(modes) - 1
+        limit = left - 15 if last else min(300.0, 0.6 * left)
+        if limit < 45:
+            outcome[mode] = "skipped: %d s left of the %d s budget" % (left, budget)
+            continue
+        # the second job re-measures the headline only: the configs[4] sub-record (8 ms steps) does not depend on the exchange
+        extra = ["--no-subrecords"] if (i > 0 and got) else []
+        got[mode], outcome[mode] = run_ranks(args, mode, int(limit), extra)
+        if got[mode] is None:
+            del got[mode]
+    if not got:
+        sys.stderr.write("bench.py: no job produced a line: %s\n" % json.dumps(outcome))
         sys.exit(1)
-    sys.exit(p.returncode)
+    best = max(got, key=lambda m: got[m]["value"])
+    line = got[best]
+    if len(modes) > 1:
+        ex = dict(line.get("exchange") or {})
+        for mode in modes:
+            key = "rccl" if mode == "rccl" else "p2p"
+            if mode in got:
+                g = got[mode]
+                used = (g.get("exchange") or {}).get("used", g["config"].get("exchange"))
+                rec = {"value": r4(g["value"]), "ms_per_step": r4(g["ms_per_step"]), "used": used}
+                if mode != "rccl" and used != "p2p":
+                    rec["note"] = "direct exchange not used: %s" % (g.get("exchange") or {}).get("direct_exchange_bring_up")
+                ex[key] = rec
+            else:
+                ex[key] = outcome[mode]
+        ex["printed"] = "rccl" if best == "rccl" else "p2p"
+        line["exchange"] = ex
+        if "sub_records" not in line:  # the second job ran without them
+            for mode in modes:
+                if mode in got and "sub_records" in got[mode]:
+                    line["sub_records"] = got[mode]["sub_records"]
+                    line["sub_roofline_unit"] = got[mode].get("sub_roofline_unit")
+                    break
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
+    sys.exit(0)
 
 
 def cfg_of(workload, H):
@@ -345,7 +434,7 @@ class Runner:
                "rollouts_per_s": K * self.world * steps / el, "ms_per_step": 1e3 * el / steps, "rank_ms_per_step": rank_ms,
                "kernel": h.rollout_kernel_name(), "kernel_ms_avg": roll_ms, "finish_kernel_ms_avg": fin_ms, "launches_timed": n_prof,
                "algorithmic_bytes_per_launch": bytes_ss * state_steps + 8 * K, "algorithmic_flop_per_launch": flop_ss * state_steps,
-               "exchange": ctl.exchange, "p2p_note": ctl.p2p_note, "record_size": h.record_size, "mlp": mlp}
+               "exchange": ctl.exchange, "p2p_note": ctl.p2p_note, "rccl_note": ctl.rccl_note, "record_size": h.record_size, "mlp": mlp}
         del ctl
         return res
 
@@ -513,7 +602,7 @@ def main():
             out["rccl_ranks"] = dist.get_world_size() if dist.is_initialized() else 1
             if rehearsal:
                 out["rehearsal"] = "MPPI_BENCH_ONE_GPU=1: %d ranks share ONE GPU over gloo + hipIpc; not a scaling measurement" % world
-            out["exchange"] = {"used": r["exchange"], "direct_exchange_bring_up": r["p2p_note"]}
+            out["exchange"] = {"used": r["exchange"], "direct_exchange_bring_up": r["p2p_note"], "rccl_call": r["rccl_note"]}
             out["rank_ms_per_step"] = [r4(q) for q in r["rank_ms_per_step"]]
         if subs:
             out["sub_records"] = [sub_record(s) for s in subs]

@@ -2,10 +2,13 @@
 // The reference's loop is: get_x -> ctrl.next(x) -> env.simulate(u) -> get_x -> ctrl.saveNext(x);
 // then ctrl.toCSV(...), then a (commented-out) chrono loop around ctrl.next. MuJoCo is replaced by the
 // same point-mass plant stepped on the host (x' = A x + B u, envs/point_mass*.xml dimensions).
-//   usage: host_loop [k=65536] [tau=64] [a_dim=3] [steps=100] [csv]
+//   usage: host_loop [k=65536] [tau=64] [a_dim=3] [steps=100] [csv | -] [trace]
+// "trace" as the 6th argument switches on the library's roctx ranges (mppi:step > mppi:rollout / mppi:finish; the reference brackets its
+// step with tf.profiler, controller_base.py:241-248): `rocprofv3 --marker-trace --kernel-trace -- examples/host_loop 65536 64 3 20 - trace`.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "mppi/controller_base.hpp"
@@ -24,6 +27,10 @@ int main(int argc, char const *argv[])
         const float pos[3] = {1.f, 0.5f, 0.75f}; // target site of envs/point_mass3d.xml:35
         for (int i = 0; i < aDim; i++) { goal.push_back(pos[i % 3]); goal.push_back(0.f); }
         if (!ctrl.setGoal(goal)) return 2;
+        if (argc > 6 && std::string(argv[6]) == "trace" && mppi_set_tuning(ctrl.handle(), MPPI_TUNE_TRACE, 1) != MPPI_OK) {
+            fprintf(stderr, "host_loop: %s\n", mppi_last_error(ctrl.handle()));
+            return 4;
+        }
         vector<float> state(sDim, 0.f), action(aDim, 0.f);
         float d2_init = 0;
         for (int i = 0; i < sDim; i++) d2_init += (state[i] - goal[i]) * (state[i] - goal[i]);
@@ -38,7 +45,7 @@ int main(int argc, char const *argv[])
             ctrl.saveNext(state);
             done = ++it >= steps;
         }
-        if (argc > 5) ctrl.toCSV(argv[5]);
+        if (argc > 5 && std::string(argv[5]) != "-") ctrl.toCSV(argv[5]);
         float d2 = 0;
         for (int i = 0; i < sDim; i++) d2 += (state[i] - goal[i]) * (state[i] - goal[i]);
         printf("after %d closed-loop steps: |x-goal|^2 = %g\n", steps, d2);

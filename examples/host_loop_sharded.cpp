@@ -7,7 +7,11 @@
 // This is the single-process flavour (ncclCommInitAll); bench.py uses one process per GPU through torch.distributed.
 // With a 5th argument "p2p" the exchange is the direct one of include/mppi_c.h instead (mppi_shard_p2p_*: the finish
 // kernel stores the record into every GPU's inbox and spins for the others; peer access inside this one process).
-//   usage: host_loop_sharded [k_per_gpu=65536] [tau=64] [a_dim=3] [steps=100] [rccl|p2p]
+// With "step" the three calls become ONE: mppi_shard_step(h, x, u, &coll, stream) with coll = {ncclAllGather, ncclAllReduce, comm} —
+// the library calls RCCL's own entry points between its kernels (it links no collective library itself). One host thread per
+// GPU then (a single thread driving several communicators would need ncclGroupStart/End around calls that also enqueue kernels).
+// Prints the pipelined time per step and the HOST time of one step's enqueue (what a Python host pays several times over).
+//   usage: host_loop_sharded [k_per_gpu=65536] [tau=64] [a_dim=3] [steps=100] [rccl|p2p|step]
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -15,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mppi_c.h"
@@ -28,6 +33,7 @@ int main(int argc, char **argv)
     const int kper = argc > 1 ? atoi(argv[1]) : 65536, tau = argc > 2 ? atoi(argv[2]) : 64;
     const int a = argc > 3 ? atoi(argv[3]) : 3, steps = argc > 4 ? atoi(argv[4]) : 100, s = 2 * a;
     const bool p2p = argc > 5 && std::string(argv[5]) == "p2p";
+    const bool one_call = argc > 5 && std::string(argv[5]) == "step";
     int ndev = 0;
     CK_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) { fprintf(stderr, "no GPU\n"); return 1; }
@@ -70,7 +76,24 @@ int main(int argc, char **argv)
         }
     }
     std::vector<float> x(s, 0.f), u(a, 0.f), u_other(a, 0.f);
+    std::vector<mppi_collectives> coll(ndev);
+    for (int d = 0; d < ndev; ++d) // RCCL's entry points as they are: the signatures mppi_collectives declares are theirs
+        coll[d] = {reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, void *)>(&ncclAllGather),
+                   reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, void *)>(&ncclAllReduce), (void *)comm[d]};
+    auto steps_of = [&](int d, int n) -> int { // n whole steps of GPU d, one C call each
+        for (int it = 0; it < n; ++it) CK_MPPI(mppi_shard_step(h[d], x_dev[d], u_dev[d], &coll[d], st[d]), h[d]);
+        return 0;
+    };
     auto step = [&]() -> int {
+        if (one_call) {
+            if (ndev == 1) return steps_of(0, 1);
+            std::vector<int> rc(ndev, 0);
+            std::vector<std::thread> th;
+            for (int d = 0; d < ndev; ++d) th.emplace_back([&, d] { rc[d] = steps_of(d, 1); });
+            for (auto &t : th) t.join();
+            for (int d = 0; d < ndev; ++d) if (rc[d]) return rc[d];
+            return 0;
+        }
         if (p2p) {
             for (int d = 0; d < ndev; ++d) CK_MPPI(mppi_shard_p2p_step(h[d], x_dev[d], u_dev[d], st[d]), h[d]);
             return 0;
@@ -103,16 +126,28 @@ int main(int argc, char **argv)
     for (int i = 0; i < s; ++i) { d2 += (x[i] - goal[i]) * (x[i] - goal[i]); d2_init += goal[i] * goal[i]; }
     // pipelined timing: steps enqueued back to back, one synchronisation at the end
     auto t0 = std::chrono::high_resolution_clock::now();
-    for (int it = 0; it < 200; ++it) if (int rc = step()) return rc;
+    if (one_call && ndev > 1) { // one thread per GPU runs its 200 steps
+        std::vector<int> rc(ndev, 0);
+        std::vector<std::thread> th;
+        for (int d = 0; d < ndev; ++d) th.emplace_back([&, d] { rc[d] = steps_of(d, 200); });
+        for (auto &t : th) t.join();
+        for (int d = 0; d < ndev; ++d) if (rc[d]) return rc[d];
+    } else
+        for (int it = 0; it < 200; ++it) if (int rc = step()) return rc;
     for (int d = 0; d < ndev; ++d) { CK_HIP(hipSetDevice(d)); CK_HIP(hipStreamSynchronize(st[d])); }
     const double el = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count() / 200;
+    // host time of one step's enqueue: 20 steps into an EMPTY queue (nothing blocks on the GPU), timed before the synchronisation
+    auto h0 = std::chrono::high_resolution_clock::now();
+    for (int it = 0; it < 20; ++it) if (int rc = step()) return rc;
+    const double host_us = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - h0).count() / 20 * 1e6;
+    for (int d = 0; d < ndev; ++d) { CK_HIP(hipSetDevice(d)); CK_HIP(hipStreamSynchronize(st[d])); }
     for (int d = 0; d < ndev && p2p; ++d) {
         int late = 0;
         CK_MPPI(mppi_shard_p2p_status(h[d], &late), h[d]);
         if (late) { fprintf(stderr, "GPU %d: a packet missed its deadline\n", d); return 7; }
     }
-    printf("%s exchange, %d GPU(s), K=%d per GPU, tau=%d: |x-goal|^2 %g -> %g after %d closed-loop steps; %.1f us per sharded control step = %.3g rollouts/s\n",
-           p2p ? "direct" : "RCCL all-gather", ndev, kper, tau, d2_init, d2, steps, el * 1e6, (double)kper * ndev / el);
+    printf("%s exchange, %d GPU(s), K=%d per GPU, tau=%d: |x-goal|^2 %g -> %g after %d closed-loop steps; %.1f us per sharded control step = %.3g rollouts/s; host enqueue %.1f us per step\n",
+           p2p ? "direct" : (one_call ? "RCCL all-gather (mppi_shard_step)" : "RCCL all-gather"), ndev, kper, tau, d2_init, d2, steps, el * 1e6, (double)kper * ndev / el, host_us);
     for (int d = 0; d < ndev; ++d) { mppi_destroy(h[d]); ncclCommDestroy(comm[d]); }
     return d2 < 0.5f * d2_init ? 0 : 1;
 }

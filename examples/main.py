@@ -10,6 +10,7 @@ dumped as <log_dir>/controller/{config,task}.yaml (what ObserverBase does, obser
 exactly those two files back (utile.py:53-59 parse_dir) and repeats the experiment — same seed, same Philox stream,
 so the replayed transitions are bit-identical."""
 import argparse
+import glob
 import os
 import sys
 import time
@@ -156,7 +157,14 @@ def main():
         if not args.plant:
             ap.error("a learned model needs --plant (the system it controls and learns)")
         plant = get_model(parse_config(args.plant), 1, conf["dt"], s_dim, a_dim, name="plant")
-        learner = m.LearnerBase(model, bufferSize=max(args.steps, 1))
+        learner = m.LearnerBase(model, bufferSize=max(args.steps, 1), logPath=os.path.join(args.log_dir, "learner") if args.log_dir else None)
+        trained_steps = 0
+        if args.train and args.log_dir:  # resume: the newest weights_step<N> a previous --train run left (weights, normalisation, Adam state)
+            saved = sorted(glob.glob(os.path.join(learner.logdir, "weights_step*")), key=lambda f: int(f.rsplit("step", 1)[1]))
+            if saved:
+                learner.load_params(saved[-1])
+                trained_steps = learner.step
+                print("resumed the learned model from %s (%d Adam steps so far)" % (saved[-1], trained_steps))
     sim = AUVSimulation(plant if learned else model, conf.get("x0"), conf["dt"]) if auv else Simulation(conf.get("env"), s_dim, a_dim, None, False,
                                                                                                          dt=conf["dt"], mass=model_dict.get("mass", 1.0))
     cost = get_cost(args.task, conf["lambda"], conf.get("gamma", 1.0), conf.get("upsilon", 1.0), conf["noise"])
@@ -177,6 +185,8 @@ def main():
                 first, last = learner.train_all(learningRate=3e-3, epoch=200)
                 cont.update_model()
                 print("step %d: trained on %d transitions, normalised loss %.4f -> %.4f" % (step + 1, step + 1, first, last))
+                if args.log_dir:  # learner_base.py:66-68 save_params
+                    print("saved", learner.save_params(learner.step))
     steady = np.sort(ts[min(5, len(ts) - 1):])  # the first calls load the code objects
     goal_of = getattr(cost, "getGoal", None) or getattr(cost, "get_goal", None)
     if goal_of is not None and auv:  # StaticCost on 13 states / StaticQuatCost: distance in position

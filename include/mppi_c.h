@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 3 /* 3: the 13-state AUV family (MPPI_MODEL_AUV / _NN_AUV, mppi_auv_desc), StaticQuatCost / ElipseCost3D state costs,
+#define MPPI_ABI_VERSION 4 /* 4: mppi_shard_step (one call per sharded step, the caller's collectives as function pointers), mppi_learner_save /
+                              _load / _peek, MPPI_TUNE_TRACE (roctx ranges); mppi_set_mlp orders against the last step's stream;
+                              3: the 13-state AUV family (MPPI_MODEL_AUV / _NN_AUV, mppi_auv_desc), StaticQuatCost / ElipseCost3D state costs,
                               mppi_auv_pieces, the learner (mppi_learner_*); 2: state_cost_kind / ellipse, transition log, tuning */
 #define MPPI_MAX_S 32  /* largest state dimension  */
 #define MPPI_MAX_A 16  /* largest action dimension */
@@ -168,8 +170,9 @@ const char *mppi_last_error(const mppi_handle *h);
 mppi_status mppi_set_goal(mppi_handle *h, const float *goal, int n);
 /* Replaces the learned model's weights and normalisation on an existing handle (same layer widths as at creation): what the
  * reference's learner does to the variables the controller's graph reads (learners/learner_base.py:469-496 apply_gradients;
- * models/nn_model.py set_Xmean_Xstd / set_Ymean_Ystd / update_weights). Waits for the handle's stream, copies, takes effect with
- * the next step. MPPI_MODEL_MLP / _NN_AUV / _NN_AUV_SPEED handles. */
+ * models/nn_model.py set_Xmean_Xstd / set_Ymean_Ystd / update_weights). Waits for the handle's stream AND for the stream the last
+ * device-resident step was enqueued on (mppi_next_device / mppi_shard_*: a rollout in flight must not read half-replaced weights;
+ * ADVICE r03), copies, takes effect with the next step. MPPI_MODEL_MLP / _NN_AUV / _NN_AUV_SPEED handles. */
 mppi_status mppi_set_mlp(mppi_handle *h, const mppi_mlp_desc *mlp);
 /* replaces ControllerBase::next (controller_base.cpp:135-153): one control step with noise
  * drawn on the device (Philox4x32-10 via rocRAND's engine); returns u = U'[0] in u_out[a],
@@ -280,6 +283,26 @@ mppi_status mppi_shard_finish(mppi_handle *h, const float *records_dev, int n_re
  * a handle (MPPI_ERR_UNSUPPORTED). The result is the unsharded normalised step's up to the float rounding of the records (2e-6). */
 mppi_status mppi_shard_cost_range(mppi_handle *h, const float *x_dev, float *range_dev, void *stream);
 mppi_status mppi_shard_partial_normalized(mppi_handle *h, const float *x_dev, const float *range_dev, float *record_dev, void *stream);
+/* ONE call per sharded step on the collective path: rollouts of this shard -> its record -> the CALLER's all-gather
+ * -> combine, update, shift; enqueue only, x_dev[s] -> u_dev[a]. The library links no collective library: `coll` carries the two
+ * functions with EXACTLY the signatures of ncclAllGather / ncclAllReduce (RCCL exports them under these names), so a native host
+ * passes them as they are (examples/host_loop_sharded.cpp) and a Python host their addresses (mppi-tf_amd/distributed.py resolves
+ * them from the librccl.so its process already holds). The library calls
+ *     all_gather(own record (device, record_size floats), records (device, shard_count * record_size floats), record_size,
+ *                MPPI_COLL_FLOAT32, comm, stream)          — in place: the own record IS records + shard_rank * record_size
+ * and, for a normalize_cost handle only, first
+ *     all_reduce(range, range, 2, MPPI_COLL_FLOAT32, MPPI_COLL_MAX, comm, stream)   — {-min, max} of the sample costs, in place
+ * on the step's stream, between its own kernels. A non-zero return of either aborts the step with MPPI_ERR_EXCHANGE (nothing of
+ * the update has been enqueued then; mppi_last_error carries the code). The send / receive buffers belong to the handle. With
+ * shard_count == 1 and coll == NULL the collective is skipped (record -> finish on one device: the sharded sequence of kernels
+ * without a communicator). Same result, bit for bit, as mppi_shard_partial -> all-gather -> mppi_shard_finish. */
+enum { MPPI_COLL_FLOAT32 = 7 /* = ncclFloat32 */, MPPI_COLL_MAX = 2 /* = ncclMax */ };
+typedef struct {
+    int (*all_gather)(const void *sendbuff, void *recvbuff, size_t sendcount, int datatype, void *comm, void *stream);
+    int (*all_reduce)(const void *sendbuff, void *recvbuff, size_t count, int datatype, int op, void *comm, void *stream); /* normalize_cost only; else may be NULL */
+    void *comm; /* ncclComm_t of this rank */
+} mppi_collectives;
+mppi_status mppi_shard_step(mppi_handle *h, const float *x_dev, float *u_dev, const mppi_collectives *coll, void *stream);
 /* Wait for the handle's own stream. */
 mppi_status mppi_synchronize(mppi_handle *h);
 
@@ -331,7 +354,12 @@ enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instea
        MPPI_TUNE_SYNC_SPIN = 4,         /* 0: mppi_next waits for the stream instead of watching the pinned u slot      */
        MPPI_TUNE_P2P_FAULT = 5,         /* 1: inbox export fails, 2: probe reports failure (exercise the RCCL fallback) */
        MPPI_TUNE_MLP_V1 = 6,            /* 1: exact-fp32 MLP rollouts on the first kernel (8 waves per workgroup) instead of k_rollout_mlp2 */
-       MPPI_TUNE_MLP32_VALU = 7 };      /* 1: a Dense(32) network on k_rollout_mlp_small (vector ALU, scalar-cache weights) instead of k_rollout_mlp32 (matrix cores) */
+       MPPI_TUNE_MLP32_VALU = 7,        /* 1: a Dense(32) network on k_rollout_mlp_small (vector ALU, scalar-cache weights) instead of k_rollout_mlp32 (matrix cores) */
+       /* 1: roctx ranges "mppi:step" > "mppi:rollout" / "mppi:exchange" / "mppi:finish" around what every step enqueues (the reference brackets
+        * its step with tf.profiler.experimental.start/stop, controller_base.py:241-248, 587-595). libroctx64.so is dlopen'ed on first use —
+        * the library has no link dependency on it; the call fails with MPPI_ERR_UNSUPPORTED when it cannot be found. Shows in
+        * `rocprofv3 --marker-trace`. */
+       MPPI_TUNE_TRACE = 8 };
 mppi_status mppi_set_tuning(mppi_handle *h, int what, int value);
 
 /* ---- measurement (the reference only has a commented-out chrono loop, main.cpp:55-64) ------ */
@@ -372,6 +400,20 @@ mppi_status mppi_learner_set_weights(mppi_learner *l, const float *const *W, con
 /* forget the Adam moments and the step count (a new tf.optimizers.Adam, learner_base.py:149) */
 mppi_status mppi_learner_reset_optimizer(mppi_learner *l);
 mppi_status mppi_learner_get_step(mppi_learner *l, int *step);
+/* Persistence (replaces NNModel.save_params / load_params, models/nn_model.py:137-142 — a Keras SavedModel there — and
+ * LearnerBase.save_params, learners/learner_base.py:66-68; the reference does not keep its optimizer state, this does, so that a resumed
+ * run continues bit for bit). ONE flat little-endian file:
+ *     char    magic[8] = "MPPILRN1"
+ *     int32   n_layers, widths[5] (n_layers + 1 used, rest 0), adam_step, has_norm
+ *     per layer l (in = widths[l], out = widths[l+1]), fp32, compact:  W[in][out] b[out]  mW[in][out] mb[out]  vW[in][out] vb[out]
+ *     if has_norm, fp64:  xmean[widths[0]] xstd[widths[0]] ymean[widths[n_layers]] ystd[widths[n_layers]]
+ * (the normalisation belongs to the model, not to the learner: the caller passes it in and gets it back; all four NULL = none).
+ * mppi_learner_save writes beside the target and renames over it. mppi_learner_load: the learner's layer widths must match (mppi_learner_peek
+ * reads them from a file, to create the learner with); weights, both Adam moments and the step count are replaced; *has_norm says whether the
+ * file held a normalisation (the four outputs are written only then; they may be NULL). */
+mppi_status mppi_learner_save(mppi_learner *l, const char *filename, const double *xmean, const double *xstd, const double *ymean, const double *ystd);
+mppi_status mppi_learner_load(mppi_learner *l, const char *filename, double *xmean, double *xstd, double *ymean, double *ystd, int *has_norm);
+mppi_status mppi_learner_peek(const char *filename, int *n_layers, int32_t *widths /* [5] */);
 
 #ifdef __cplusplus
 }

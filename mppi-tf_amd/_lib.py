@@ -21,10 +21,12 @@ ACTION_COST_CPP, ACTION_COST_PY = 0, 1
 DBG_COSTS, DBG_BETA, DBG_ETA, DBG_WEIGHTS, DBG_NOISE, DBG_U_UPDATED = range(6)
 CSV_REFERENCE, CSV_ROUNDTRIP = 0, 1
 # mppi_set_tuning items (diagnostics; the library reads no environment variable)
-TUNING = {"force_tile_kernel": 0, "pc_producers": 1, "pc_balance": 2, "pc_lds_min": 3, "sync_spin": 4, "p2p_fault": 5, "mlp_v1": 6, "mlp32_valu": 7}
+TUNING = {"force_tile_kernel": 0, "pc_producers": 1, "pc_balance": 2, "pc_lds_min": 3, "sync_spin": 4, "p2p_fault": 5, "mlp_v1": 6, "mlp32_valu": 7,
+          "trace": 8}
 P2P_FAULTS = {"": 0, "export": 1, "probe": 2}
 
 FP = C.POINTER(C.c_float)
+DP = C.POINTER(C.c_double)
 
 
 class MppiError(RuntimeError):
@@ -56,6 +58,11 @@ class Config(C.Structure):
                 ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
                 ("flags", C.c_int32), ("state_cost_kind", C.c_int32), ("ellipse", FP),
                 ("auv", C.POINTER(AuvDesc)), ("quat_Q", FP), ("ellipse3d", FP)]
+
+
+class Collectives(C.Structure):
+    """mppi_collectives: the caller's all-gather / all-reduce with ncclAllGather's / ncclAllReduce's signatures + the communicator"""
+    _fields_ = [("all_gather", C.c_void_p), ("all_reduce", C.c_void_p), ("comm", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol include/mppi_c.h declares
@@ -103,6 +110,7 @@ SIGNATURES = {
     "mppi_shard_finish": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mppi_shard_cost_range": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mppi_shard_partial_normalized": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mppi_shard_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.POINTER(Collectives), C.c_void_p]),
     "mppi_synchronize": (C.c_int, [_H]),
     "mppi_set_action_limits": (C.c_int, [_H, FP, FP, C.c_int]),
     "mppi_set_sequence_filter": (C.c_int, [_H, C.c_int, C.c_int]),
@@ -126,6 +134,9 @@ SIGNATURES = {
     "mppi_learner_set_weights": (C.c_int, [_H, C.POINTER(FP), C.POINTER(FP)]),
     "mppi_learner_reset_optimizer": (C.c_int, [_H]),
     "mppi_learner_get_step": (C.c_int, [_H, C.POINTER(C.c_int)]),
+    "mppi_learner_save": (C.c_int, [_H, C.c_char_p, DP, DP, DP, DP]),
+    "mppi_learner_load": (C.c_int, [_H, C.c_char_p, DP, DP, DP, DP, C.POINTER(C.c_int)]),
+    "mppi_learner_peek": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int32)]),
 }
 
 _lib = None
@@ -144,7 +155,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.mppi_abi_version() != 3:
+    if lib.mppi_abi_version() != 4:
         raise OSError("libmppi_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -470,6 +481,10 @@ class Handle:
         self._check(self.lib.mppi_shard_partial_normalized(self.h, x_ptr, range_ptr, record_ptr, stream))
 
     # ---- options of the Python reference's update ---------------------------------------------
+    def shard_step(self, x_ptr, u_ptr, coll=None, stream=0):
+        """mppi_shard_step: the whole sharded step in ONE call; coll = a Collectives (or None on an unsharded handle: record -> finish)"""
+        self._check(self.lib.mppi_shard_step(self.h, x_ptr, u_ptr, C.byref(coll) if coll is not None else None, stream))
+
     def set_action_limits(self, a_min=None, a_max=None):
         """clip_act (controller_base.py:500-504): clamp U' rows to [a_min, a_max]; None, None = off"""
         if a_min is None and a_max is None:
@@ -628,6 +643,39 @@ class Learner:
 
     def reset_optimizer(self):
         self._check(self.lib.mppi_learner_reset_optimizer(self.h))
+
+    # persistence (mppi_learner_save / _load / _peek): weights, both Adam moments, the step count and — the model's, handed through —
+    # the normalisation, in the flat format include/mppi_c.h documents
+    def save(self, filename, norm=None):
+        """norm: dict(xmean, xstd, ymean, ystd) or None"""
+        held = [None] * 4
+        if norm is not None:
+            n_in, n_out = self.widths[0], self.widths[-1]
+            held = [np.ascontiguousarray(np.asarray(norm[k], np.float64).reshape(n)) for k, n in
+                    (("xmean", n_in), ("xstd", n_in), ("ymean", n_out), ("ystd", n_out))]
+        self._check(self.lib.mppi_learner_save(self.h, os.fsencode(filename), *[a.ctypes.data_as(DP) if a is not None else None for a in held]))
+
+    def load(self, filename):
+        """-> the file's normalisation dict(xmean, xstd, ymean, ystd), or None when it holds none"""
+        n_in, n_out = self.widths[0], self.widths[-1]
+        out = [np.zeros(n_in), np.zeros(n_in), np.zeros(n_out), np.zeros(n_out)]
+        has = C.c_int(0)
+        self._check(self.lib.mppi_learner_load(self.h, os.fsencode(filename), *[a.ctypes.data_as(DP) for a in out], C.byref(has)))
+        return dict(zip(("xmean", "xstd", "ymean", "ystd"), out)) if has.value else None
+
+    @classmethod
+    def from_file(cls, filename, device=0):
+        """a learner of the file's network with the file's weights, Adam moments and step count -> (learner, normalisation or None)"""
+        lib = load()
+        n, w = C.c_int(0), (C.c_int32 * 5)()
+        st = lib.mppi_learner_peek(os.fsencode(filename), C.byref(n), w)
+        if st != OK:
+            raise MppiError(st, (lib.mppi_learner_last_error(None) or b"").decode())
+        widths = [int(w[i]) for i in range(n.value + 1)]
+        zero = dict(W=[np.zeros((widths[i], widths[i + 1]), np.float32) for i in range(n.value)],
+                    b=[np.zeros(widths[i + 1], np.float32) for i in range(n.value)])
+        lrn = cls(zero, device=device)
+        return lrn, lrn.load(filename)
 
     def step_count(self):
         v = C.c_int(0)

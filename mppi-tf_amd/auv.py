@@ -9,6 +9,8 @@ Same class and method names, argument meaning and shapes (trailing singleton kep
 reference, so the parity tests read like scripts/test.py. Every numeric method is a call into libmppi_hip.so (HIP kernels);
 nothing is computed in numpy and there is no fallback. fp32 on the device (the Python reference is fp64).
 """
+import os
+
 import numpy as np
 
 from ._lib import ACTION_COST_PY, Handle
@@ -170,6 +172,31 @@ class NNAUVModel:
     def update_weights(self, var, msg=False):
         self._weights = dict(W=[np.asarray(v, np.float32) for v in var[0::2]], b=[np.asarray(v, np.float32) for v in var[1::2]])
         self._h = None
+
+    def normalisation(self):
+        return dict(xmean=self.Xmean, xstd=self.Xstd, ymean=self.Ymean, ystd=self.Ystd)
+
+    # nn_model.py:137-142 (a Keras SavedModel under path/weights_step<N> there): the flat file of include/mppi_c.h's mppi_learner_save —
+    # weights + this model's normalisation; the Adam slots are zero and the step count 0 when the MODEL writes it (LearnerBase.save_params
+    # writes the same format with the optimizer's state). Written through the device library, like everything numeric here.
+    def save_params(self, path, step):
+        from ._lib import Learner
+        os.makedirs(path, exist_ok=True)
+        f = os.path.join(path, "weights_step{}".format(step))
+        lrn = Learner(dict(W=self._weights["W"], b=self._weights["b"]), device=self._device)
+        lrn.save(f, self.normalisation())
+        lrn.close()
+        return f
+
+    def load_params(self, path):
+        from ._lib import Learner
+        lrn, norm = Learner.from_file(path, device=self._device)
+        w = lrn.get_weights()
+        lrn.close()
+        self._weights, self._h = dict(W=w["W"], b=w["b"]), None
+        if norm is not None:
+            self.set_Xmean_Xstd(norm["xmean"], norm["xstd"])
+            self.set_Ymean_Ystd(norm["ymean"], norm["ystd"])
 
     def mlp(self):
         """the dict Handle(nnauv=...) takes"""

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +51,37 @@ hipError_t mppi_raise_lds_ceiling(const void *kernel, int device, size_t bytes)
     if (e == hipSuccess) cur = bytes;
     return e;
 }
+
+// ---- roctx ranges (MPPI_TUNE_TRACE): the reference brackets its step with tf.profiler.experimental.start/stop
+// (controller_base.py:241-248, 587-595). The marker library is dlopen'ed on first use — rocprofiler-sdk's (what rocprofv3
+// --marker-trace records) first, the legacy libroctx64 second — so the product keeps no link dependency on a profiler.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+    bool load()
+    {
+        if (tried) return push != nullptr;
+        tried = true;
+        for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void *lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) continue;
+            push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+            if (push && pop) return true;
+            push = nullptr; pop = nullptr;
+        }
+        return false;
+    }
+} g_roctx;
+// a range that lasts for the scope; free when the handle does not trace
+struct TraceRange {
+    bool on;
+    TraceRange(const mppi_handle *h, const char *name) : on(h->trace && g_roctx.push) { if (on) g_roctx.push(name); }
+    ~TraceRange() { if (on) g_roctx.pop(); }
+};
+} // namespace
 
 // ----------------------------------------------------------------------------------------
 extern "C" int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
@@ -134,7 +166,7 @@ extern "C" void mppi_destroy(mppi_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     float *bufs[] = {h->d_x, h->d_Ubuf[0], h->d_Ubuf[1], h->d_u, h->d_cost, h->d_cost2, h->d_part, h->d_part2, h->d_part3,
-                     h->d_record, h->d_dbg, h->d_mm, h->d_eps};
+                     h->d_record, h->d_dbg, h->d_mm, h->d_eps, h->d_recs, h->d_range};
     for (float *p : bufs) if (p) (void)hipFree(p);
     if (h->d_step) (void)hipFree(h->d_step);
     if (h->dM) (void)hipFree(h->dM);
@@ -445,6 +477,7 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
                                 const float *U_in, float *U_out, float *u_out, float *record_out, int apply, bool xchg = false)
 {
     // a profiled step = the rollout kernel + the finish that applies the update
+    TraceRange tr(h, apply ? "mppi:finish" : "mppi:record");
     const bool prof = apply && h->prof_n < h->prof_cap;
     const float *nil_dev = h->norm_two_pass ? h->d_mm + 2 : nullptr; // this step's records were made at the temperature k_cost_minmax left there
     float *out = h->d_part2;
@@ -594,6 +627,7 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
 {
     const bool mlp = h->hc.model_kind == MPPI_MODEL_MLP;
     const bool gen = h->is_gen != 0;
+    TraceRange tr(h, "mppi:rollout");
     *nrec = h->nbp; // every slot: those no tile owns hold neutral records
     h->norm_two_pass = 0;
     HIP_TRY(h, ensure_record_layout(h, st, (mlp && !h->normalize) ? h->nb_mlp : h->nb)); // (normalizeCost: the tile kernel writes the records)
@@ -756,7 +790,9 @@ extern "C" mppi_status mppi_set_mlp(mppi_handle *h, const mppi_mlp_desc *d)
         if (!d->W[l] || !d->b[l]) return fail(h, MPPI_ERR_INVALID_ARG, "NULL MLP weight pointer");
     }
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream)); // steps in flight read the old weights
+    // steps in flight read the old weights — on the handle's stream or on the caller's (mppi_next_device / mppi_shard_*): a weight
+    // push is rare, so it simply waits for the whole device (only h->stream was waited for)
+    HIP_TRY(h, hipDeviceSynchronize());
     return upload_mlp(h, d, false);
 }
 
@@ -765,6 +801,7 @@ extern "C" mppi_status mppi_next_device(mppi_handle *h, const float *x_dev, floa
     if (!h || !x_dev || !u_dev) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL device pointer") : MPPI_ERR_INVALID_ARG;
     if (h->shard_count != 1) return fail(h, MPPI_ERR_INVALID_ARG, "sharded handle: use mppi_shard_partial / mppi_shard_finish");
     HIP_TRY(h, hipSetDevice(h->device));
+    TraceRange step_range(h, "mppi:step");
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     int nrec = 0;
     mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr, &nrec);
@@ -792,7 +829,13 @@ extern "C" mppi_status mppi_shard_partial(mppi_handle *h, const float *x_dev, fl
 // makes its record from costs normalised with the agreed range. Both halves take the path enqueue_partials takes on an unsharded
 // handle — two passes of k_rollout_pc where it serves the configuration, else cost pass + normalise + record pass; which of the two
 // depends on the configuration only, never on the shard's size: all ranks make their records in the same units.
-static bool norm_fast(const mppi_handle *h) { return h->hc.model_kind != MPPI_MODEL_MLP && !h->is_gen && pc_eligible(h); }
+//  pc_eligible's horizon bound depends on pc_np, and pc_np on THIS shard's tile count (or a per-handle tuning): with
+// 132 < H <= 160 and ragged shards straddling 512 tiles one rank would make raw-cost records at the range temperature and another
+// normalised-cost records at lambda. A sharded handle therefore takes the fast form only below the bound that holds for every pc_np.
+static bool norm_fast(const mppi_handle *h)
+{
+    return h->hc.model_kind != MPPI_MODEL_MLP && !h->is_gen && pc_eligible(h) && (h->shard_count == 1 || h->H <= 132);
+}
 
 extern "C" mppi_status mppi_shard_cost_range(mppi_handle *h, const float *x_dev, float *range_dev, void *stream)
 {
@@ -849,6 +892,39 @@ extern "C" mppi_status mppi_shard_finish(mppi_handle *h, const float *records_de
     HIP_TRY(h, launch_finish(h, st, records_dev, 2 + h->HA, 1, n_records, h->U_cur(), h->U_other(), u_dev, nullptr, 1));
     HIP_TRY(h, advance_sequence(h, st));
     return MPPI_OK;
+}
+
+// One call per sharded step on the collective path (include/mppi_c.h): record -> the caller's all-gather (in place) -> finish.
+extern "C" mppi_status mppi_shard_step(mppi_handle *h, const float *x_dev, float *u_dev, const mppi_collectives *coll, void *stream)
+{
+    if (!h || !x_dev || !u_dev) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL device pointer") : MPPI_ERR_INVALID_ARG;
+    const bool gather = coll && coll->all_gather;
+    if (h->shard_count > 1 && !gather) return fail(h, MPPI_ERR_INVALID_ARG, "mppi_shard_step: shard_count > 1 needs coll->all_gather (ncclAllGather's signature)");
+    if (h->normalize && gather && !coll->all_reduce) return fail(h, MPPI_ERR_INVALID_ARG, "mppi_shard_step: a normalize_cost handle needs coll->all_reduce (ncclAllReduce's signature)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = 2 + h->HA;
+    if (!h->d_recs) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_recs, sizeof(float) * (size_t)n * h->shard_count));
+        HIP_TRY(h, hipMalloc((void **)&h->d_range, sizeof(float) * 2));
+    }
+    TraceRange step_range(h, "mppi:step");
+    float *own = h->d_recs + (size_t)n * h->shard_rank;
+    mppi_status s;
+    if (h->normalize) {
+        if ((s = mppi_shard_cost_range(h, x_dev, h->d_range, stream)) != MPPI_OK) return s;
+        if (gather) {
+            TraceRange tr(h, "mppi:exchange");
+            const int rc = coll->all_reduce(h->d_range, h->d_range, 2, MPPI_COLL_FLOAT32, MPPI_COLL_MAX, coll->comm, stream ? stream : (void *)h->stream);
+            if (rc != 0) return fail(h, MPPI_ERR_EXCHANGE, "mppi_shard_step: all_reduce returned " + std::to_string(rc));
+        }
+        if ((s = mppi_shard_partial_normalized(h, x_dev, h->d_range, own, stream)) != MPPI_OK) return s;
+    } else if ((s = mppi_shard_partial(h, x_dev, own, stream)) != MPPI_OK) return s;
+    if (gather) {
+        TraceRange tr(h, "mppi:exchange");
+        const int rc = coll->all_gather(own, h->d_recs, (size_t)n, MPPI_COLL_FLOAT32, coll->comm, stream ? stream : (void *)h->stream);
+        if (rc != 0) return fail(h, MPPI_ERR_EXCHANGE, "mppi_shard_step: all_gather returned " + std::to_string(rc));
+    }
+    return mppi_shard_finish(h, h->d_recs, h->shard_count, u_dev, stream);
 }
 
 // ---- direct record exchange (see include/mppi_c.h) -----------------------------------------------
@@ -941,6 +1017,7 @@ extern "C" mppi_status mppi_shard_p2p_step(mppi_handle *h, const float *x_dev, f
     if (*(volatile unsigned *)h->h_xchg_status & 1u)
         return fail(h, MPPI_ERR_EXCHANGE, "direct exchange: a packet missed its deadline; the direct path is closed for this handle");
     HIP_TRY(h, hipSetDevice(h->device));
+    TraceRange step_range(h, "mppi:step");
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     int nrec = 0;
     mppi_status s = enqueue_partials(h, st, SRC_PHILOX, x_dev, nullptr, nullptr, &nrec);
@@ -964,6 +1041,7 @@ static mppi_status step_host(mppi_handle *h, const float *x, int n_x, const floa
     if (!x || !u_out || n_x != h->s || n_u != h->a) return fail(h, MPPI_ERR_INVALID_ARG, "x must have s_dim floats and u_out a_dim floats");
     if (h->shard_count != 1) return fail(h, MPPI_ERR_INVALID_ARG, "sharded handle: use mppi_shard_partial / mppi_shard_finish");
     HIP_TRY(h, hipSetDevice(h->device));
+    TraceRange step_range(h, "mppi:step");
     int src = SRC_PHILOX;
     if (eps) {
         if (n_eps != (size_t)h->K_local * h->HA) return fail(h, MPPI_ERR_INVALID_ARG, "eps must hold K_local*tau*a floats");
@@ -1127,6 +1205,9 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
     case MPPI_TUNE_P2P_FAULT:
         if (value < 0 || value > 2) return fail(h, MPPI_ERR_INVALID_ARG, "fault: 0 none, 1 export, 2 probe");
         h->p2p_fault = value; break;
+    case MPPI_TUNE_TRACE:
+        if (value != 0 && !g_roctx.load()) return fail(h, MPPI_ERR_UNSUPPORTED, "MPPI_TUNE_TRACE: neither librocprofiler-sdk-roctx.so nor libroctx64.so could be loaded");
+        h->trace = value != 0; break;
     default: return fail(h, MPPI_ERR_INVALID_ARG, "unknown tuning item");
     }
     return MPPI_OK;

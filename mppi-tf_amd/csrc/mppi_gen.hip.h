@@ -297,7 +297,10 @@ __device__ __forceinline__ float state_cost_quat(const DevConsts *__restrict__ C
     for (int i = 1; i < 4; ++i) dot = dot + x[3 + i] * C->goal[3 + i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) d[i] = x[i] - C->goal[i];
-    d[3] = 2.0f * acosf(dot);
+    // <q, g> of two unit quaternions can round to 1 + 1 ulp in fp32 when the vehicle sits AT a goal attitude that is not axis-aligned:
+    // acosf is NaN there, one NaN cost makes eta, U' and the warm start NaN for good (the reference has the same hazard in fp64,
+    // static_cost.py:151). Clamped to [-1, 1]: the reference's value wherever the reference's is finite.
+    d[3] = 2.0f * acosf(fminf(fmaxf(dot, -1.0f), 1.0f));
 #pragma unroll
     for (int i = 0; i < 6; ++i) d[4 + i] = x[7 + i] - C->goal[7 + i];
 #pragma unroll

@@ -45,6 +45,7 @@ struct mppi_handle {
     int pc_lds_min = 0;   // MPPI_TUNE_PC_LDS_MIN: pad the dynamic LDS (caps workgroups per CU)
     int sync_spin = 1;    // MPPI_TUNE_SYNC_SPIN: the synchronous step watches the pinned u slot (0: waits for the stream)
     int p2p_fault = 0;    // MPPI_TUNE_P2P_FAULT: 1 = inbox export refused, 2 = probe reports failure (fallback tests)
+    int trace = 0;        // MPPI_TUNE_TRACE: roctx ranges around what a step enqueues
     float *d_x = nullptr, *d_u = nullptr, *d_cost = nullptr, *d_cost2 = nullptr;
     // The nominal sequence lives in one of two buffers of tau*a + a floats whose last a floats stay zero. A step
     // reads U from ubuf[u_cur] + u_off and writes U' to the other buffer at offset 0; the shifted sequence
@@ -62,6 +63,7 @@ struct mppi_handle {
     int *d_sg_start = nullptr;
     float *d_part = nullptr, *d_part2 = nullptr, *d_part3 = nullptr, *d_record = nullptr, *d_dbg = nullptr, *d_mm = nullptr;
     float *d_eps = nullptr; // lazily allocated [K_local, H, a] for injected noise / debug export
+    float *d_recs = nullptr, *d_range = nullptr; // mppi_shard_step: all shards' records (the own one in place) and the {-min, max} pair, lazily
     unsigned long long *d_step = nullptr;
     // pinned, device-mapped host staging for the synchronous path: x slot 0 | x slot 1 | u. The kernels read
     // x and write u straight through these (zero-copy over PCIe, 24 B / 12 B): no H2D / D2H copy nodes per step.

@@ -394,3 +394,120 @@ extern "C" mppi_status mppi_learner_get_step(mppi_learner *l, int *step)
     L_TRY(l, hipMemcpy(step, l->d_step, sizeof(int), hipMemcpyDeviceToHost));
     return MPPI_OK;
 }
+
+// ---- persistence (reference: nn_model.py:137-142 save_params / load_params, learner_base.py:66-68) ----------------
+// One flat little-endian file, documented in include/mppi_c.h: magic "MPPILRN1", n_layers, widths[5], Adam step, has_norm, then per layer
+// W b mW mb vW vb (fp32, compact [in][out]), then the optional fp64 normalisation (xmean, xstd, ymean, ystd).
+namespace {
+struct LearnerFileHeader { char magic[8]; int32_t n_layers; int32_t widths[5]; int32_t step; int32_t has_norm; };
+static_assert(sizeof(LearnerFileHeader) == 40, "file header layout");
+const char kLearnerMagic[8] = {'M', 'P', 'P', 'I', 'L', 'R', 'N', '1'};
+
+bool read_header(FILE *f, LearnerFileHeader &hd)
+{
+    if (fread(&hd, sizeof(hd), 1, f) != 1 || memcmp(hd.magic, kLearnerMagic, 8) != 0) return false;
+    if (hd.n_layers < 1 || hd.n_layers > kMaxLayers) return false;
+    for (int k = 0; k <= hd.n_layers; ++k) if (hd.widths[k] < 1 || hd.widths[k] > W32) return false;
+    return hd.step >= 0 && (hd.has_norm == 0 || hd.has_norm == 1);
+}
+} // namespace
+
+extern "C" mppi_status mppi_learner_peek(const char *filename, int *n_layers, int32_t *widths)
+{
+    if (!filename || !n_layers || !widths) return lfail(nullptr, MPPI_ERR_INVALID_ARG, "NULL argument");
+    FILE *f = fopen(filename, "rb");
+    if (!f) return lfail(nullptr, MPPI_ERR_IO, std::string("cannot open ") + filename);
+    LearnerFileHeader hd;
+    const bool ok = read_header(f, hd);
+    fclose(f);
+    if (!ok) return lfail(nullptr, MPPI_ERR_IO, std::string(filename) + ": not a learner file (MPPILRN1)");
+    *n_layers = hd.n_layers;
+    for (int k = 0; k < 5; ++k) widths[k] = k <= hd.n_layers ? hd.widths[k] : 0;
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_learner_save(mppi_learner *l, const char *filename, const double *xmean, const double *xstd,
+                                         const double *ymean, const double *ystd)
+{
+    if (!l || !filename) return l ? lfail(l, MPPI_ERR_INVALID_ARG, "NULL filename") : MPPI_ERR_INVALID_ARG;
+    const bool norm = xmean || xstd || ymean || ystd;
+    if (norm && !(xmean && xstd && ymean && ystd)) return lfail(l, MPPI_ERR_INVALID_ARG, "normalisation: all four of xmean, xstd, ymean, ystd or none");
+    L_TRY(l, hipSetDevice(l->device));
+    L_TRY(l, hipStreamSynchronize(l->stream));
+    const int L = l->net.n_layers;
+    LearnerFileHeader hd{};
+    memcpy(hd.magic, kLearnerMagic, 8);
+    hd.n_layers = L;
+    for (int k = 0; k <= L; ++k) hd.widths[k] = l->net.width[k];
+    L_TRY(l, hipMemcpy(&hd.step, l->d_step, sizeof(int), hipMemcpyDeviceToHost));
+    hd.has_norm = norm ? 1 : 0;
+    std::vector<float> body;
+    std::vector<float> pad(W32 * W32), pb(W32);
+    for (int k = 0; k < L; ++k) {
+        const int in = l->net.width[k], out = l->net.width[k + 1];
+        const float *mats[3] = {l->net.W[k], l->adam.m[k], l->adam.v[k]}, *vecs[3] = {l->net.b[k], l->adam.mb[k], l->adam.vb[k]};
+        for (int q = 0; q < 3; ++q) {
+            L_TRY(l, hipMemcpy(pad.data(), mats[q], sizeof(float) * W32 * W32, hipMemcpyDeviceToHost));
+            L_TRY(l, hipMemcpy(pb.data(), vecs[q], sizeof(float) * W32, hipMemcpyDeviceToHost));
+            for (int i = 0; i < in; ++i) for (int o = 0; o < out; ++o) body.push_back(pad[i * W32 + o]);
+            for (int o = 0; o < out; ++o) body.push_back(pb[o]);
+        }
+    }
+    // written beside the target and renamed over it: a reader (or a crash) never sees half a file
+    const std::string tmp = std::string(filename) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return lfail(l, MPPI_ERR_IO, "cannot open " + tmp);
+    bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1 && fwrite(body.data(), sizeof(float), body.size(), f) == body.size();
+    if (ok && norm) {
+        const size_t nx = (size_t)l->net.width[0], ny = (size_t)l->net.width[L];
+        ok = fwrite(xmean, sizeof(double), nx, f) == nx && fwrite(xstd, sizeof(double), nx, f) == nx &&
+             fwrite(ymean, sizeof(double), ny, f) == ny && fwrite(ystd, sizeof(double), ny, f) == ny;
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), filename) != 0) { (void)remove(tmp.c_str()); return lfail(l, MPPI_ERR_IO, std::string("cannot write ") + filename); }
+    return MPPI_OK;
+}
+
+extern "C" mppi_status mppi_learner_load(mppi_learner *l, const char *filename, double *xmean, double *xstd, double *ymean, double *ystd, int *has_norm)
+{
+    if (!l || !filename) return l ? lfail(l, MPPI_ERR_INVALID_ARG, "NULL filename") : MPPI_ERR_INVALID_ARG;
+    FILE *f = fopen(filename, "rb");
+    if (!f) return lfail(l, MPPI_ERR_IO, std::string("cannot open ") + filename);
+    LearnerFileHeader hd;
+    const int L = l->net.n_layers;
+    bool ok = read_header(f, hd);
+    if (ok && hd.n_layers != L) ok = false;
+    for (int k = 0; ok && k <= L; ++k) ok = hd.widths[k] == l->net.width[k];
+    if (!ok) { fclose(f); return lfail(l, MPPI_ERR_IO, std::string(filename) + ": not a learner file of this network's layer widths"); }
+    size_t nfl = 0;
+    for (int k = 0; k < L; ++k) nfl += (size_t)3 * (l->net.width[k] + 1) * l->net.width[k + 1];
+    std::vector<float> body(nfl);
+    ok = fread(body.data(), sizeof(float), nfl, f) == nfl;
+    const size_t nx = (size_t)l->net.width[0], ny = (size_t)l->net.width[L];
+    std::vector<double> nrm(2 * (nx + ny));
+    if (ok && hd.has_norm) ok = fread(nrm.data(), sizeof(double), nrm.size(), f) == nrm.size();
+    fclose(f);
+    if (!ok) return lfail(l, MPPI_ERR_IO, std::string(filename) + ": truncated");
+    L_TRY(l, hipSetDevice(l->device));
+    L_TRY(l, hipStreamSynchronize(l->stream));
+    const float *p = body.data();
+    std::vector<float> pad(W32 * W32), pb(W32);
+    for (int k = 0; k < L; ++k) {
+        const int in = l->net.width[k], out = l->net.width[k + 1];
+        float *mats[3] = {l->net.W[k], l->adam.m[k], l->adam.v[k]}, *vecs[3] = {l->net.b[k], l->adam.mb[k], l->adam.vb[k]};
+        for (int q = 0; q < 3; ++q) {
+            std::fill(pad.begin(), pad.end(), 0.0f); std::fill(pb.begin(), pb.end(), 0.0f); // the padding stays exactly zero
+            for (int i = 0; i < in; ++i) for (int o = 0; o < out; ++o) pad[i * W32 + o] = *p++;
+            for (int o = 0; o < out; ++o) pb[o] = *p++;
+            L_TRY(l, hipMemcpy(mats[q], pad.data(), sizeof(float) * W32 * W32, hipMemcpyHostToDevice));
+            L_TRY(l, hipMemcpy(vecs[q], pb.data(), sizeof(float) * W32, hipMemcpyHostToDevice));
+        }
+    }
+    L_TRY(l, hipMemcpy(l->d_step, &hd.step, sizeof(int), hipMemcpyHostToDevice));
+    if (has_norm) *has_norm = hd.has_norm;
+    if (hd.has_norm && xmean && xstd && ymean && ystd) {
+        memcpy(xmean, nrm.data(), sizeof(double) * nx); memcpy(xstd, nrm.data() + nx, sizeof(double) * nx);
+        memcpy(ymean, nrm.data() + 2 * nx, sizeof(double) * ny); memcpy(ystd, nrm.data() + 2 * nx + ny, sizeof(double) * ny);
+    }
+    return MPPI_OK;
+}

@@ -19,6 +19,8 @@ and always exchanges its records by all-gather.
 torch is plumbing here: device buffers, the current stream, and torch.distributed (backend
 "nccl" is RCCL on ROCm; "gloo" drives the CPU test of this file's logic with a test backend).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -60,6 +62,15 @@ class HipShardBackend:
     def step(self, x, u):
         """unsharded whole step (mppi_next_device): no record round trip"""
         self.h.next_device(x.data_ptr(), u.data_ptr(), self._stream())
+
+    def shard_step(self, x, u, coll):
+        """the whole sharded step in ONE C call (mppi_shard_step): record -> the collectives `coll` points at -> finish"""
+        self.h.shard_step(x.data_ptr(), u.data_ptr(), coll, self._stream())
+
+    def make_collectives(self, rank, world, group):
+        """this rank's own RCCL communicator behind an mppi_collectives struct (collective over `group`)"""
+        from .rccl import RcclComm
+        return RcclComm(rank, world, group)
 
     # direct exchange (mppi_shard_p2p_*)
     def p2p_export(self):
@@ -104,8 +115,9 @@ class ShardedController:
     def __init__(self, backend=None, group=None, device_index=0, exchange=None, p2p_timeout_ms=2000, **cfg):
         """cfg: Handle arguments (k = GLOBAL sample count, tau, s_dim, a_dim, sigma, goal, mlp, ...).
         exchange: "auto" (direct exchange if its self-test passes on every rank, else the all-gather), "p2p"
-        (direct exchange or raise), "rccl" (all-gather); default from MPPI_EXCHANGE, else "auto"."""
-        import os
+        (direct exchange or raise), "rccl" (all-gather); default from MPPI_EXCHANGE, else "auto".
+        MPPI_RCCL_CALL=torch keeps the all-gather path on torch.distributed (three C calls + one collective call per step) instead
+        of mppi_shard_step with the controller's own communicator (A/B timing, tools/time_sharded.py)."""
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -132,6 +144,11 @@ class ShardedController:
             if exchange == "p2p" and not self.p2p:
                 raise RuntimeError("direct exchange requested but unavailable: " + self.p2p_note)
         self.exchange = "none" if not sharded else ("p2p" if self.p2p else "rccl")
+        # The collective path as ONE C call per step (mppi_shard_step calling ncclAllGather itself) where the backend offers it and
+        # the job runs on RCCL (or has one rank); else three calls + a torch.distributed collective (gloo tests, fallback).
+        self.rccl, self.rccl_note = None, "not requested"
+        if self.exchange == "rccl" and os.environ.get("MPPI_RCCL_CALL", "c") != "torch":
+            self.rccl, self.rccl_note = self._bring_up_rccl()
 
     def _vote(self, ok):
         """True iff ok on every rank"""
@@ -141,6 +158,23 @@ class ShardedController:
         t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.backend.device if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return bool(t.item())
+
+    def _bring_up_rccl(self):
+        """-> (RcclComm or None, note). A collective when the job has more than one rank: every rank takes the same branch."""
+        if not hasattr(self.backend, "make_collectives"):
+            return None, "backend without mppi_shard_step"
+        if dist.is_initialized() and self.world > 1 and dist.get_backend(self.group) != "nccl":
+            return None, "the job's backend is not RCCL"
+        comm, note = None, ""
+        try:
+            comm = self.backend.make_collectives(self.rank, self.world, self.group)
+        except Exception as e:  # no librccl in the process, ncclCommInitRank refused, ...
+            note = "RCCL communicator: %s" % e
+        if not self._vote(comm is not None):
+            if comm is not None:
+                comm.close()
+            return None, note or "a peer could not create its RCCL communicator"
+        return comm, "one C call per step (mppi_shard_step -> ncclAllGather), own communicator of %d rank(s)" % self.world
 
     def _bring_up_p2p(self, timeout_ms):
         """export -> exchange IPC handles -> open -> attach -> probe x3, with a vote after each phase that can fail.
@@ -192,6 +226,9 @@ class ShardedController:
                     raise ExchangeTimeout(str(e)) from None
                 raise
             return self.u
+        if self.rccl is not None:
+            self.backend.shard_step(x, self.u, self.rccl.coll)
+            return self.u
         collective = self.world > 1 or (self.force_exchange and dist.is_initialized())
         if self.normalize:
             self.backend.cost_range(x, self.range)  # {-min, max} of this rank's costs
@@ -229,6 +266,8 @@ class ShardedController:
         step counter to every rank, continue on the all-gather path. Call it on all ranks after ExchangeTimeout."""
         self.p2p, self.exchange = False, "rccl"
         self.p2p_note = "closed after a missed deadline"
+        if self.rccl is None and os.environ.get("MPPI_RCCL_CALL", "c") != "torch":
+            self.rccl, self.rccl_note = self._bring_up_rccl()
         U = self.backend.action_sequence()
         step = torch.tensor([self.backend.step_counter()], dtype=torch.int64)
         if dist.is_initialized() and self.world > 1:

@@ -7,6 +7,8 @@ mean / std of the data, noise augmentation of the inputs) is numpy on the host, 
 The reference's replay buffer is cpprb's ReplayBuffer (a ring of transitions): restated here as three numpy arrays.
 TensorBoard logging, plotting, k-fold grid search are outside the path.
 """
+import os
+
 import numpy as np
 
 from ._lib import Learner
@@ -56,8 +58,10 @@ class LearnerBase:
         if filename is not None:
             self.load_rb(filename)
         self.log, self.step, self.sigma = log, 0, 0.001
-        self._device, self._dev = device, None
+        self._device, self._dev, self._dev_model = device, None, None
         self.last_losses = []
+        self.logdir = logPath  # where save_params puts weights_step<N> (learner_base.py:40-52 stamps a sub-directory; this keeps the path given)
+        self.val_log = []      # (epoch, validate(...)) of the last train(..., val=...)
 
     # ---- replay buffer (learner_base.py:54-66)
     def load_rb(self, filename):
@@ -72,6 +76,28 @@ class LearnerBase:
     def save_rb(self, filename):
         self.rb.save_transitions(filename)
 
+    # ---- persistence (learner_base.py:66-68 save_params -> NNModel.save_params, nn_model.py:137-142). The reference saves the
+    # Keras model only; this file also carries both Adam moments and the step count (mppi_learner_save's flat format), so that a
+    # run resumed in a new process continues bit for bit.
+    def params_path(self, step, logdir=None):
+        return os.path.join(logdir or self.logdir or ".", "weights_step{}".format(step))
+
+    def save_params(self, step, logdir=None):
+        path = self.params_path(step, logdir)
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        self._device_learner(self.model).save(path, self.model.normalisation())
+        return path
+
+    def load_params(self, path):
+        """weights + normalisation into the model, weights + Adam moments + step count into the device learner"""
+        self._dev, norm = Learner.from_file(path, device=self._device)
+        self._dev_model = self.model
+        self._pull(self.model)
+        if norm is not None:
+            self.model.set_Xmean_Xstd(norm["xmean"], norm["xstd"])
+            self.model.set_Ymean_Ystd(norm["ymean"], norm["ystd"])
+        self.step = self._dev.step_count()
+
     def stats(self):
         """mean / std of the un-normalised training pairs become the model's normalisation (learner_base.py:71-83)"""
         data = self.rb_trans()
@@ -82,9 +108,17 @@ class LearnerBase:
 
     # ---- training (learner_base.py:146-153, 324-358, 469-496)
     def _device_learner(self, model):
-        if self._dev is None:
-            w = model.get_weights()
-            self._dev = Learner(dict(W=w[0::2], b=w[1::2]), device=self._device)
+        """The device learner holding `model`'s CURRENT weights. In the reference learner and model share tf.Variables, so
+        model.update_weights(...) (the grid search's reset, learner_base.py:143; a loaded weight file) takes effect on the next
+        step; here the weights are pushed before every train / evaluate — a few KB (they used to be uploaded once,
+        at first use, and a later update_weights was silently ignored and then overwritten by _pull). The Adam moments stay, as
+        an optimizer's slots do when its variables are assigned. One device learner per model object."""
+        w = model.get_weights()
+        weights = dict(W=w[0::2], b=w[1::2])
+        if self._dev is None or self._dev_model is not model:
+            self._dev, self._dev_model = Learner(weights, device=self._device), model
+        else:
+            self._dev.set_weights(weights)
         return self._dev
 
     def train_all(self, learningRate=0.1, batchSize=32, epoch=100, val=None, writer=None, augment=True):
@@ -109,11 +143,86 @@ class LearnerBase:
         dev = self._device_learner(self.model)
         dev.set_data(XEp, yEp)
         o = self.optimizer
-        first, last = dev.train(epoch, learningRate, o.beta_1, o.beta_2, o.epsilon)
+        self.val_log = []
+        if val is None:
+            first, last = dev.train(epoch, learningRate, o.beta_1, o.beta_2, o.epsilon)
+        else:
+            # learner_base.py:336-358: every 10th epoch the model is validated on held-out trajectories val = (gtTrajs, actionSeqs):
+            # the epochs run on the device in blocks of 10 with the validation between them (the reference logs the numbers to
+            # TensorBoard; they are kept in self.val_log and handed to `writer(epoch, dict)` if one is given)
+            first = last = None
+            for e0 in range(0, epoch, 10):
+                self._pull(self.model)
+                errs = self.validate(self.model, val[1], val[0], transition=True, split=True, norm=True)
+                names = ("Val-Total", "Val-Total-Norm", "Val-Split", "Val-Split-Norm", "Val-Transition", "Val-Transition-Norm",
+                         "Val-Transition-Split", "Val-Transition-Split-Norm")
+                entry = dict(zip(names, errs))
+                self.val_log.append((e0, entry))
+                if callable(writer):
+                    writer(e0, entry)
+                f, last = dev.train(min(10, epoch - e0), learningRate, o.beta_1, o.beta_2, o.epsilon)
+                first = f if first is None else first
         self.last_losses = [first, last]
         self._pull(self.model)
         self.step += epoch
         return first, last
+
+    # ---- validation (learner_base.py:218-320)
+    def norm_trajs(self, model, trajs):
+        """trajectories [k, tau, s] in the network's output units (learner_base.py:360-367: (traj - Ymean) / Ystd)"""
+        return (np.asarray(trajs, np.float64) - np.asarray(model.Ymean)) / np.asarray(model.Ystd)
+
+    def validate(self, model, actionSeqs, gtTrajs, plot=False, transition=False, split=False, norm=False):
+        """Error of the model on k trajectories gtTrajs [k, tau, s] with their action sequences actionSeqs [k, tau, a]
+        (learner_base.py:218-320): the model is rolled tau-1 steps from each trajectory's first state (on the device, the model's own
+        step) and compared with the ground truth — err [, errNorm] [, errSplit, errSplitNorm] — and with transition=True every
+        (x_t, u_t) -> x_t+1 pair is predicted on its own (transErr...). Same return tuples as the reference for every flag combination."""
+        actionSeqs, gtTrajs = np.asarray(actionSeqs, np.float64), np.asarray(gtTrajs, np.float64)
+        tau = actionSeqs.shape[1]
+        state = gtTrajs[:, 0][..., None]
+        trajs = [state[:, None]]
+        for i in range(tau - 1):
+            state = np.asarray(model.build_step_graph("val", state, actionSeqs[:, i][..., None]), np.float64)
+            trajs.append(state[:, None])
+        trajs = np.concatenate(trajs, axis=1)[..., 0]
+        errSplit = np.mean((trajs - gtTrajs) ** 2, axis=(0, 1))
+        err = float(np.mean(errSplit))
+        out_n = len(np.asarray(model.Ymean).ravel())
+        if out_n == trajs.shape[-1]:
+            errSplitNorm = np.mean((self.norm_trajs(model, trajs) - self.norm_trajs(model, gtTrajs)) ** 2, axis=(0, 1))
+        else:  # NNAUVModelSpeed normalises the 6 velocity outputs only: its trajectory error in those units (state[7:13])
+            errSplitNorm = np.mean(((trajs[..., -out_n:] - gtTrajs[..., -out_n:]) / np.asarray(model.Ystd)) ** 2, axis=(0, 1))
+        errNorm = float(np.mean(errSplitNorm))
+        if transition:
+            k, s_dim, a_dim = gtTrajs.shape[0], gtTrajs.shape[2], actionSeqs.shape[2]
+            actions = actionSeqs[:, :-1].reshape((tau - 1) * k, a_dim, 1)
+            states = gtTrajs[:, :-1].reshape((tau - 1) * k, s_dim, 1)
+            nextStates = gtTrajs[:, 1:].reshape((tau - 1) * k, s_dim, 1)
+            XNorm, yNorm = model.prepare_training_data(states, nextStates, actions)
+            dev = Learner(dict(W=model.get_weights()[0::2], b=model.get_weights()[1::2]), device=self._device)  # the network alone (model._predict_nn)
+            dev.set_data(XNorm, yNorm)
+            _, predNorm = dev.evaluate(pred=True)
+            dev.close()
+            yN = np.asarray(yNorm, np.float32)
+            transErrSplitNorm = np.mean((predNorm - yN) ** 2, axis=0)
+            transErrNorm = float(np.mean(transErrSplitNorm))
+            transErrSplit = np.mean(((predNorm - yN) * np.asarray(model.Ystd)) ** 2, axis=0)  # denormalizeY: Ymean cancels in the difference
+            transErr = float(np.mean(transErrSplit))
+        if transition and split and norm:
+            return err, errNorm, errSplit, errSplitNorm, transErr, transErrNorm, transErrSplit, transErrSplitNorm
+        if transition and split:
+            return err, errSplit, transErr, transErrSplit
+        if transition and norm:
+            return err, errNorm, transErr, transErrNorm
+        if split and norm:
+            return err, errNorm, errSplit, errSplitNorm
+        if transition:
+            return err, transErr
+        if split:
+            return err, errSplit
+        if norm:
+            return err, errNorm
+        return err
 
     def _train_step(self, model, optimizer, Xnorm, Ynorm, split=False, norm=False):
         """ONE Adam step on (Xnorm, Ynorm) (learner_base.py:469-496) -> (loss, grads): the loss of the forward pass before the update in

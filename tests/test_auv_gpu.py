@@ -653,3 +653,156 @@ def test_13_state_kernels_with_a_dense_sigma(m, G, kind):
     bar = (2e-5 if kind == "bf16x3" else 1e-5) * scale
     np.testing.assert_allclose(h.get_action_sequence(), U64, rtol=0, atol=bar)
     np.testing.assert_allclose(u, u64, rtol=0, atol=bar)
+
+
+# ------------------------------------------------------------------------------------------------ full size
+# Every 13-state sub-record of bench.py runs K = 65536, H = 64 (1024 tiles = one wave per SIMD, a 1024-record finish, 16 horizon
+# groups x 6 Philox blocks, the record pass regenerating the noise): the same (kernel, K, H) against the oracle here, on the bench's
+# own task (auv_task: rexrov2, the static 13-state goal, 1500 N noise).
+FULL_K, FULL_H = 65536, 64
+
+
+def full_size_cfg(kind):
+    """-> (Handle kwargs, oracle Problem kwargs, x0) of the bench's task with the model `kind`"""
+    from mppi_tf_amd.auv import auv_task
+    cfg = auv_task(FULL_H, learned=(kind != "auv"))
+    x0 = np.asarray(cfg.pop("x0"), F32)
+    ok = dict(tau=FULL_H, s=13, a=6, dt=cfg["dt"], lam=cfg["lam"], sigma=cfg["sigma"], goal=cfg["goal"], Q=cfg["Q"])
+    if kind == "auv":
+        ok["auv"] = cfg["auv"]
+        return cfg, ok, x0
+    # a learned model at the task's scales: forces of 1500 N enter the network through its input normalisation, the predicted
+    # state delta leaves it through a small output scale — the recurrence stays bounded over 64 steps (synthetic weights, SURVEY §8d)
+    speed = kind == "speed"
+    net = make_nnauv_speed(3, 16, 3) if speed else make_nnauv(3, 32, 3)
+    n_state = 9 if speed else 10
+    net["xstd"] = np.array([1.0] * n_state + [1500.0] * 6, F32)
+    net["xmean"] = np.zeros(n_state + 6, F32)
+    net["ystd"] = np.full(6 if speed else 13, 0.02, F32)
+    net["ymean"] = np.zeros(6 if speed else 13, F32)
+    key = "nnauv_speed" if speed else "nnauv"
+    cfg[key], ok[key] = net, net
+    if kind == "bf16x3":
+        cfg["mlp_bf16x3"] = True
+    return cfg, ok, x0
+
+
+def shards_agree_with(m, cfg, x0, U_in, u, c, shards=8):
+    """the K-sharded step (records exchanged by hand) against the unsharded one: same costs, replicated control within 2e-6 of sigma"""
+    import torch
+    hs = [m.Handle(k=FULL_K, shard_rank=g, shard_count=shards, **cfg) for g in range(shards)]
+    xd = torch.tensor(x0, device="cuda")
+    n = hs[0].record_size
+    recs = torch.zeros(shards * n, device="cuda")
+    us = [torch.zeros(6, device="cuda") for _ in range(shards)]
+    for g, hg in enumerate(hs):
+        hg.set_action_sequence(U_in)
+        hg.shard_partial(xd.data_ptr(), recs[g * n:(g + 1) * n].data_ptr())
+        hg.synchronize()
+    for g, hg in enumerate(hs):
+        hg.shard_finish(recs.data_ptr(), shards, us[g].data_ptr())
+        hg.synchronize()
+        np.testing.assert_array_equal(us[g].cpu().numpy(), us[0].cpu().numpy())
+        np.testing.assert_allclose(us[g].cpu().numpy() / 1500.0, u / 1500.0, rtol=0, atol=2e-6)
+        np.testing.assert_array_equal(hg.debug_get(m.DBG_COSTS), c[hg.k_offset:hg.k_offset + hg.k_local])
+
+
+def update_is_the_recombination(m, h, U_in, c, eps, u, lam=1.0, scale=1500.0):
+    """weights = the soft-min of the kernel's own costs, sum to 1; U' = U + sum_k w_k eps_k recomputed in fp64 from the exported noise"""
+    c64 = c.astype(np.float64)
+    e = np.exp(-(c64 - c64.min()) / lam)
+    w = h.debug_get(m.DBG_WEIGHTS).astype(np.float64)
+    assert abs(w.sum() - 1) < 1e-5 and (w >= 0).all()
+    np.testing.assert_allclose(w, e / e.sum(), rtol=1e-5, atol=1e-12)
+    Uupd = h.debug_get(m.DBG_U_UPDATED).astype(np.float64)
+    want = U_in + np.tensordot(e / e.sum(), eps.astype(np.float64), axes=(0, 0))
+    print("max|U' - fp64 recombination| / sigma = %.3g" % (np.abs(Uupd - want).max() / scale))
+    np.testing.assert_allclose(Uupd / scale, want / scale, rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(u, Uupd[0].astype(F32))
+
+
+def test_full_size_fossen_auv_costs_bit_identical(m):
+    """k_rollout_gen<0, 32, true> (AUVModel rk2, rexrov2) at the bench's size, fused Philox step: ALL 65536 sample costs bit-identical
+    to the fp32 oracle on the exported noise (auv_model.py:282-333), the noise is the oracle's Philox stream for a = 6, U' is the fp64
+    recombination, and the 8-way sharded step is the unsharded one."""
+    cfg, ok, x0 = full_size_cfg("auv")
+    h = m.Handle(k=FULL_K, **cfg)
+    assert h.rollout_kernel_name() == "mppi::k_rollout_gen<0, 32, true>"
+    p32 = orc.Problem(threads=0, **ok)
+    U_in = (100.0 * np.random.default_rng(1).standard_normal((FULL_H, 6))).astype(F32)
+    h.set_action_sequence(U_in)
+    u = h.next(x0)
+    c, eps = h.debug_get(m.DBG_COSTS), h.debug_get(m.DBG_NOISE)
+    assert np.isfinite(c).all()
+    np.testing.assert_array_equal(c, p32.rollout_cost(x0, U_in, eps))
+    np.testing.assert_allclose(eps[:128] / 1500.0, orc.noise(1, 0, 0, 128, FULL_H, 6, cfg["sigma"]) / 1500.0, rtol=0, atol=5e-6)
+    update_is_the_recombination(m, h, U_in, c, eps, u)
+    shards_agree_with(m, cfg, x0, U_in, u, c)
+
+
+def test_multi_round_fossen_auv_costs_bit_identical(m):
+    """K = 200001 (3126 tiles: several rounds per SIMD, a ragged last tile, the 16:1 record fold in front of the finish), rk2:
+    costs bit-identical to the fp32 oracle, U' the fp64 recombination."""
+    cfg, ok, x0 = full_size_cfg("auv")
+    K, H = 200001, 16
+    cfg["tau"], ok["tau"] = H, H
+    h = m.Handle(k=K, **cfg)
+    p32 = orc.Problem(threads=0, **ok)
+    U_in = (100.0 * np.random.default_rng(2).standard_normal((H, 6))).astype(F32)
+    h.set_action_sequence(U_in)
+    u = h.next(x0)
+    c, eps = h.debug_get(m.DBG_COSTS), h.debug_get(m.DBG_NOISE)
+    assert c.shape == (K,) and eps.shape == (K, H, 6)
+    np.testing.assert_array_equal(c, p32.rollout_cost(x0, U_in, eps))
+    update_is_the_recombination(m, h, U_in, c, eps, u)
+
+
+@pytest.mark.parametrize("kind", ["mfma", "bf16x3", "speed"])
+def test_full_size_learned_13_state_models(m, kind):
+    """k_rollout_nnauv32<true>, k_rollout_nnauv32_bx3<true> (NNAUVModel, nn_model.py:215-304) and NNAUVModelSpeed's kernel (nn_model.py:307-588)
+    at the bench's size: 1536 sampled costs as close to the fp64 oracle as the fp32 CPU evaluation is (4x; 8x for the split-bf16 kernel), U' = the
+    fp64 recombination of the exported noise with the soft-min of the kernel's own costs, 8-way sharded == unsharded."""
+    cfg, ok, x0 = full_size_cfg(kind)
+    h = m.Handle(k=FULL_K, **cfg)
+    name = h.rollout_kernel_name()
+    assert name.startswith({"mfma": "mppi::k_rollout_nnauv32<true>", "bf16x3": "mppi::k_rollout_nnauv32_bx3<true>", "speed": "mppi::k_rollout_"}[kind]), name
+    p32, p64 = orc.Problem(threads=0, **ok), orc.Problem(threads=0, dtype=np.float64, **ok)
+    U_in = (100.0 * np.random.default_rng(1).standard_normal((FULL_H, 6))).astype(F32)
+    h.set_action_sequence(U_in)
+    u = h.next(x0)
+    c, eps = h.debug_get(m.DBG_COSTS), h.debug_get(m.DBG_NOISE)
+    assert np.isfinite(c).all()
+    idx = np.sort(np.random.default_rng(3).choice(FULL_K, 1536, replace=False))
+    truth = p64.rollout_cost(x0, U_in, eps[idx])
+    cpu = p32.rollout_cost(x0, U_in, eps[idx]).astype(np.float64)
+    rel = lambda a: float((np.abs(a - truth) / np.abs(truth)).max())
+    e_gpu, e_cpu = rel(c[idx].astype(np.float64)), rel(cpu)
+    print("%s K=%d H=%d: max rel cost error on 1536 sampled rollouts GPU %.3g, fp32 CPU %.3g" % (name, FULL_K, FULL_H, e_gpu, e_cpu))
+    assert e_gpu < (8 if kind == "bf16x3" else 4) * max(e_cpu, 1e-6)
+    np.testing.assert_allclose(eps[:128] / 1500.0, orc.noise(1, 0, 0, 128, FULL_H, 6, cfg["sigma"]) / 1500.0, rtol=0, atol=5e-6)
+    update_is_the_recombination(m, h, U_in, c, eps, u)
+    shards_agree_with(m, cfg, x0, U_in, u, c)
+
+
+def test_static_quat_cost_at_the_goal_attitude_is_finite(m):
+    """<q, g_q> of two unit quaternions can round to 1 + 1 ulp when the vehicle sits AT a goal attitude that is not
+    axis-aligned; acosf(1 + ulp) is NaN and one NaN cost poisons eta, U' and the warm start for good. The device clamps the dot
+    product to [-1, 1]: the reference's value wherever the reference's is finite (elsewhere the reference's own cost is NaN,
+    static_cost.py:141-159). Found by search: goal attitudes whose fp32 dot with themselves exceeds 1."""
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal((20000, 4)).astype(F32)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True).astype(F32)).astype(F32)
+    dot = ((q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1]) + q[:, 2] * q[:, 2]) + q[:, 3] * q[:, 3]  # the cost's own order, fp32
+    over = np.nonzero(dot > 1.0)[0]
+    assert over.size > 0
+    g = q[over[0]]
+    goal = [1.0, 2.0, -3.0] + [float(v) for v in g] + [0.0] * 6
+    x = np.array(goal, F32)
+    h = m.Handle(k=64, tau=4, s_dim=13, a_dim=6, sigma=np.eye(6), goal=goal, Q=Q10, quat_cost=True, auv=rexrov(m))
+    c = h.state_cost(x[None])
+    assert np.isfinite(c).all() and float(c[0]) == 0.0
+    # the closed loop started at the goal stays finite
+    hh = m.Handle(k=1024, tau=8, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=50.0 * np.eye(6), goal=goal, Q=Q10, quat_cost=True, auv=rexrov(m), seed=3)
+    for _ in range(3):
+        assert np.isfinite(hh.next(x)).all()
+    assert np.isfinite(hh.get_action_sequence()).all()

@@ -270,3 +270,173 @@ def test_weights_pushed_into_a_live_controller(m):
     ctl2 = m.ControllerBase(model=model2, cost=m.StaticCost(1.0, 1.0, 1.0, base["sigma"], np.array(base["goal"])[:, None], np.ones(13), diag=True),
                             k=1024, tau=6, sDim=13, aDim=6, lam=1.0, sigma=base["sigma"], seed=4)
     np.testing.assert_array_equal(ctl.next(x13[:, None]), ctl2.next(x13[:, None]))
+
+
+def fossen_transitions(m, n, seed=0, scale=300.0):
+    from conftest import load_golden
+    plant = m.AUVModel(actionDim=6, dt=0.1, parameters=load_golden("model_auv")["params"])
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, 13)) * np.array([1, 1, 1, 0, 0, 0, 0, .5, .5, .5, .2, .2, .2])
+    q = rng.standard_normal((n, 4)) * 0.3 + np.array([0, 0, 0, 1.0])
+    x[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    u = scale * rng.standard_normal((n, 6))
+    return plant, x[..., None], u[..., None], plant.build_step_graph("plant", x[..., None], u[..., None])
+
+
+def test_update_weights_between_trainings_reaches_the_device(m):
+    """the device learner used to be built once from the model's weights and never refreshed — the reference's grid-search
+    pattern model.update_weights(init_weights) (learner_base.py:143), or a loaded weight file, was ignored by the next train() and then
+    overwritten by it. Now: train, put the initial weights back, train again == a fresh learner trained once from those weights."""
+    _, x, u, xn = fossen_transitions(m, 2000)
+    model = m.NNAUVModel()
+    init = model.get_weights()
+    learner = m.LearnerBase(model, bufferSize=2000)
+    learner.add_rb(x, u, xn)
+    learner.stats()
+    learner.train_all(learningRate=3e-3, epoch=20)
+    assert not np.array_equal(model.get_weights()[0], init[0])
+    model.update_weights(init)
+    a = learner.train_all(learningRate=3e-3, epoch=20)  # (train_all starts a new Adam, learner_base.py:149)
+    fresh_model = m.NNAUVModel()
+    fresh = m.LearnerBase(fresh_model, bufferSize=2000)
+    fresh.add_rb(x, u, xn)
+    fresh.stats()
+    b = fresh.train_all(learningRate=3e-3, epoch=20)
+    assert a == b
+    for wa, wb in zip(model.get_weights(), fresh_model.get_weights()):
+        np.testing.assert_array_equal(wa, wb)
+    # evaluate() looks at the model it is given, not at what an earlier call left on the device
+    X, y = model.prepare_training_data(x, xn, u)
+    l_trained = learner.evaluate(model, X, y)
+    model.update_weights(init)
+    l_init = learner.evaluate(model, X, y)
+    assert l_init > 2 * l_trained
+
+
+RESUME_WORKER = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import mppi_tf_amd as m
+path, rb, out = sys.argv[2:5]
+model = m.NNAUVModel()
+learner = m.LearnerBase(model, filename=rb, bufferSize=2000)
+learner.load_params(path)
+d = learner.rb_trans()
+X, y = model.prepare_training_data(d["obs"], d["next_obs"], d["act"])
+learner.train(X, y, epoch=3, learningRate=3e-3)
+h = m.Handle(k=1024, tau=8, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=100.0 * np.eye(6), goal=[1.0, 0.5, -0.5, 0, 0, 0, 1.0] + [0.0] * 6,
+             Q=np.array([50.0] * 3 + [5.0] * 4 + [1.0] * 6), nnauv=model.mlp(), seed=2)
+u = h.next(np.array([0, 0, 0, 0, 0, 0, 1.0] + [0.0] * 6, np.float32))
+np.savez(out, u=u, step=learner.step, dev_step=learner._dev.step_count(), **{"w%d" % i: w for i, w in enumerate(model.get_weights())})
+"""
+
+
+def test_what_the_learner_learned_survives_the_process(m, tmp_path):
+    """LearnerBase.save_params (learner_base.py:66-68) / NNModel.save_params / load_params (nn_model.py:137-142): weights,
+    normalisation, both Adam moments and the step count in ONE flat file (mppi_learner_save). save -> NEW PROCESS -> load -> the next Adam
+    steps and the next control step are bit-identical to the ones the saving process goes on to make. The file's layout is checked
+    against the documented one byte count by byte count."""
+    import struct
+    import subprocess
+    import sys
+    from conftest import ROOT
+    _, x, u, xn = fossen_transitions(m, 2000, seed=4)
+    model = m.NNAUVModel()
+    learner = m.LearnerBase(model, bufferSize=2000, logPath=str(tmp_path / "learner"))
+    learner.add_rb(x, u, xn)
+    learner.stats()
+    X, y = model.prepare_training_data(x, xn, u)
+    learner.train(X, y, epoch=20, learningRate=3e-3)
+    path = learner.save_params(learner.step)
+    assert path.endswith("weights_step20")
+    rb = str(tmp_path / "rb.npz")
+    learner.save_rb(rb)
+    # the documented layout
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"MPPILRN1"
+    n_layers, *rest = struct.unpack("<8i", raw[8:40])
+    widths, step, has_norm = rest[:5], rest[5], rest[6]
+    assert (n_layers, list(widths), step, has_norm) == (4, [16, 32, 32, 32, 13], 20, 1)
+    n_fl = sum(3 * (widths[l] + 1) * widths[l + 1] for l in range(4))
+    assert len(raw) == 40 + 4 * n_fl + 8 * 2 * (16 + 13)
+    W0 = np.frombuffer(raw, "<f4", 16 * 32, 40).reshape(16, 32)
+    np.testing.assert_array_equal(W0, model.get_weights()[0])
+    np.testing.assert_array_equal(np.frombuffer(raw, "<f8", 16, 40 + 4 * n_fl), model.Xmean)
+    # this process goes on
+    learner.train(X, y, epoch=3, learningRate=3e-3)
+    h = m.Handle(k=1024, tau=8, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=100.0 * np.eye(6), goal=[1.0, 0.5, -0.5, 0, 0, 0, 1.0] + [0.0] * 6,
+                 Q=np.array([50.0] * 3 + [5.0] * 4 + [1.0] * 6), nnauv=model.mlp(), seed=2)
+    u_here = h.next(np.array([0, 0, 0, 0, 0, 0, 1.0] + [0.0] * 6, F32))
+    # a new process resumes from the file
+    out = str(tmp_path / "resumed.npz")
+    r = subprocess.run([sys.executable, "-c", RESUME_WORKER, ROOT, path, rb, out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(out)
+    assert int(d["step"]) == 23 and int(d["dev_step"]) == 23
+    for i, w in enumerate(model.get_weights()):
+        np.testing.assert_array_equal(d["w%d" % i], w)
+    np.testing.assert_array_equal(d["u"], u_here)
+    # the model's own save_params / load_params (weights + normalisation, no optimizer state): a controller built from the loaded model is the same controller
+    f = model.save_params(str(tmp_path / "model"), 23)
+    other = m.NNAUVModel()
+    other.load_params(f)
+    for wa, wb in zip(model.get_weights(), other.get_weights()):
+        np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_array_equal(other.Xstd, model.Xstd)
+    np.testing.assert_array_equal(other.Ymean, model.Ymean)
+    with pytest.raises(m.MppiError):  # another architecture's file
+        m.Learner(make_net([9, 16, 6])).load(f)
+    with pytest.raises(m.MppiError):
+        m.Learner.from_file(rb)  # not a learner file
+
+
+def test_validate_and_the_validation_loop_of_train(m):
+    """LearnerBase.validate (learner_base.py:218-320) and the every-10th-epoch validation of train (:336-358): the trajectory error of the
+    model rolled from each trajectory's first state against the fp64 oracle rolling the same weights, the transition error against a
+    numpy forward pass, every flag combination's return shape, and the log train(..., val=...) leaves."""
+    plant, x, u, xn = fossen_transitions(m, 3000, seed=6)
+    model = m.NNAUVModel()
+    learner = m.LearnerBase(model, bufferSize=3000)
+    learner.add_rb(x, u, xn)
+    learner.stats()
+    # held-out trajectories of the plant: k = 12, tau = 9
+    rng = np.random.default_rng(9)
+    k, tau = 12, 9
+    acts = 300.0 * rng.standard_normal((k, tau, 6))
+    st = np.zeros((k, 13, 1))
+    st[:, 6] = 1.0
+    traj = [st]
+    for t in range(tau - 1):
+        traj.append(plant.build_step_graph("plant", traj[-1], acts[:, t][..., None]))
+    gt = np.concatenate([s[:, None] for s in traj], axis=1)[..., 0]
+    X, y = model.prepare_training_data(x, xn, u)
+    first, last = learner.train(X, y, epoch=35, learningRate=3e-3, val=(gt, acts))
+    assert [e for e, _ in learner.val_log] == [0, 10, 20, 30] and last < first
+    assert learner.val_log[-1][1]["Val-Transition-Norm"] < learner.val_log[0][1]["Val-Transition-Norm"]
+    assert learner.val_log[0][1]["Val-Split"].shape == (13,) and learner.step == 35
+    # the numbers, against independent evaluations of the same weights
+    err, errNorm, errSplit, errSplitNorm, tErr, tErrNorm, tSplit, tSplitNorm = learner.validate(model, acts, gt, transition=True, split=True, norm=True)
+    p64 = orc.Problem(tau=2, s=13, a=6, dt=0.1, sigma=np.eye(6), goal=np.zeros(13), nnauv=model.mlp(), dtype=np.float64)
+    s64, rolled = gt[:, 0].copy(), [gt[:, 0].copy()]
+    for t in range(tau - 1):
+        s64 = p64.model_next(s64, acts[:, t])
+        rolled.append(s64)
+    rolled = np.stack(rolled, axis=1)
+    ref_split = np.mean((rolled - gt) ** 2, axis=(0, 1))
+    np.testing.assert_allclose(errSplit, ref_split, rtol=2e-3, atol=1e-9)
+    assert abs(err - ref_split.mean()) <= 2e-3 * ref_split.mean()
+    np.testing.assert_allclose(errSplitNorm, np.mean(((rolled - gt) / model.Ystd) ** 2, axis=(0, 1)), rtol=2e-3, atol=1e-9)
+    Xn, Yn = model.prepare_training_data(gt[:, :-1].reshape(-1, 13, 1), gt[:, 1:].reshape(-1, 13, 1), acts[:, :-1].reshape(-1, 6, 1))
+    hcur = Xn
+    w = model.get_weights()
+    for l in range(4):
+        hcur = hcur @ w[2 * l].astype(np.float64) + w[2 * l + 1]
+        hcur = np.maximum(hcur, 0) if l < 3 else hcur
+    np.testing.assert_allclose(tSplitNorm, np.mean((hcur - Yn) ** 2, axis=0), rtol=1e-4, atol=1e-9)
+    assert abs(tErrNorm - np.mean((hcur - Yn) ** 2)) <= 1e-4 * tErrNorm
+    np.testing.assert_allclose(tSplit, np.mean(((hcur - Yn) * model.Ystd) ** 2, axis=0), rtol=1e-4, atol=1e-12)
+    # the reference's return tuples
+    assert isinstance(learner.validate(model, acts, gt), float)
+    assert len(learner.validate(model, acts, gt, transition=True)) == 2 and len(learner.validate(model, acts, gt, split=True)) == 2
+    assert len(learner.validate(model, acts, gt, norm=True)) == 2 and len(learner.validate(model, acts, gt, split=True, norm=True)) == 4
+    assert len(learner.validate(model, acts, gt, transition=True, split=True)) == 4 and len(learner.validate(model, acts, gt, transition=True, norm=True)) == 4

@@ -476,6 +476,99 @@ def test_sharded_normalize_cost_equals_the_unsharded_normalised_step(m, path, sh
         plain.shard_cost_range(torch.zeros(6, device="cuda").data_ptr(), torch.zeros(2, device="cuda").data_ptr())
 
 
+def test_sharded_normalize_cost_path_is_a_function_of_the_global_configuration(m):
+    """with 132 < H <= 160 the producer/consumer kernel serves a handle only with 5 producer waves, and the producer
+    count follows the SHARD's tile count (<= 512 tiles: 5, else 3). K = 65537 over two ranks gives shards of 512 and 513 tiles: before
+    the fix rank 0 made raw-cost records at the range temperature (fast form) and rank 1 normalised-cost records at lambda. Both now
+    take the cost pass + normalise + record pass form; the combined step is the unsharded normalised step."""
+    K, H, a, lam = 65537, 140, 3, 0.4
+    make = lambda **kw: make_pair(m, K, H, a, lam=lam, normalize=True, seed=33, **kw)[0]
+    x = np.array([0.2, 0.1, -0.3, 0, 0.5, -0.1], F32)
+    hs, out = run_sharded_normalized(m, make, 2, x)
+    assert [(h.k_local + 63) // 64 for h in hs] == [512, 513]
+    full = make()
+    for us, agreed in out:
+        u_full = full.next(x)
+        c = full.debug_get(m.DBG_COSTS)
+        np.testing.assert_array_equal(agreed, np.array([-c.min(), c.max()], F32))
+        np.testing.assert_array_equal(us[1], us[0])
+        np.testing.assert_allclose(us[0], u_full, rtol=0, atol=2e-6)
+    for h in hs:
+        np.testing.assert_allclose(h.get_action_sequence(), full.get_action_sequence(), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+@pytest.mark.parametrize("comm", ["none", "rccl"])
+def test_shard_step_is_the_three_calls_in_one(m, normalize, comm):
+    """mppi_shard_step: record -> the CALLER's all-gather -> finish in ONE C call, the collectives handed over as function
+    pointers with ncclAllGather's / ncclAllReduce's signatures. Bit for bit the controls of mppi_shard_partial -> all-gather ->
+    mppi_shard_finish — without a communicator (one shard, coll = NULL) and through RCCL's own entry points on a one-rank
+    communicator created here (ncclCommInitRank via ctypes, the librccl.so torch holds); also for a normalize_cost handle, whose
+    step has the second, 2-float all-reduce(MAX)."""
+    import torch
+    K, H, a, lam = 8192, 32, 3, 0.5
+    make = lambda: make_pair(m, K, H, a, lam=lam, normalize=normalize, seed=17)[0]
+    one, three = make(), make()
+    coll = None
+    if comm == "rccl":
+        from mppi_tf_amd.rccl import RcclComm
+        rc = RcclComm(0, 1)
+        coll = rc.coll
+    n = three.record_size
+    rec, rng = torch.zeros(n, device="cuda"), torch.zeros(2, device="cuda")
+    u1, u3 = torch.zeros(a, device="cuda"), torch.zeros(a, device="cuda")
+    x = torch.tensor([0.2, 0.1, -0.3, 0, 0.5, -0.1], device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for step in range(4):
+        one.shard_step(x.data_ptr(), u1.data_ptr(), coll, st)
+        if normalize:
+            three.shard_cost_range(x.data_ptr(), rng.data_ptr(), st)
+            three.shard_partial_normalized(x.data_ptr(), rng.data_ptr(), rec.data_ptr(), st)
+        else:
+            three.shard_partial(x.data_ptr(), rec.data_ptr(), st)
+        three.shard_finish(rec.data_ptr(), 1, u3.data_ptr(), st)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(u1.cpu().numpy(), u3.cpu().numpy())
+    np.testing.assert_array_equal(one.get_action_sequence(), three.get_action_sequence())
+    assert one.get_step_counter() == three.get_step_counter() == 4
+    # a sharded handle without an all-gather, and a failing collective: refused / reported, never a silent wrong step
+    sh = make_pair(m, K, H, a, seed=17, shard_rank=0, shard_count=2)[0]
+    with pytest.raises(m.MppiError):
+        sh.shard_step(x.data_ptr(), u1.data_ptr(), None, st)
+    import ctypes as C
+    from mppi_tf_amd._lib import Collectives
+    FAIL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)(lambda *a_: 5)
+    bad = Collectives(all_gather=C.cast(FAIL, C.c_void_p).value, all_reduce=None, comm=None)
+    plain = make_pair(m, K, H, a, seed=17)[0]
+    U0, s0 = plain.get_action_sequence(), plain.get_step_counter()
+    with pytest.raises(m.MppiError) as ei:
+        plain.shard_step(x.data_ptr(), u1.data_ptr(), bad, st)
+    assert ei.value.status == 8 and "5" in str(ei.value)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(plain.get_action_sequence(), U0)  # nothing of the update was enqueued
+    assert plain.get_step_counter() == s0
+
+
+def test_sharded_controller_takes_the_one_call_path_with_its_own_communicator(m, monkeypatch):
+    """ShardedController on the collective path = ONE C call per step (mppi_shard_step -> ncclAllGather on the controller's own
+    communicator); MPPI_RCCL_CALL=torch keeps the three calls + torch.distributed. Same controls either way."""
+    import torch
+    from mppi_tf_amd.distributed import ShardedController
+    monkeypatch.setenv("MPPI_FORCE_EXCHANGE", "1")
+    monkeypatch.delenv("MPPI_EXCHANGE", raising=False)
+    cfg = dict(k=4096, tau=32, s_dim=6, a_dim=3, sigma=0.25 * np.eye(3), goal=GOAL3, seed=11, lam=0.5)
+    fast = ShardedController(exchange="rccl", **cfg)
+    assert fast.rccl is not None and "one C call" in fast.rccl_note
+    monkeypatch.setenv("MPPI_RCCL_CALL", "torch")
+    slow = ShardedController(exchange="rccl", **cfg)
+    assert slow.rccl is None
+    x = torch.tensor([0.2, 0.1, -0.3, 0, 0.5, -0.1], device="cuda")
+    for _ in range(3):
+        ua, ub = fast.next(x), slow.next(x)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(ua.cpu().numpy(), ub.cpu().numpy())
+
+
 def test_sharded_controller_with_normalize_cost(m, monkeypatch):
     """ShardedController(normalize_cost=True) on the real backend, exchange forced on one rank: the range / record / finish sequence
     gives the unsharded handle's controls (2e-6); the direct exchange is not brought up for it (it carries the records only)."""
@@ -1574,3 +1667,16 @@ def test_device_resident_steps_replay_from_a_hipgraph(m):
     np.testing.assert_array_equal(ug[1].cpu().numpy(), ud.cpu().numpy())
     np.testing.assert_array_equal(hg.get_action_sequence(), hd.get_action_sequence())
     assert hg.get_step_counter() == hd.get_step_counter() == 1 + 2 * replays
+
+
+def test_roctx_ranges_around_the_step(m):
+    """MPPI_TUNE_TRACE (the reference brackets its step with tf.profiler.experimental.start/stop,
+    controller_base.py:241-248, 587-595): roctx ranges mppi:step > mppi:rollout / mppi:finish around what a step enqueues, the marker
+    library dlopen'ed on first use. Tracing changes nothing about the step; profiles/r04_marker_trace.* holds a rocprofv3 --marker-trace
+    timeline of examples/host_loop with it."""
+    x = np.array([0.2, 0.1, -0.3, 0, 0.5, -0.1], F32)
+    traced, plain = make_pair(m, 2048, 16, 3, seed=5, tuning={"trace": 1})[0], make_pair(m, 2048, 16, 3, seed=5)[0]
+    for _ in range(3):
+        np.testing.assert_array_equal(traced.next(x), plain.next(x))
+    traced.set_tuning("trace", 0)
+    np.testing.assert_array_equal(traced.next(x), plain.next(x))
