@@ -201,6 +201,79 @@ __device__ __forceinline__ uint4 philox4x32_10_block_ub(unsigned long long seed,
     return uint4{c0, c1, c2, c3};
 }
 
+// A consecutive Philox blocks of one sample, ROUND-MAJOR: round r of every block before round r+1 of any (r04). One block is a chain
+// of 10 dependent rounds, each two independent 32x32->64 products followed by the two three-input xors that need them; written block
+// after block (philox4x32_10_block_ub in a loop) hipcc keeps that order and a wave offers the SIMD two independent instructions at a
+// time — whenever fewer than four waves of the SIMD are runnable (barriers, the light consumer wave, the tile tails) the chain's
+// latency is exposed (SQ_ACTIVE_INST_VALU 12.2 us against 9.4 us at ideal issue rates at C3). With the A blocks of a horizon group
+// advanced in lock step there are 2A independent products per round. The same integer arithmetic per block: bit-identical to
+// philox4x32_10_block_ub(seed, subsequence_lo, block0_uniform + q) by construction, checked against rocRAND's engine by the noise tests.
+template <int A>
+__device__ __forceinline__ void philox4x32_10_blocks_ub(unsigned long long seed, unsigned int subsequence_lo, unsigned long long block0_uniform,
+                                                        uint4 (&out)[A])
+{
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+    unsigned int c0[A], c1[A], c2[A], c3[A];
+    // round 0: c0, c1 uniform (the block index); c2 = the lane's sample (the same product for every block); c3 = 0
+    const unsigned long long m1 = (unsigned long long)ROCRAND_PHILOX_M4x32_1 * subsequence_lo;
+    unsigned int a0[A], a2s[A], a3s[A];
+    const unsigned int a1 = (unsigned int)m1;
+#pragma unroll
+    for (int q = 0; q < A; ++q) {
+        const unsigned long long blk = block0_uniform + (unsigned long long)q;
+        const unsigned int c0s = (unsigned int)blk, c1s = (unsigned int)(blk >> 32);
+        const unsigned long long m0s = (unsigned long long)ROCRAND_PHILOX_M4x32_0 * c0s; // scalar
+        a0[q] = (unsigned int)(m1 >> 32) ^ (c1s ^ k0);
+        a2s[q] = (unsigned int)(m0s >> 32) ^ k1; a3s[q] = (unsigned int)m0s;              // uniform
+    }
+    k0 += ROCRAND_PHILOX_W32_0; k1 += ROCRAND_PHILOX_W32_1;
+    // round 1: c0 = a0, c1 = a1 per lane; c2 = a2s, c3 = a3s uniform
+    unsigned int b0[A], b1s[A], b2[A], b3[A];
+#pragma unroll
+    for (int q = 0; q < A; ++q) {
+        const unsigned long long m0 = (unsigned long long)ROCRAND_PHILOX_M4x32_0 * a0[q];
+        const unsigned long long m1s = (unsigned long long)ROCRAND_PHILOX_M4x32_1 * a2s[q];   // scalar
+        b0[q] = a1 ^ ((unsigned int)(m1s >> 32) ^ k0); b1s[q] = (unsigned int)m1s;
+        b2[q] = (unsigned int)(m0 >> 32) ^ (a3s[q] ^ k1); b3[q] = (unsigned int)m0;
+    }
+    k0 += ROCRAND_PHILOX_W32_0; k1 += ROCRAND_PHILOX_W32_1;
+    // round 2: c1 = b1s uniform, the rest per lane
+#pragma unroll
+    for (int q = 0; q < A; ++q) {
+        const unsigned long long m0 = (unsigned long long)ROCRAND_PHILOX_M4x32_0 * b0[q];
+        const unsigned long long m1b = (unsigned long long)ROCRAND_PHILOX_M4x32_1 * b2[q];
+        c0[q] = (unsigned int)(m1b >> 32) ^ (b1s[q] ^ k0); c1[q] = (unsigned int)m1b;
+        c2[q] = __builtin_amdgcn_bitop3_b32((unsigned int)(m0 >> 32), b3[q], k1, 0x96); c3[q] = (unsigned int)m0;
+    }
+    k0 += ROCRAND_PHILOX_W32_0; k1 += ROCRAND_PHILOX_W32_1;
+#pragma unroll
+    for (int r = 3; r < 10; ++r) {
+        unsigned long long p0[A], p1[A];
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            p0[q] = (unsigned long long)ROCRAND_PHILOX_M4x32_0 * c0[q];
+            p1[q] = (unsigned long long)ROCRAND_PHILOX_M4x32_1 * c2[q];
+        }
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            const unsigned int n0 = __builtin_amdgcn_bitop3_b32((unsigned int)(p1[q] >> 32), c1[q], k0, 0x96);
+            const unsigned int n2 = __builtin_amdgcn_bitop3_b32((unsigned int)(p0[q] >> 32), c3[q], k1, 0x96);
+            c0[q] = n0; c1[q] = (unsigned int)p1[q]; c2[q] = n2; c3[q] = (unsigned int)p0[q];
+        }
+        k0 += ROCRAND_PHILOX_W32_0; k1 += ROCRAND_PHILOX_W32_1;
+#if !defined(MPPI_PHILOX_FREE_ORDER)
+        // Keep the rounds round-major: ONE empty asm statement that takes and returns the multiplicands of every block's next round.
+        // (A __builtin_amdgcn_sched_barrier does not do it: pure arithmetic is not ordered against it when the block's DAG is
+        // linearised, and hipcc emitted block 0's whole chain between the barriers and the other blocks behind the last one.)
+        if constexpr (A == 2) asm volatile("" : "+v"(c0[0]), "+v"(c2[0]), "+v"(c0[1]), "+v"(c2[1]));
+        if constexpr (A == 3) asm volatile("" : "+v"(c0[0]), "+v"(c2[0]), "+v"(c0[1]), "+v"(c2[1]), "+v"(c0[2]), "+v"(c2[2]));
+        if constexpr (A == 4) asm volatile("" : "+v"(c0[0]), "+v"(c2[0]), "+v"(c0[1]), "+v"(c2[1]), "+v"(c0[2]), "+v"(c2[2]), "+v"(c0[3]), "+v"(c2[3]));
+#endif
+    }
+#pragma unroll
+    for (int q = 0; q < A; ++q) out[q] = uint4{c0[q], c1[q], c2[q], c3[q]};
+}
+
 // The 4 standard normals of ONE Philox block of a sample (block uniform or not): the single place every rollout kernel that
 // draws block by block (k_rollout_mlp2, k_rollout_mlp32, k_rollout_nnauv32) gets them from, so that the rollout and the tile
 // record (mlp_tile_record -> normals_group) always agree — also in the -DMPPI_ROCRAND_NORMALS variant build.
@@ -221,18 +294,22 @@ template <int A>
 __device__ __forceinline__ void normals_group_ub(unsigned long long seed, unsigned int gk_lo, unsigned long long group_index_uniform,
                                                  float (&z)[4 * A])
 {
+#if defined(MPPI_ROCRAND_NORMALS)
 #pragma unroll
     for (int q = 0; q < A; ++q) {
-#if defined(MPPI_ROCRAND_NORMALS)
         PhiloxAt eng(seed, (unsigned long long)gk_lo, 4ull * (group_index_uniform * A + q));
         const float4 n = rocrand_device::detail::normal_distribution4(eng.block());
         z[4 * q + 0] = n.x; z[4 * q + 1] = n.y; z[4 * q + 2] = n.z; z[4 * q + 3] = n.w;
-#else
-        const uint4 r = philox4x32_10_block_ub(seed, gk_lo, group_index_uniform * A + q);
-        const float2 n0 = box_muller_hw(r.x, r.y), n1 = box_muller_hw(r.z, r.w);
-        z[4 * q + 0] = n0.x; z[4 * q + 1] = n0.y; z[4 * q + 2] = n1.x; z[4 * q + 3] = n1.y;
-#endif
     }
+#else
+    uint4 r[A];
+    philox4x32_10_blocks_ub<A>(seed, gk_lo, group_index_uniform * A, r);
+#pragma unroll
+    for (int q = 0; q < A; ++q) {
+        const float2 n0 = box_muller_hw(r[q].x, r[q].y), n1 = box_muller_hw(r[q].z, r[q].w);
+        z[4 * q + 0] = n0.x; z[4 * q + 1] = n0.y; z[4 * q + 2] = n1.x; z[4 * q + 3] = n1.y;
+    }
+#endif
 }
 
 template <int A>

@@ -678,7 +678,7 @@ def full_size_cfg(kind):
     n_state = 9 if speed else 10
     net["xstd"] = np.array([1.0] * n_state + [1500.0] * 6, F32)
     net["xmean"] = np.zeros(n_state + 6, F32)
-    net["ystd"] = np.full(6 if speed else 13, 0.02, F32)
+    net["ystd"] = np.full(6 if speed else 13, 0.05, F32)
     net["ymean"] = np.zeros(6 if speed else 13, F32)
     key = "nnauv_speed" if speed else "nnauv"
     cfg[key], ok[key] = net, net
@@ -778,7 +778,14 @@ def test_full_size_learned_13_state_models(m, kind):
     rel = lambda a: float((np.abs(a - truth) / np.abs(truth)).max())
     e_gpu, e_cpu = rel(c[idx].astype(np.float64)), rel(cpu)
     print("%s K=%d H=%d: max rel cost error on 1536 sampled rollouts GPU %.3g, fp32 CPU %.3g" % (name, FULL_K, FULL_H, e_gpu, e_cpu))
-    assert e_gpu < (8 if kind == "bf16x3" else 4) * max(e_cpu, 1e-6)
+    fac = 8 if kind == "bf16x3" else 4
+    assert e_gpu < fac * max(e_cpu, 1e-6)
+    # the task's costs share a large constant part (1e4 x the squared distance to a goal 10 m away): measured against the SPREAD of the
+    # costs over the samples — what the soft-min sees — the bar is the same
+    spread = truth.std()
+    s_gpu, s_cpu = float(np.abs(c[idx] - truth).max() / spread), float(np.abs(cpu - truth).max() / spread)
+    print("   relative to the costs' spread over the samples (%.3g of their mean): GPU %.3g, fp32 CPU %.3g" % (spread / truth.mean(), s_gpu, s_cpu))
+    assert s_gpu < fac * max(s_cpu, 1e-6)
     np.testing.assert_allclose(eps[:128] / 1500.0, orc.noise(1, 0, 0, 128, FULL_H, 6, cfg["sigma"]) / 1500.0, rtol=0, atol=5e-6)
     update_is_the_recombination(m, h, U_in, c, eps, u)
     shards_agree_with(m, cfg, x0, U_in, u, c)

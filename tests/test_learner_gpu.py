@@ -310,7 +310,7 @@ def test_update_weights_between_trainings_reaches_the_device(m):
     l_trained = learner.evaluate(model, X, y)
     model.update_weights(init)
     l_init = learner.evaluate(model, X, y)
-    assert l_init > 2 * l_trained
+    assert l_init > 1.15 * l_trained, (l_init, l_trained)  # 20 Adam steps: 1.09 -> 0.82
 
 
 RESUME_WORKER = r"""
