@@ -25,13 +25,7 @@
 // Layer 2's bias is the accumulators' initial value (8 LDS reads per set and step, once the set's image is written).
 #pragma once
 
-#ifndef MPPI_BX3_CUT
-#define MPPI_BX3_CUT 1000 // timing only: the pieces behind MFMA m >= CUT are left out (the cumulative cost of a half-step's pieces)
-#endif
-#ifndef MPPI_BX3_ABL
-#define MPPI_BX3_ABL 0 // timing-only ablations (wrong results): 1 no layer 3 / finish, 2 no preparation, 4 no barriers, 8 no layer-3 pieces, 16 no relu/split
-                       // pieces, 32 no B-fragment reads in the stream; -DMPPI_BX3_STAMP prints the shader clock workgroup 0 ran at (profiles/r03_bx3_pieces.txt)
-#endif
+// (MPPI_BX3_CUT / MPPI_BX3_ABL / MPPI_BX3_STAMP_*: the timing-study layer, mppi_ablate.hip.h — 1000 / 0 / nothing in the shipped build)
 
 namespace mppi {
 
@@ -508,9 +502,7 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3(
     };
 
     const int n_tiles = (K + kBx3R - 1) / kBx3R;
-#ifdef MPPI_BX3_STAMP
-    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    MPPI_BX3_STAMP_BEGIN();
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     k0 = tile * kBx3R;
     cA = 0.0f; cB = 0.0f;
@@ -579,11 +571,7 @@ __global__ __launch_bounds__(kBx3Threads, 1) void k_rollout_mlp_bx3(
     mlp_tile_record<A, DIAG, 4>(C, c, valid, w, lane, kk, H, NG, SRC, eps_hbm, seed, koff + (unsigned long long)kk, base,
                                 partials + (size_t)record_slot(tile, rsc) * rsb, rsc);
     } // tiles
-#ifdef MPPI_BX3_STAMP
-    if (tid == 0 && blockIdx.x == 0) // shader clock against the 100 MHz reference: the clock the MFMA stream really ran at
-        printf("bx3 workgroup 0: %llu shader cycles in %llu ticks of 100 MHz = %.0f MHz\n", __builtin_amdgcn_s_memtime() - st_c0,
-               __builtin_amdgcn_s_memrealtime() - st_r0, 100.0 * (double)(__builtin_amdgcn_s_memtime() - st_c0) / (double)(__builtin_amdgcn_s_memrealtime() - st_r0));
-#endif
+    MPPI_BX3_STAMP_END();
 }
 
 } // namespace mppi

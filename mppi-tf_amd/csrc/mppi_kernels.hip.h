@@ -3,6 +3,7 @@
 #pragma once
 
 #include "mppi_device.hip.h"
+#include "mppi_ablate.hip.h" // timing-study macros: plain code in the shipped build
 
 #include <type_traits>
 
@@ -58,12 +59,7 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
         const unsigned long long seed = C->seed;
         for (int g = tid / R; g < NG; g += TQ) {
             float z[4 * A];
-#if defined(MPPI_ABLATE_PHILOX) // timing-only build: cheap stand-in for Philox + Box-Muller (tools/ablate.py)
-#pragma unroll
-            for (int j = 0; j < 4 * A; ++j) z[j] = (float)((int)((gk * 2654435761ull + (base + g) * 40503ull + j) & 1023) - 512) * (1.0f / 512.0f);
-#else
-            normals_group<A>(seed, gk, base + (unsigned long long)g, z);
-#endif
+            MPPI_NORMALS_GROUP(A, seed, gk, base + (unsigned long long)g, z);
 #pragma unroll
             for (int tl = 0; tl < 4; ++tl) {
                 const int t = 4 * g + tl;
@@ -107,11 +103,7 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
             float x[S];
 #pragma unroll
             for (int i = 0; i < S; ++i) x[i] = x_dev[i];
-#if defined(MPPI_ABLATE_ROLLOUT) // timing-only build: one step instead of H
-            for (int t = 0; t < 1; ++t) {
-#else
-            for (int t = 0; t < H; ++t) {
-#endif
+            for (int t = 0; t < MPPI_ABL_STEPS(H); ++t) {
                 float u[A], e[A], v[A];
 #pragma unroll
                 for (int j = 0; j < A; ++j) {
@@ -147,11 +139,7 @@ __global__ __launch_bounds__(kThreads) void k_rollout_tile(
     // record element (b, col) lives at partials[b*rsb + col*rsc]: column-major (rsb = 1) for the finish kernel
     float *rec = partials + (size_t)record_slot(blockIdx.x, rsc) * rsb;
     if (tid == 0) { rec[0] = red_s[0]; rec[(size_t)rsc] = red_s[1]; }
-#if defined(MPPI_ABLATE_WSUM) // timing-only build: no weighted-noise sum
-    for (int c = tid; c < 1; c += kThreads) {
-#else
-    for (int c = tid; c < HA; c += kThreads) {
-#endif
+    for (int c = tid; c < MPPI_ABL_WSUM_COLS(HA); c += kThreads) {
         const float *row = eps_s + (size_t)c * RP;
         float acc = 0.0f;
 #pragma unroll 8
@@ -186,26 +174,6 @@ __device__ __forceinline__ void static_for(F &&f)
         static_for<I + 1, N>(f);
     }
 }
-
-// -DMPPI_PC_TIMELINE (tools/timeline.py, timing study only): every wave stamps s_memrealtime (100 MHz) at its
-// phase boundaries into LDS and the consumer dumps the 64 stamps in place of the tile's costs.
-#if defined(MPPI_PC_TIMELINE)
-__device__ __forceinline__ unsigned long long pc_stamp()
-{
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#endif
-#if defined(MPPI_PC_TIMELINE)
-#define MPPI_STAMP_RT(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); if (lane == 0) tl_s[(slot)] = (float)(t_ & 0xFFFFFFull); } while (0)
-#define MPPI_STAMP(slot) do { const unsigned long long t_ = pc_stamp(); if (lane == 0) tl_s[(slot)] = (float)(t_ & 0xFFFFFFull); } while (0)
-#else
-#define MPPI_STAMP_RT(slot) do { } while (0)
-#define MPPI_STAMP(slot) do { } while (0)
-#endif
 
 // Wave priority by progress (s_setprio): the SIMD arbiter favours the oldest wave, so the workgroups sharing a CU
 // finish one after the other and the last one runs alone, latency-bound. Lowering a wave's priority as it advances
@@ -263,11 +231,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
     const int nch = (NG + NP - 1) / NP;       // chunks
     float *buf = smem;                        // [2][CS][(A+1)][64]
     float *w_s = smem;                        // [64] weights: reuses buffer 0 once every chunk is consumed
-#if defined(MPPI_PC_TIMELINE)
-    __shared__ float tl_s[64];
-    if (threadIdx.x < 64) tl_s[threadIdx.x] = 0.0f;
-    __syncthreads();
-#endif
+    MPPI_TL_DECL();
 
     const int tid = threadIdx.x;
     // Role placement. A workgroup's waves are spread over the CU's 4 SIMDs and the 4 workgroups that share a CU
@@ -294,11 +258,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
     const int k0 = blockIdx.x * 64;
     const bool valid = (k0 + lane) < K;
     float *rec = partials + (size_t)record_slot(blockIdx.x, rsc) * rsb; // element (b, col) at partials[b*rsb + col*rsc]
-#if defined(MPPI_PC_TIMELINE)
-    if (lane == 0) { // where this wave runs: HW_ID[15:0] (wave, simd, pipe, cu, sh, se) and XCC_ID[3:0]; role in slot
-        tl_s[48 + wave] = (float)(__builtin_amdgcn_s_getreg((15 << 11) | 4) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16));
-    }
-#endif
+    MPPI_TL_WHERE(wave);
 
     if (wave != 0) {
         // ------------------------------------------------------------------ producers
@@ -328,12 +288,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
                         for (int j = 0; j < A; ++j) ug[tl][j] = U_dev[tt * A + j];
                     }
                     float z[4 * A];
-#if defined(MPPI_ABLATE_PHILOX)
-#pragma unroll
-                    for (int j = 0; j < 4 * A; ++j) z[j] = (float)((int)((gk * 2654435761ull + (base + g) * 40503ull + j) & 1023) - 512) * (1.0f / 512.0f);
-#else
-                    normals_group_ub<A>(seed, gk, base + (unsigned long long)g, z);
-#endif
+                    MPPI_NORMALS_GROUP_UB(A, seed, gk, base + (unsigned long long)g, z);
 #pragma unroll
                     for (int tl = 0; tl < 4; ++tl) {
                         const int t = 4 * g + tl;
@@ -379,12 +334,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
 #pragma unroll
         for (int r = 0; r < NREG; ++r) eps_r[r] = w * eps_r[r];
         float tot[(NREG + 63) / 64];
-#if defined(MPPI_ABLATE_WSUM)
-#pragma unroll
-        for (int m = 0; m < (NREG + 63) / 64; ++m) tot[m] = eps_r[m];
-#else
-        wave_transpose_sum<NREG>(eps_r, tot, lane);
-#endif
+        MPPI_WAVE_TRANSPOSE_SUM(NREG, eps_r, tot, lane);
         const int colbase = lane_column(lane);
 #pragma unroll
         for (int m = 0; m < (NREG + 63) / 64; ++m) {
@@ -421,11 +371,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
             if (balance) pc_set_prio(ch, nch, gen);
             const float *cb = buf + (ch & 1) * CH;
             const int tend = min(CS, H - ch * CS);
-#if defined(MPPI_ABLATE_ROLLOUT)
-            for (int tl = 0; tl < (ch == 0 ? 1 : 0); ++tl) {
-#else
-            for (int tl = 0; tl < tend; ++tl) {
-#endif
+            for (int tl = 0; tl < MPPI_ABL_CHUNK_STEPS(tend, ch); ++tl) {
                 float v[A], ac;
                 if constexpr (PACKED) {
                     const slot_t sv = *static_cast<const slot_t *>(__builtin_assume_aligned(cb + (tl * 64 + lane) * SLOT, SLOT * 4));
@@ -448,9 +394,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
             if (ch + 1 < nch) __syncthreads(); // chunk ch consumed / chunk ch+1 published
         }
         c = c + cost_of(x); // terminal: x_H counted a second time, :271-272
-#if !defined(MPPI_PC_TIMELINE)
-        if (valid) cost[k0 + lane] = c;
-#endif
+        MPPI_STORE_COST(valid, cost + k0 + lane, c);
         // tile-local mBeta / mExpArg / mExp / mNabla (controller_base.cpp:166-182)
         const float beta = wave_min(valid ? c : INFINITY);
         const float arg = CC->neg_inv_lambda * (c - beta);
@@ -461,17 +405,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
         MPPI_STAMP(9);
         MPPI_STAMP_RT(63);
         __syncthreads(); // weights published
-#if defined(MPPI_PC_TIMELINE)
-        __builtin_amdgcn_s_sleep(127); // let the producers finish and stamp (a few hundred cycles), then dump
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(127);
-        if (valid) cost[k0 + lane] = tl_s[lane];
-#endif
+        MPPI_TL_DUMP(valid, cost + k0 + lane);
     }
 }
 
@@ -556,11 +490,7 @@ __device__ __forceinline__ void column_combine(Load ld, int nb, float neg_inv_la
     const int tid = threadIdx.x;
     constexpr int PER = 4; // records per thread held in registers (nb <= 1024 in one pass)
     float bb[PER], ee[PER], vv[PER];
-    // -DMPPI_FINISH_STAGE=n (timing study, tools/ablate.py finish_s*): the kernel stops after stage n — 0 entry, 1 the record loads,
-    // 2 the min over the records, 3 the weighted sums; results are then meaningless, only the kernel time counts
-#if defined(MPPI_FINISH_STAGE)
-    if (MPPI_FINISH_STAGE == 0) { beta_out = 0.f; eta_out = 1.0; V_out = 0.0; return; }
-#endif
+    MPPI_FINISH_STOP(0, 0.f); // (timing-study builds only: mppi_ablate.hip.h)
 #pragma unroll
     for (int i = 0; i < PER; ++i) { // unconditional clamped loads (see k_combine_group)
         const int b = min(tid + i * kThreads, nb - 1);
@@ -568,9 +498,7 @@ __device__ __forceinline__ void column_combine(Load ld, int nb, float neg_inv_la
         ee[i] = ld(b, 1);
         vv[i] = ld(b, 2);
     }
-#if defined(MPPI_FINISH_STAGE)
-    if (MPPI_FINISH_STAGE == 1) { float s_ = 0.f; for (int i = 0; i < PER; ++i) s_ += bb[i] + ee[i] + vv[i]; beta_out = s_; eta_out = 1.0; V_out = 0.0; return; }
-#endif
+    MPPI_FINISH_STOP(1, ((bb[0] + ee[0] + vv[0]) + (bb[1] + ee[1] + vv[1])) + ((bb[2] + ee[2] + vv[2]) + (bb[3] + ee[3] + vv[3])));
     float bmin = INFINITY;
 #pragma unroll
     for (int i = 0; i < PER; ++i) bmin = fminf(bmin, (tid + i * kThreads < nb) ? bb[i] : INFINITY);
@@ -581,9 +509,7 @@ __device__ __forceinline__ void column_combine(Load ld, int nb, float neg_inv_la
     float beta = red_f[0];
 #pragma unroll
     for (int w = 1; w < kThreads / 64; ++w) beta = fminf(beta, red_f[w]);
-#if defined(MPPI_FINISH_STAGE)
-    if (MPPI_FINISH_STAGE == 2) { beta_out = beta + ee[0] + vv[0]; eta_out = 1.0; V_out = 0.0; return; }
-#endif
+    MPPI_FINISH_STOP(2, beta + ee[0] + vv[0]);
 
     double se = 0.0, sv = 0.0;
 #pragma unroll
@@ -960,17 +886,10 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
 
         // normalised inputs of this lane's rollout (+ the bias input 1, + zero padding)
         float in[K1];
-#if defined(MPPI_ABLATE_MLP_DIV) // timing-only: multiply instead of divide
-#pragma unroll
-        for (int i = 0; i < S; ++i) in[i] = (x[i] - M->xmean[i]) * M->xstd[i];
-#pragma unroll
-        for (int i = 0; i < A; ++i) in[S + i] = (v[i] - M->xmean[S + i]) * M->xstd[S + i];
-#else
 #pragma unroll
         for (int i = 0; i < S; ++i) in[i] = (x[i] - M->xmean[i]) / M->xstd[i];
 #pragma unroll
         for (int i = 0; i < A; ++i) in[S + i] = (v[i] - M->xmean[S + i]) / M->xstd[S + i];
-#endif
         in[NIN] = 1.0f;
 #pragma unroll
         for (int i = NIN + 1; i < K1; ++i) in[i] = 0.0f;
@@ -1037,13 +956,8 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
         float py0[S], py1[S];
 #pragma unroll
         for (int n = 0; n < S; ++n) { py0[n] = 0.0f; py1[n] = 0.0f; }
-#if defined(MPPI_ABLATE_MLP_L3) // timing-only: 1 of 16 rows
-#pragma unroll
-        for (int r = 0; r < 1; ++r) {
-#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-#endif
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
             const float hv0 = acc0[r] < 0.0f ? 0.0f : acc0[r];
             const float hv1 = acc1[r] < 0.0f ? 0.0f : acc1[r];
@@ -1067,10 +981,8 @@ __global__ __launch_bounds__(kMlpThreads, 2) void k_rollout_mlp(
 #pragma unroll
         for (int n = 0; n < S; ++n) {
             float y = y_s[(0 * S + n) * R + lane];
-#if !defined(MPPI_ABLATE_MLP_Y) // timing-only: skip the cross-wave partial sum
 #pragma unroll
             for (int ww = 1; ww < 8; ++ww) y = y + y_s[(ww * S + n) * R + lane];
-#endif
             y = y + M->b3[n];
             x[n] = x[n] + (y * M->ystd[n] + M->ymean[n]);
         }

@@ -43,21 +43,7 @@
 
 namespace mppi {
 
-#ifdef MPPI_MLP2_STAMP
-__device__ unsigned long long g_mlp2_stamp[4 * 4096]; // per workgroup: s_memtime begin/end, s_memrealtime begin/end
-#endif
-#ifdef MPPI_MLP2_TRACE
-// s_memtime after the k pairs listed in kMlp2TraceKp, in one steady-state half-step of workgroup 0 (4 waves)
-constexpr int kMlp2TraceKp[] = {0, 4, 5, 6, 8, 9, 10, 28, 29, 32, 33, 34, 36, 37, 38, 44, 45, 46, 47, 48, 49, 50, 51, 66, 68, 69, 70, 100, 128};
-constexpr int kMlp2TraceN = sizeof(kMlp2TraceKp) / sizeof(int);
-__device__ unsigned long long g_mlp2_trace[4 * 32];
-__host__ __device__ constexpr int mlp2_trace_slot(int kp)
-{
-    for (int i = 0; i < kMlp2TraceN; ++i)
-        if (kMlp2TraceKp[i] == kp) return i;
-    return -1;
-}
-#endif
+// (MPPI_MLP2_STAMP_AT / MPPI_MLP2_TRACE_*: the timing-study layer, mppi_ablate.hip.h — nothing in the shipped build)
 
 constexpr int kMlp2Threads = 256;
 constexpr int kMlp2R = 64; // rollouts per workgroup: two sets of 32
@@ -435,9 +421,7 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
         float bq[4]; // B operands of k pairs kp .. kp+3 (ring): h1[2 kp + hh][j]
 #pragma unroll
         for (int i = 0; i < 3; ++i) bq[i] = smem[b_rd0 + (Q * kHid + 2 * i) * R];
-#ifdef MPPI_MLP2_TRACE
-        unsigned long long tr[kMlp2TraceN];
-#endif
+        MPPI_MLP2_TRACE_DECL();
         static_for<0, NKP>([&](auto kpc) {
             constexpr int kp = decltype(kpc)::value;
             const float b = bq[kp % 4];
@@ -483,17 +467,10 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
                     if (gn < NG) noise_groups(gn);
                 }
             }
-#ifdef MPPI_MLP2_TRACE
-            if constexpr (Q == 0 && mlp2_trace_slot(kp) >= 0) tr[mlp2_trace_slot(kp)] = __builtin_amdgcn_s_memtime();
-#endif
+            MPPI_MLP2_TRACE_AT(Q, kp);
             __builtin_amdgcn_sched_barrier(0);
         });
-#ifdef MPPI_MLP2_TRACE
-        if constexpr (Q == 0 && decltype(finc)::value && decltype(prepc)::value) {
-            if (t_prep == 10 && tile_is_first && blockIdx.x == 0 && lane == 0)
-                for (int i = 0; i < kMlp2TraceN; ++i) g_mlp2_trace[w * 32 + i] = tr[i];
-        }
-#endif
+        if constexpr (Q == 0 && decltype(finc)::value && decltype(prepc)::value) MPPI_MLP2_TRACE_FLUSH(t_prep == 10 && tile_is_first && blockIdx.x == 0 && lane == 0);
     };
 
     // The stationary weights (258 global loads per lane, plus W1 / W3 / U staged in LDS) are this workgroup's for its
@@ -507,12 +484,7 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
     // ---- prologue: noise of group 0 of both sets; step 0 of set 0 up to its image
     if constexpr (SRC == SRC_PHILOX) noise_groups(0);
     __syncthreads();
-#ifdef MPPI_MLP2_STAMP
-    if (tid == 0 && blockIdx.x < 4096 && tile_is_first) {
-        g_mlp2_stamp[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
-        g_mlp2_stamp[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
+    MPPI_MLP2_STAMP_AT(0);
     {
         integral_constant<int, 0> c0;
         StepRegs g;
@@ -538,13 +510,7 @@ __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
         }
         half_step(s1, yes, no, H);
     }
-#ifdef MPPI_MLP2_STAMP
-    if (tid == 0 && blockIdx.x < 4096 && tile_is_first) {
-        g_mlp2_stamp[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
-        g_mlp2_stamp[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
-    }
-    tile_is_first = false;
-#endif
+    MPPI_MLP2_STAMP_AT(1);
     // ---- epilogue: set 1's last step
     {
         integral_constant<int, 1> c1;
