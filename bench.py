@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--horizon", type=int, default=None, help="H (default 64; 32 for pm1d)")
     ap.add_argument("--samples", type=int, default=None, help="rollouts PER GPU (default 65536; 4096 for pm2d, 128 for pm1d)")
     ap.add_argument("--min-time", type=float, default=1.0, help="repeat the K-step batch until this many seconds are timed (headline only)")
+    ap.add_argument("--bf16x3", action="store_true", help="the split-bf16 matrix-core variant of a learned-model workload (MPPI_FLAG_MLP_BF16X3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true")
     return ap.parse_args()
@@ -247,8 +248,7 @@ def work_per_state_step(workload):
     a, net = WORKLOADS[workload]
     s = 13 if workload in GEN else 2 * a
     flop = 6 * s + 5 * a + 3
-    if workload == "auv":
-        flop = 2 * 330 + 40 + 5 * a + 3  # two state_dot evaluations (rk2) of the Fossen model + quaternion normalisation + costs
+    # (the 13-state family's lane-per-rollout kernels are priced from their COUNTED instruction stream, roofline_of: no FLOP estimate)
     if net:
         hid, n_hidden = net
         n_in, n_out = {"nnauv": (16, s), "nnspeed": (15, 6)}.get(workload, (s + a, s))
@@ -312,18 +312,34 @@ def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20):
     return float(np.median(ts)), float(ts[int(0.95 * (len(ts) - 1))])
 
 
-def measured(name):
-    """profiles/<name>_latest.json (written by tools/summarize_profiles.py from rocprofv3 --pmc passes), or None when it
-    is absent or was taken on other kernel sources than the ones this run executes."""
+_kernel_profiles = None
+
+
+def measured(kernel):
+    """What rocprofv3's counters say about `kernel` (profiles/kernels_latest.json, written by tools/summarize_profiles.py from
+    separate --pmc passes of this bench): {"valu": instructions per launch by class x issue cycles, "mfma": matrix-pipe busy
+    fraction, "traffic": HBM bytes per launch, "stats": rocprofv3 --kernel-trace --stats average}, or (None, why) when the file
+    is absent, holds nothing for this kernel, or was taken on other kernel sources than the ones this run executes."""
+    global _kernel_profiles
     import mppi_tf_amd as m
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", name + "_latest.json")))
-    except Exception:
-        return None, "no profiles/%s_latest.json" % name
+    if _kernel_profiles is None:
+        try:
+            _kernel_profiles = json.load(open(os.path.join(ROOT, "profiles", "kernels_latest.json")))
+        except Exception:
+            _kernel_profiles = {}
+    d = _kernel_profiles.get("kernels", {}).get(kernel)
+    if d is None:
+        return None, "profiles/kernels_latest.json holds nothing for %s" % kernel
     sha = m.build.source_sha()
     if d.get("code_sha") != sha:
-        return None, "profiles/%s_latest.json is of sources %s, this run executes %s" % (name, d.get("code_sha"), sha)
+        return None, "profiles/kernels_latest.json has %s of sources %s, this run executes %s" % (kernel, d.get("code_sha"), sha)
     return d, None
+
+
+def valu_floor(v):
+    """(floor_us, SIMD-cycles the launch's vector instructions need, peak G SIMD-cycle/s) from a `valu` profile record"""
+    cyc = sum(v["insts_per_launch"][c] * v["cycles_per_inst"][c] for c in v["insts_per_launch"])
+    return cyc / (v["simds"] * v["clock_mhz"]), cyc, v["simds"] * v["clock_mhz"] * 1e-3
 
 
 class Runner:
@@ -445,52 +461,44 @@ def r4(v):
 
 def roofline_of(r):
     """The bound each kernel is actually on: `mfma` for the learned 2x256 / Dense(32) models (exact-fp32
-    matrix cores; the split-bf16 variant against the bf16 peak), `valu_issue` for the analytic models — their noise never
-    leaves the chip, so HBM is idle (`traffic`); `algorithmic_hbm_frac` keeps SURVEY §8d's materialised-noise figure."""
+    matrix cores; the split-bf16 variants against the bf16 peak), `valu_issue` for the lane-per-rollout kernels (the analytic
+    point mass — its noise never leaves the chip, so HBM is idle (`traffic`) — the Fossen AUVModel, NNAUVModelSpeed, the small
+    networks on the vector ALU). `frac` of a valu_issue kernel = floor / kernel time, floor = the launch's COUNTED vector
+    instructions by class (rocprofv3 SQ_INSTS_VALU_*) x the issue cycles per instruction of the class measured on this part
+    (profiles/r02_valu_issue.json) / (1024 SIMDs x 2.4 GHz) — no hand-estimated FLOP count.
+    `algorithmic_hbm_frac` keeps SURVEY §8d's materialised-noise figure for the BASELINE point-mass configurations."""
     kus = 1e3 * r["kernel_ms_avg"]
     base = {"kernel": r["kernel"].replace("mppi::", ""), "kernel_us": r4(kus), "finish_kernel_us": r4(1e3 * r["finish_kernel_ms_avg"]),
             "launches_timed": r["launches_timed"]}
-    if "k_rollout_gen" in r["kernel"]:  # lane-per-rollout kernels of the 13-state family: packed-fp32 vector issue is their ceiling
-        flop = r["algorithmic_flop_per_launch"]
-        tf = flop / (kus * 1e-6) / 1e12 if kus > 0 else 0.0
-        # the Fossen model is op-by-op fp32 (-ffp-contract=off, bit-identical to the CPU restatement): no fma, so v_pk_mul/v_pk_add
-        # (2 operations per lane and cycle) is its ceiling, half of v_pk_fma_f32's; the learned NNAUVModel may fuse
-        peak = VALU_F32_PEAK_TFLOPS / 2 if "gen<0" in r["kernel"] else VALU_F32_PEAK_TFLOPS
-        base.update({"bound": "valu_issue", "achieved": r4(tf), "peak": r4(peak), "unit": "TFLOP/s", "frac": r4(tf / peak),
-                     "traffic": None, "algorithmic_flop_per_launch": flop})
-        return base
-    if r["mlp"] is not None:
+    prof, why = measured(r["kernel"])
+    prof = prof or {}
+    traffic = (prof.get("traffic") or {}).get("hbm_bytes_per_launch")
+    valu_bound = r["mlp"] is None or "k_rollout_gen" in r["kernel"] or "mlp_small" in r["kernel"]
+    if not valu_bound:
         flop = r["algorithmic_flop_per_launch"]
         bx3 = "bx3" in r["kernel"]
-        small_valu = "mlp_small" in r["kernel"]
         tf = (3 if bx3 else 1) * flop / (kus * 1e-6) / 1e12 if kus > 0 else 0.0
-        peak = MFMA_BF16_PEAK_TFLOPS if bx3 else (VALU_F32_PEAK_TFLOPS if small_valu else MFMA_F32_PEAK_TFLOPS)
-        mf, why = measured("mfma")
-        ok = mf is not None and mf.get("kernel") == r["kernel"]
-        base.update({"bound": "valu_issue" if small_valu else "mfma", "achieved": r4(tf), "peak": peak, "unit": "TFLOP/s", "frac": r4(tf / peak),
-                     "traffic": mf.get("hbm_bytes_per_launch") if ok else None, "mfma_busy_frac": r4(mf.get("mfma_busy_frac")) if ok else None,
-                     "algorithmic_flop_per_launch": flop})
+        peak = MFMA_BF16_PEAK_TFLOPS if bx3 else MFMA_F32_PEAK_TFLOPS
+        mf = prof.get("mfma") or {}
+        base.update({"bound": "mfma", "achieved": r4(tf), "peak": peak, "unit": "TFLOP/s", "frac": r4(tf / peak), "traffic": traffic,
+                     "mfma_busy_frac": r4(mf.get("mfma_busy_frac")), "vector_insts_per_mfma": r4(mf.get("other_vector_insts_per_mfma")),
+                     "algorithmic_flop_per_launch": flop, "profiles": prof.get("tag")})
         if bx3:
             base["algorithmic_TFLOP_per_s"] = r4(tf / 3)
         return base
-    alg = r["algorithmic_bytes_per_launch"]
-    alg_gbs = alg / (kus * 1e-6) / 1e9 if kus > 0 else 0.0
-    tr, why_t = measured("traffic")
-    traffic = tr.get("hbm_bytes_per_launch") if tr and tr.get("kernel") == r["kernel"] else None
-    d, why_v = measured("valu")
-    base.update({"bound": "valu_issue", "unit": "G SIMD-cycle/s", "traffic": traffic,
-                 "algorithmic_bytes_per_launch": alg, "algorithmic_hbm_frac": r4(alg_gbs / HBM_PEAK_GBS)})
-    if d is None or d.get("kernel") != r["kernel"]:
-        base.update({"achieved": None, "peak": None, "frac": None,
-                     "pmc_note": why_v or "profiles/valu_latest.json describes %s" % d.get("kernel")})
+    base.update({"bound": "valu_issue", "unit": "G SIMD-cycle/s", "traffic": traffic})
+    if r["mlp"] is None and "k_rollout_gen" not in r["kernel"]:  # the BASELINE point-mass configurations: SURVEY §8d's byte model beside it
+        alg = r["algorithmic_bytes_per_launch"]
+        base.update({"algorithmic_bytes_per_launch": alg, "algorithmic_hbm_frac": r4(alg / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS) if kus > 0 else None})
+    v = prof.get("valu")
+    if v is None:
+        base.update({"achieved": None, "peak": None, "frac": None, "pmc_note": why or "no VALU-class counters for this kernel"})
         return base
-    cyc = sum(d["insts_per_launch"][c] * d["cycles_per_inst"][c] for c in d["insts_per_launch"])  # SIMD-cycles the launch's vector instructions need
-    peak = d["simds"] * d["clock_mhz"] * 1e-3                                                        # G SIMD-cycles per second the chip offers
-    floor_us = cyc / (d["simds"] * d["clock_mhz"])
-    busy = d.get("active_quad_cycles_per_launch")
+    floor_us, cyc, peak = valu_floor(v)
+    busy = v.get("active_quad_cycles_per_launch")
     base.update({"achieved": r4(cyc / (kus * 1e-6) / 1e9) if kus > 0 else None, "peak": r4(peak), "frac": r4(floor_us / kus) if kus > 0 else None,
-                 "floor_us": r4(floor_us), "valu_busy_us": r4(busy * 4.0 / d["simds"] / d["clock_mhz"]) if busy else None,
-                 "valu_insts_per_launch": int(sum(d["insts_per_launch"].values())), "profiles": d.get("tag")})
+                 "floor_us": r4(floor_us), "valu_busy_us": r4(busy * 4.0 / v["simds"] / v["clock_mhz"]) if busy else None,
+                 "valu_insts_per_launch": int(sum(v["insts_per_launch"].values())), "profiles": prof.get("tag")})
     try:  # what an EMPTY kernel of this launch shape reads between the same two timestamps (tools/micro/dispatch_overhead.hip): fixed cost of a dispatch
         fixed = json.load(open(os.path.join(ROOT, "profiles", "dispatch_latest.json")))["empty_kernel_event_us"]
         if kus > fixed:
@@ -560,7 +568,7 @@ def main():
     K = args.samples or {"pm1d": 128, "pm2d": 4096}.get(headline, 65536)
     steps = args.steps if args.steps is not None else (20 if is_mlp else 200)
     rn = Runner(args, dev, world, rank, local_rank)
-    r = rn.run(headline, K, H, steps, args.warmup if not is_mlp else min(args.warmup, 3), args.min_time)
+    r = rn.run(headline, K, H, steps, args.warmup if not is_mlp else min(args.warmup, 3), args.min_time, **(dict(mlp_bf16x3=True) if args.bf16x3 else {}))
 
     subs = []
     if args.workload is None and not args.no_subrecords:

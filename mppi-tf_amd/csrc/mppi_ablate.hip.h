@@ -2,6 +2,7 @@
 // The shipped library defines NONE of the symbols below: every macro then expands to the plain code and the kernels read without
 // a single #if. The study builds (mppi-tf_amd/build.py build_variant, driven by tools/ablate.py and tools/timeline.py) define one of
 //   MPPI_ABLATE_PHILOX    a cheap arithmetic stand-in for Philox + Box-Muller
+//   MPPI_PHILOX_BLOCK_MAJOR  the Philox blocks of a horizon group one after the other (r03's order; same numbers, A/B timing of r04's round-major order)
 //   MPPI_ABLATE_ROLLOUT   one recurrence step instead of H
 //   MPPI_ABLATE_WSUM      no weighted-noise sum / transposing butterfly
 //   MPPI_FINISH_STAGE=n   k_finish_cols stops after stage n (0 entry, 1 record loads, 2 the min over the records)
@@ -16,6 +17,9 @@
     _Pragma("unroll") for (int j_ = 0; j_ < (n); ++j_) (z)[j_] = (float)((int)(((gk) * 2654435761ull + (grp) * 40503ull + j_) & 1023) - 512) * (1.0f / 512.0f)
 #define MPPI_NORMALS_GROUP(A, seed, gk, grp, z) MPPI_ABL_STANDIN_(z, 4 * (A), gk, grp)
 #define MPPI_NORMALS_GROUP_UB(A, seed, gk, grp, z) MPPI_ABL_STANDIN_(z, 4 * (A), gk, grp)
+#elif defined(MPPI_PHILOX_BLOCK_MAJOR) // A/B: the Philox blocks of a group one after the other (r03) instead of round-major (r04)
+#define MPPI_NORMALS_GROUP(A, seed, gk, grp, z) normals_group<A>(seed, gk, grp, z)
+#define MPPI_NORMALS_GROUP_UB(A, seed, gk, grp, z) normals_group_ub_block_major<A>(seed, gk, grp, z)
 #else
 #define MPPI_NORMALS_GROUP(A, seed, gk, grp, z) normals_group<A>(seed, gk, grp, z)
 #define MPPI_NORMALS_GROUP_UB(A, seed, gk, grp, z) normals_group_ub<A>(seed, gk, grp, z)

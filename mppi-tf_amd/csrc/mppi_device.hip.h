@@ -289,6 +289,18 @@ __device__ __forceinline__ float4 normals_of_block(unsigned long long seed, unsi
 #endif
 }
 
+// (A/B timing only, tools/ablate.py philox_block_major: r03's order — one block's ten rounds after the other)
+template <int A>
+__device__ __forceinline__ void normals_group_ub_block_major(unsigned long long seed, unsigned int gk_lo, unsigned long long group_index_uniform, float (&z)[4 * A])
+{
+#pragma unroll
+    for (int q = 0; q < A; ++q) {
+        const uint4 r = philox4x32_10_block_ub(seed, gk_lo, group_index_uniform * A + q);
+        const float2 n0 = box_muller_hw(r.x, r.y), n1 = box_muller_hw(r.z, r.w);
+        z[4 * q + 0] = n0.x; z[4 * q + 1] = n0.y; z[4 * q + 2] = n1.x; z[4 * q + 3] = n1.y;
+    }
+}
+
 // normals_group for a wave-uniform group index and a sample index below 2^32 (the rollout kernels' case)
 template <int A>
 __device__ __forceinline__ void normals_group_ub(unsigned long long seed, unsigned int gk_lo, unsigned long long group_index_uniform,

@@ -10,6 +10,7 @@ from mppi_tf_amd import build
 
 VARIANTS = {
     "full": [],
+    "philox_block_major": ["MPPI_PHILOX_BLOCK_MAJOR"],  # r03's Philox order against r04's round-major one (same results)
     "no_philox": ["MPPI_ABLATE_PHILOX"],
     "no_rollout": ["MPPI_ABLATE_ROLLOUT"],
     "no_wsum": ["MPPI_ABLATE_WSUM"],

@@ -1,30 +1,43 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun) from the repo root: collects the rocprofv3 evidence for bench.py —
-# kernel-trace stats, and PMC counters in SEPARATE passes (never combined with sys/hip traces):
-# SQ occupancy/issue counters, then FETCH_SIZE, then WRITE_SIZE. Results land in gpurun_out/profiles_<tag>/;
-# tools/summarize_profiles.py turns them into the files committed under profiles/.
+# Run ON THE GPU BOX (via gpurun) from the repo root: collects the rocprofv3 evidence behind bench.py's roofline fields, for every
+# kernel the bench line quotes —
+#   tools/collect_profiles.sh TAG WORKLOAD[:bx3] [WORKLOAD[:bx3] ...]        e.g.  r04 pm3d mlp mlp:bx3 mlp32 mlp32:bx3 nnauv nnauv:bx3 auv nnspeed
+# per workload: --kernel-trace --stats, then PMC counters in SEPARATE passes (never combined with sys/hip/marker traces): the VALU
+# instruction classes, the busy cycles of the issue ports, the matrix pipe, GRBM_GUI_ACTIVE, and (point mass / 2x256 MLP) FETCH_SIZE and
+# WRITE_SIZE. Results land in gpurun_out/profiles_<tag>/<workload>/; tools/summarize_profiles.py turns them into the files under profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r04}
+shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 rm -rf $OUT   # never mix passes of different runs (gpurun merges gpurun_out/ back over what is already there: clear the local copy too)
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-WORKLOAD=${2:-pm3d}
-STEPS=200; [ "$WORKLOAD" = "mlp" ] && STEPS=10
-BENCH="python3 $R/bench.py --workload $WORKLOAD --steps $STEPS --warmup 3 --no-cpu-baseline --no-subrecords --min-time 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1
-# VALU instructions by class (for the issue-rate floor, roofline.valu) and the busy cycles of the issue ports: own passes
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- $BENCH > $OUT/pmc_sq2.log 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC --kernel-trace --output-format csv -d $OUT/pmc_sq3 -- $BENCH > $OUT/pmc_sq3.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_grbm -- $BENCH > $OUT/pmc_grbm.log 2>&1
-if [ "$WORKLOAD" = "mlp" ]; then  # matrix-core occupancy of the MLP kernels (own pass; a refused counter only loses this pass)
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $OUT/pmc_mfma -- $BENCH > $OUT/pmc_mfma.log 2>&1
-fi
+for SPEC in "$@"; do
+  WL=${SPEC%%:*}
+  EXTRA=""; [ "$SPEC" != "$WL" ] && EXTRA="--bf16x3"
+  NAME=${SPEC/:/_}
+  D=$OUT/$NAME
+  mkdir -p $D
+  STEPS=100
+  case $WL in mlp) STEPS=10;; mlp32|nnauv|auv|nnspeed) STEPS=30;; esac
+  BENCH="python3 $R/bench.py --workload $WL $EXTRA --steps $STEPS --warmup 3 --no-cpu-baseline --no-subrecords --min-time 0"
+  echo "== $NAME: $BENCH"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- $BENCH > $D/stats.log 2>&1
+  # VALU instructions by class (the issue-rate floor) and the busy cycles of the issue ports: own passes
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --kernel-trace --output-format csv -d $D/pmc_sq2 -- $BENCH > $D/pmc_sq2.log 2>&1
+  rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC --kernel-trace --output-format csv -d $D/pmc_sq3 -- $BENCH > $D/pmc_sq3.log 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVES --kernel-trace --output-format csv -d $D/pmc_sq -- $BENCH > $D/pmc_sq.log 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $D/pmc_grbm -- $BENCH > $D/pmc_grbm.log 2>&1
+  case $WL in pm3d|pm2d|pm1d|auv|nnspeed) ;; *)  # matrix-core occupancy of the learned-model kernels (a refused counter only loses this pass)
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --kernel-trace --output-format csv -d $D/pmc_mfma -- $BENCH > $D/pmc_mfma.log 2>&1;;
+  esac
+  case $WL in pm3d|mlp)
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/pmc_fetch -- $BENCH > $D/pmc_fetch.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/pmc_write -- $BENCH > $D/pmc_write.log 2>&1;;
+  esac
+  grep -h '"metric"' $D/*.log | head -1 > $D/bench_under_profiler.json
+done
 cd $R
-grep -h '"metric"' $OUT/*.log | head -1 > $OUT/bench_under_profiler.json
-ls -R $OUT | head -40
+ls $OUT
