@@ -286,7 +286,7 @@ def cpu_baseline(workload, H, K, mlp, budget_s=12.0):
             "sample": "%d whole control steps (Philox noise + rollouts + update) of the same workload at K=%d H=%d, OpenMP over samples" % (n, Kc, H)}
 
 
-def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20):
+def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20, **handle_kw):
     """Host-synchronous closed loop: mppi_next(x)->u with the plant stepped on the host (the shape of the reference's
     loop, main.cpp:37-43). Median / p95 ms per control step."""
     import numpy as np
@@ -294,7 +294,7 @@ def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20):
     cfg = cfg_of(workload, H)
     gen = workload in GEN  # 13-state family: the state is held at the task's x0 (no host plant for the Fossen model here)
     x = np.asarray(cfg.pop("x0"), np.float32) if gen else np.zeros(2 * a, np.float32)
-    h = m.Handle(k=K, **model_kw_of(workload, mlp), **cfg)
+    h = m.Handle(k=K, **model_kw_of(workload, mlp), **cfg, **handle_kw)
     if mlp is not None or gen:
         steps, warmup = 20, 3
     dt, ts = 0.1, []
@@ -620,7 +620,7 @@ def main():
                 out["sub_records"][0]["exchange"] = subs[0]["exchange"]
                 out["sub_records"][0]["rank_ms_per_step"] = [r4(q) for q in subs[0]["rank_ms_per_step"]]
         if world == 1:
-            med, p95 = sync_latency(m, headline, H, K, r["mlp"])
+            med, p95 = sync_latency(m, headline, H, K, r["mlp"], **(dict(mlp_bf16x3=True) if args.bf16x3 else {}))
             out["ms_per_control_step_sync"] = {"median": r4(med), "p95": r4(p95)}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(headline, H, K, r["mlp"])

@@ -1200,7 +1200,8 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
         h->nb_mlp = h->mlp_v2 ? (h->K_local + kMlp2R - 1) / kMlp2R : (h->K_local + kMlpR - 1) / kMlpR; // d_part is sized for the larger count
         break;
     case MPPI_TUNE_MLP32_VALU:
-        if (h->mlp_small != 32 || h->mlp_bx3) return fail(h, MPPI_ERR_INVALID_ARG, "not an exact-fp32 Dense(32) MLP handle");
+        if (!(h->mlp_small == 32 || (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED && h->mlp_small == 16)) || h->mlp_bx3)
+            return fail(h, MPPI_ERR_INVALID_ARG, "not an exact-fp32 Dense(32) MLP handle (or an NNAUVModelSpeed one)");
         h->mlp32_valu = value != 0; break;
     case MPPI_TUNE_P2P_FAULT:
         if (value < 0 || value > 2) return fail(h, MPPI_ERR_INVALID_ARG, "fault: 0 none, 1 export, 2 probe");

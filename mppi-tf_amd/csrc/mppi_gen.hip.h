@@ -473,11 +473,13 @@ __device__ __forceinline__ void euler_from_quat(const float (&q)[4], float (&e)[
         return;
     }
     const float th_y = -asinf(r20);
-    const float sc = nonzero_sign(cosf(th_y));
+    // sign_cos_theta_y of the published algorithm = sign(cos(th_y)): outside the gimbal-lock branch |r20| <= 1 - 1e-6, so
+    // |th_y| <= pi/2 - 1.4e-3 and cos(th_y) >= 1.4e-3 — the sign is +1 for every input that reaches this line, and the products
+    // with it are exact. The cosf it replaces was 117 of this function's 324 vector instructions (full-range argument reduction).
     r00 = nonzero_sign(r00) * eps + r00;
     r22 = nonzero_sign(r22) * eps + r22;
-    e[2] = atan2f(r10 * sc, r00 * sc);
-    e[0] = atan2f(r21 * sc, r22 * sc);
+    e[2] = atan2f(r10, r00);
+    e[0] = atan2f(r21, r22);
     e[1] = th_y;
 }
 
@@ -790,6 +792,172 @@ __global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnauv32(
             mfma32_hidden_64_80(acc1, acc0, ah[0], bht[0]);
             if (n_hidden >= 3) {
                 mfma32_hidden_80_64(acc0, acc1, ah[1], bht[1]);
+                finish(acc0, ac);
+            } else {
+                finish(acc1, ac);
+            }
+        } else {
+            finish(acc0, ac);
+        }
+    }
+    c = c + gen_state_cost(C, G, x); // terminal cost, controller_base.cpp:271-272
+    // lane l of BOTH waves now stands for rollout k0 + l of the tile
+    if (hh == 0) cost_s[32 * w + j] = c;
+    __syncthreads();
+    const float ct = cost_s[lane];
+    const bool valid = (k0 + lane) < K;
+    const int kt = valid ? k0 + lane : K - 1;
+    if (w == 0 && valid) cost[k0 + lane] = ct;
+    if (MODE == MODE_COST_ONLY) return;
+    mlp_tile_record<A, DIAG, 2>(C, ct, valid, w, lane, kt, H, NG, SRC, eps_hbm, seed, (unsigned long long)C->k_offset + (unsigned long long)kt,
+                                base, partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc);
+}
+
+// k_rollout_nnspeed32<HID>: NNAUVModelSpeed (nn_model.py:307-588) with its Dense(HID, relu) x 1..3 + Dense(6) network on the matrix cores,
+// exact fp32 (r04). On k_rollout_gen<2, HID> the 848 weights of a step come through the scalar cache and, at one wave
+// per SIMD, every s_load wait is exposed; its counters read 738 `other` vector instructions per wave-step (moves and lane reads of spilled
+// scalars) beside 860 of arithmetic. Here, as in k_rollout_nnauv32: the weights are stationary A operands, a layer is one asm statement of
+// v_mfma_f32_32x32x2_f32 (mppi_mfma32.hip.h), the accumulators of one layer are the B operands of the next. What this model adds:
+//   * 15 inputs = (3 Euler angles of the attitude, 6 body velocities, 6 forces), padded to 8 k pairs (input 15 has zero weights);
+//   * HID = 16 (the reference's shape, nn_model.py:340-346) fills half of the 32-row tile: units 0..15 are accumulator registers 0..7 of
+//     the two lane halves, a hidden layer is 8 k pairs (mfma32_hidden8_*), the tile's other rows carry zero weights and biases;
+//   * the 6 outputs (the velocity delta) on the vector ALU from the accumulators (W3 rows padded to 8 in LDS, lane halves combined with
+//     v_permlane32_swap), then next_state: the pose integrated with the class's own quaternion kinematics, quaternion renormalised;
+//   * euler_from_quat (asinf, two atan2f) per step and rollout on the vector ALU.
+// One wave = 32 rollouts (both lane halves carry rollout j's state), a workgroup = 2 waves = one 64-rollout tile record.
+template <int HID, bool DIAG>
+__global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnspeed32(
+    const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
+    const float *__restrict__ U_dev, const float *__restrict__ eps_hbm, const unsigned long long *__restrict__ step_ctr,
+    float *__restrict__ cost, float *__restrict__ partials, const int SRC, const int MODE, const int rsb, const int rsc)
+{
+    static_assert(HID == 16 || HID == 32, "Dense(16) or Dense(32) hidden layers");
+    constexpr int S = kGenS, A = kGenA, NIN = kGenSpeedNin, NOUT = 6, K1H = 8, NP = HID / 2, W3LD = 8;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float w3_s[HID * W3LD];   // output-layer rows [unit][6 outputs + 2 zeros]
+    __shared__ float z_s[2][4 * A][32];                                // per wave: the normals of one horizon group
+    __shared__ float cost_s[64];
+    const int H = C->H, HA = H * A, K = C->K_local;
+    const int NG = (H + 3) / 4;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 31, hh = lane >> 5;
+    const int k0 = blockIdx.x * 64;
+    const int kk = min(k0 + 32 * w + j, K - 1); // rollouts past K recompute the last sample, outside every sum
+    const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
+    const unsigned long long seed = C->seed;
+    const unsigned int gk = (unsigned int)C->k_offset + (unsigned int)kk;
+    const int n_hidden = M->n_layers - 1;
+    auto unit_of = [](int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); };
+    const bool row_live = j < HID; // lane (j, hh) supplies row j of the A operand: output unit j of the layer
+
+    // ---- stationary operands
+    float a1[K1H];
+#pragma unroll
+    for (int s1 = 0; s1 < K1H; ++s1) a1[s1] = (row_live && 2 * s1 + hh < NIN) ? M->Wl[0][(2 * s1 + hh) * HID + j] : 0.0f;
+    f32x16 b1t, bht[2];
+    float ah[2][NP];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b1t[r] = unit_of(r, hh) < HID ? M->bl[0][unit_of(r, hh)] : 0.0f;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const bool have = l + 2 <= n_hidden; // hidden-to-hidden layer l exists
+        const float *Wl = have ? M->Wl[l + 1] : M->Wl[0], *bl = have ? M->bl[l + 1] : M->bl[0];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) ah[l][s] = (have && row_live) ? Wl[unit_of(s, hh) * HID + j] : 0.0f; // k pair s = input units u(s, 0), u(s, 1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bht[l][r] = (have && unit_of(r, hh) < HID) ? bl[unit_of(r, hh)] : 0.0f;
+    }
+    const float *W3g = M->Wl[n_hidden], *b3g = M->bl[n_hidden];
+    const int ld3 = M->ld[n_hidden];
+    for (int i = tid; i < HID * W3LD; i += kNnauv32Threads) w3_s[i] = (i & 7) < NOUT ? W3g[(i >> 3) * ld3 + (i & 7)] : 0.0f;
+    float xm[NIN + 1], xr[NIN + 1], b3v[NOUT], ysd[NOUT], ymn[NOUT];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) { xm[i] = M->xmean[i]; xr[i] = 1.0f / M->xstd[i]; }
+    xm[NIN] = 0.0f; xr[NIN] = 0.0f; // the padding input of the eighth k pair
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) { b3v[i] = b3g[i]; ysd[i] = M->ystd[i]; ymn[i] = M->ymean[i]; }
+    const float dt = C->dt;
+    float x[S], c = 0.0f;
+#pragma unroll
+    for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+    __syncthreads();
+
+    // output layer + next_state (nn_model.py:463-472) + step cost, from the (relu'd) accumulators of the last hidden layer
+    auto finish = [&](const f32x16 &hacc, float ac) {
+        f32x2 py[NOUT / 2];
+#pragma unroll
+        for (int r = 0; r < NP; ++r) { // the lane half's units u(r, hh)
+            const float *wp = w3_s + (8 * (r >> 2) + 4 * hh + (r & 3)) * W3LD;
+            const f32x4 t0 = *static_cast<const f32x4 *>(__builtin_assume_aligned(wp, 16));
+            const f32x4 t1 = *static_cast<const f32x4 *>(__builtin_assume_aligned(wp + 4, 16));
+            const f32x2 h2 = {hacc[r], hacc[r]};
+            const f32x2 w01 = {t0.x, t0.y}, w23 = {t0.z, t0.w}, w45 = {t1.x, t1.y};
+            py[0] = r == 0 ? h2 * w01 : __builtin_elementwise_fma(h2, w01, py[0]);
+            py[1] = r == 0 ? h2 * w23 : __builtin_elementwise_fma(h2, w23, py[1]);
+            py[2] = r == 0 ? h2 * w45 : __builtin_elementwise_fma(h2, w45, py[2]);
+        }
+        float delta[NOUT];
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) { // the other half's units: lower + upper, in every lane
+            float a = (n & 1) ? py[n / 2].y : py[n / 2].x, b = a;
+            permlane32_swap(a, b); // a = the lower half's partial in all lanes, b = the upper half's
+            const float y = (a + b) + b3v[n];
+            delta[n] = y * ysd[n] + ymn[n];
+        }
+        nnauv_speed_next_state(dt, x, delta);
+        const float sc = gen_state_cost(C, G, x); // cost on the POST-step state
+        const float tmp = sc + ac;
+        c = c + tmp;
+    };
+
+    for (int t = 0; t < H; ++t) {
+        if (SRC == SRC_PHILOX && (t & 3) == 0) { // this wave's normals of the group: block q by the half with q & 1 == hh
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < A; ++q) {
+                if ((q & 1) == hh) {
+                    const float4 n = normals_of_block(seed, (unsigned long long)gk, (base + (unsigned long long)(t >> 2)) * A + q);
+                    z_s[w][4 * q + 0][j] = n.x; z_s[w][4 * q + 1][j] = n.y; z_s[w][4 * q + 2][j] = n.z; z_s[w][4 * q + 3][j] = n.w;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): one wave's LDS accesses complete in order
+            __builtin_amdgcn_wave_barrier();
+        }
+        float u[A], e[A], v[A];
+        if (SRC == SRC_PHILOX) {
+            float z1[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) z1[i] = z_s[w][(t & 3) * A + i][j];
+            scale_noise<A, DIAG>(C, z1, e);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
+        }
+#pragma unroll
+        for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
+        const float ac = action_cost<A, DIAG>(C, u, e);
+        // inputs (prepare_data, nn_model.py:438-461): Euler angles of the attitude, body velocities, forces; input 15 is the zero padding
+        const float q4[4] = {x[3], x[4], x[5], x[6]};
+        float eu[3];
+        euler_from_quat(q4, eu);
+        float in[NIN + 1];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) in[i] = eu[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { in[3 + i] = x[7 + i]; in[9 + i] = v[i]; }
+        in[NIN] = 0.0f;
+        float bv[K1H]; // the B operand of lane (j, hh), k pair s1, is input 2 s1 + hh of rollout j
+#pragma unroll
+        for (int s1 = 0; s1 < K1H; ++s1) bv[s1] = hh ? (in[2 * s1 + 1] - xm[2 * s1 + 1]) * xr[2 * s1 + 1] : (in[2 * s1] - xm[2 * s1]) * xr[2 * s1];
+        f32x16 acc0;
+        mfma32_layer1<K1H>(acc0, a1, bv, b1t);
+        if (n_hidden >= 2) {
+            f32x16 acc1;
+            if constexpr (HID == 16) mfma32_hidden8_64_80(acc1, acc0, ah[0], bht[0]);
+            else mfma32_hidden_64_80(acc1, acc0, ah[0], bht[0]);
+            if (n_hidden >= 3) {
+                if constexpr (HID == 16) mfma32_hidden8_80_64(acc0, acc1, ah[1], bht[1]);
+                else mfma32_hidden_80_64(acc0, acc1, ah[1], bht[1]);
                 finish(acc0, ac);
             } else {
                 finish(acc1, ac);

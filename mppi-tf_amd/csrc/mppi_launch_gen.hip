@@ -181,6 +181,13 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
         }
         return hipGetLastError();
     }
+    // NNAUVModelSpeed: the matrix-core kernel for rollouts and cost-only passes (r04); the other modes and MPPI_TUNE_MLP32_VALU stay
+    // on the lane-per-rollout kernel
+    if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED && !h->mlp32_valu && (mode == MODE_ROLLOUT || mode == MODE_COST_ONLY) && noise_out == nullptr) {
+        if (h->mlp_small == 16) { if (h->sigma_diag) MPPI_NNAUV32_L((k_rollout_nnspeed32<16, true>)); else MPPI_NNAUV32_L((k_rollout_nnspeed32<16, false>)); }
+        else { if (h->sigma_diag) MPPI_NNAUV32_L((k_rollout_nnspeed32<32, true>)); else MPPI_NNAUV32_L((k_rollout_nnspeed32<32, false>)); }
+        return hipGetLastError();
+    }
 #undef MPPI_NNAUV32_L
     if (h->hc.model_kind == MPPI_MODEL_AUV) MPPI_GEN_L(GEN_MODEL_AUV, 32);
     else if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED) {
@@ -196,9 +203,13 @@ const char *mppi_gen_kernel_name(const mppi_handle *h)
 {
     const bool d = h->sigma_diag != 0; // the last template argument: exactly diagonal Sigma (as the profiler spells the instance)
     if (h->hc.model_kind == MPPI_MODEL_AUV) return d ? "mppi::k_rollout_gen<0, 32, true>" : "mppi::k_rollout_gen<0, 32, false>";
-    if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED)
+    if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED) {
+        if (!h->mlp32_valu)
+            return h->mlp_small == 16 ? (d ? "mppi::k_rollout_nnspeed32<16, true>" : "mppi::k_rollout_nnspeed32<16, false>")
+                                      : (d ? "mppi::k_rollout_nnspeed32<32, true>" : "mppi::k_rollout_nnspeed32<32, false>");
         return h->mlp_small == 16 ? (d ? "mppi::k_rollout_gen<2, 16, true>" : "mppi::k_rollout_gen<2, 16, false>")
                                   : (d ? "mppi::k_rollout_gen<2, 32, true>" : "mppi::k_rollout_gen<2, 32, false>");
+    }
     if (h->mlp_small == 32 && !h->mlp32_valu)
         return h->mlp_bx3 ? (d ? "mppi::k_rollout_nnauv32_bx3<true>" : "mppi::k_rollout_nnauv32_bx3<false>")
                           : (d ? "mppi::k_rollout_nnauv32<true>" : "mppi::k_rollout_nnauv32<false>");

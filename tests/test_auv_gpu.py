@@ -197,20 +197,24 @@ def test_nnauv_speed_single_step_and_data_preparation(m, hid, n_hidden):
         m.Handle(k=64, tau=4, s_dim=13, a_dim=6, sigma=np.eye(6), goal=np.zeros(13), nnauv_speed=bad)
 
 
-@pytest.mark.parametrize("hid,n_hidden", [(16, 3), (32, 2)])
+@pytest.mark.parametrize("hid,n_hidden,valu", [(16, 3, False), (32, 2, False), (16, 1, False), (32, 3, False), (16, 3, True), (32, 2, True)],
+                         ids=["16x3-mfma", "32x2-mfma", "16x1-mfma", "32x3-mfma", "16x3-valu", "32x2-valu"])
 @pytest.mark.parametrize("cost", ["quadratic", "quat"])
-def test_nnauv_speed_control_step_against_oracle(m, hid, n_hidden, cost):
-    """NNAUVModelSpeed in the full path (k_rollout_gen<2, hid>): costs as close to fp64 as an fp32 CPU evaluation is (4x), U' at 1e-5 on
-    unit noise; the fused Philox step on its own exported noise; 4-way sharding; ControllerBase(model=NNAUVModelSpeed, ...)."""
+def test_nnauv_speed_control_step_against_oracle(m, hid, n_hidden, valu, cost):
+    """NNAUVModelSpeed in the full path — on the matrix cores (k_rollout_nnspeed32<hid>, r04: the Dense stack as v_mfma_f32_32x32x2_f32
+    layers, Euler angles and quaternion kinematics on the vector ALU) and, with MPPI_TUNE_MLP32_VALU, on the lane-per-rollout kernel
+    (k_rollout_gen<2, hid>): costs as close to fp64 as an fp32 CPU evaluation is (4x), U' at 1e-5 on unit noise; the fused Philox step on
+    its own exported noise; 4-way sharding; ControllerBase(model=NNAUVModelSpeed, ...)."""
     import torch
     K, H = 2048, 10
     mlp = make_nnauv_speed(7, hid, n_hidden)
     sigma = 0.25 * np.eye(6)
     goal_q = GOAL13[:3] + [0.0, 0.0, np.sin(0.5), np.cos(0.5)] + [0.0] * 6
     ck = dict(goal=GOAL13, Q=np.array([10.0] * 3 + [5.0] * 4 + [1.0] * 6)) if cost == "quadratic" else dict(goal=goal_q, Q=Q10 / 10, quat_cost=True)
-    cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv_speed=mlp, seed=9, **ck)
+    cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv_speed=mlp, seed=9, tuning={"mlp32_valu": 1} if valu else None, **ck)
     h = m.Handle(**cfg)
-    assert h.rollout_kernel_name() == "mppi::k_rollout_gen<2, %d, true>" % hid  # (true: the diagonal-Sigma instance)
+    kernel = ("mppi::k_rollout_gen<2, %d, true>" if valu else "mppi::k_rollout_nnspeed32<%d, true>") % hid  # (true: the diagonal-Sigma instance)
+    assert h.rollout_kernel_name() == kernel
     mk = lambda dt: orc.Problem(tau=H, s=13, a=6, dt=0.1, lam=1.0, sigma=sigma, nnauv_speed=mlp, threads=0, dtype=dt, **ck)
     p32, p64 = mk(F32), mk(np.float64)
     rng = np.random.default_rng(1)
@@ -256,7 +260,7 @@ def test_nnauv_speed_control_step_against_oracle(m, hid, n_hidden, cost):
         nn.set_Ymean_Ystd(mlp["ymean"], mlp["ystd"])
         ctl = m.ControllerBase(model=nn, cost=m.StaticQuatCost(1.0, 1.0, 1.0, sigma, np.array(goal_q)[:, None], Q10 / 10), k=K, tau=H, sDim=13, aDim=6,
                                lam=1.0, sigma=sigma, seed=9)
-        assert ctl._h.rollout_kernel_name() == "mppi::k_rollout_gen<2, %d, true>" % hid
+        assert ctl._h.rollout_kernel_name() == "mppi::k_rollout_nnspeed32<%d, true>" % hid
         assert np.isfinite(ctl.next(x0[:, None])).all()
 
 
@@ -765,7 +769,7 @@ def test_full_size_learned_13_state_models(m, kind):
     cfg, ok, x0 = full_size_cfg(kind)
     h = m.Handle(k=FULL_K, **cfg)
     name = h.rollout_kernel_name()
-    assert name.startswith({"mfma": "mppi::k_rollout_nnauv32<true>", "bf16x3": "mppi::k_rollout_nnauv32_bx3<true>", "speed": "mppi::k_rollout_"}[kind]), name
+    assert name.startswith({"mfma": "mppi::k_rollout_nnauv32<true>", "bf16x3": "mppi::k_rollout_nnauv32_bx3<true>", "speed": "mppi::k_rollout_nnspeed32<16, true>"}[kind]), name
     p32, p64 = orc.Problem(threads=0, **ok), orc.Problem(threads=0, dtype=np.float64, **ok)
     U_in = (100.0 * np.random.default_rng(1).standard_normal((FULL_H, 6))).astype(F32)
     h.set_action_sequence(U_in)
