@@ -979,6 +979,247 @@ __global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnspeed32(
                                 base, partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc);
 }
 
+// k_rollout_nnspeed_pc<HID>: NNAUVModelSpeed as a two-wave pipeline per 64-rollout tile (r04). In k_rollout_nnspeed32 a wave is 32
+// rollouts whose per-rollout vector work — Euler angles, quaternion kinematics, the 13-term cost, the noise: ~650 instructions a step —
+// runs on 64 lanes for 32 results, and the f32 MFMA does not overlap with it. The model itself offers the split: next_state integrates
+// the POSE from the OLD velocities (nn_model.py:463-472), only the velocities take the network's output. So per tile
+//   wave N (network): lane = rollout. Noise, v = u + eps, action cost; inputs (Euler angles from P, its velocities, v), the Dense stack as
+//       TWO column blocks of 32 rollouts per weight register (mfma32x2_*: one v_permlane32_swap of the lane's (even, odd) inputs yields
+//       the B operands of both blocks), the 6 outputs, vel' = vel + delta;
+//   wave P (pose):    lane = rollout. cost of the state the previous step produced, pose' = normalize(pose + J(q) vel dt), Euler(q');
+// exchange through double-buffered LDS — P -> N: 3 Euler angles; N -> P: 6 velocities + the action cost — one workgroup barrier per step:
+// N(t) and P(t) both depend on step t-1 only and run side by side. Every per-rollout instruction now serves 64 rollouts.
+// A workgroup is TWO tiles (4 waves, one per SIMD); the role comes from the SIMD a wave runs on, flipped for every second workgroup of a
+// CU, so that each SIMD hosts one N and one P wave (as k_rollout_pc places its consumer; falls back to the wave index).
+// Same arithmetic per rollout as k_rollout_nnspeed32 (the output layer's half sums in the same order): same bars.
+constexpr int kNnspeedPcThreads = 256;
+struct GenQuadConsts { // kernel-local copy of the diagonal quadratic cost (no constant re-fetch behind the per-step barrier)
+    float goal[kGenS], qdiag[kGenS];
+};
+
+template <int HID, bool DIAG>
+__global__ __launch_bounds__(kNnspeedPcThreads) void k_rollout_nnspeed_pc(
+    const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const MlpDev *__restrict__ M, const float *__restrict__ x_dev,
+    const float *__restrict__ U_dev, const float *__restrict__ eps_hbm, const unsigned long long *__restrict__ step_ctr,
+    float *__restrict__ cost, float *__restrict__ partials, const int SRC, const int MODE, const int rsb, const int rsc, const int n_tiles,
+    const int balance)
+{
+    static_assert(HID == 16 || HID == 32, "Dense(16) or Dense(32) hidden layers");
+    constexpr int S = kGenS, A = kGenA, NIN = kGenSpeedNin, NOUT = 6, K1H = 8, NP = HID / 2, W3LD = 8;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float w3_s[HID * W3LD]; // output-layer rows [unit][6 outputs + 2 zeros]
+    __shared__ float eu_s[2][2][3][64];   // [tile of the workgroup][step parity][angle][rollout]            P -> N
+    __shared__ float vel_s[2][2][7][64];  // [tile][step parity][6 velocities of the NEXT state, action cost][rollout]   N -> P
+    __shared__ float cost_s[2][64];
+    __shared__ int simd_s[4];
+    const int H = C->H, HA = H * A, K = C->K_local;
+    const int NG = (H + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- which tile, which role
+    int pair = wave_hw >> 1, role = wave_hw & 1; // role 0 = network, 1 = pose
+    {
+        const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); // HW_REG_HW_ID[5:4]
+        if (lane == 0) simd_s[wave_hw] = simd;
+        __syncthreads();
+        const int s0 = simd_s[0], s1 = simd_s[1], s2 = simd_s[2], s3 = simd_s[3];
+        if (balance && ((1 << s0) | (1 << s1) | (1 << s2) | (1 << s3)) == 15) {
+            const int gen = (int)(blockIdx.x >> 8); // arrival order on the CU (256 CUs)
+            pair = simd & 1;
+            role = ((simd >> 1) ^ gen) & 1;
+        }
+        pair = __builtin_amdgcn_readfirstlane(pair);
+        role = __builtin_amdgcn_readfirstlane(role);
+    }
+    const int tile = 2 * (int)blockIdx.x + pair;
+    const bool tile_ok = tile < n_tiles; // the second tile of the last workgroup may not exist: its waves still keep every barrier
+    const int k0 = tile * 64;
+    const bool valid = tile_ok && (k0 + lane) < K;
+    const int kk = min(k0 + lane, K - 1); // rollouts past K recompute the last sample, outside every sum
+    const int n_hidden = M->n_layers - 1;
+    const float *W3g = M->Wl[n_hidden];
+    const int ld3 = M->ld[n_hidden];
+    for (int i = tid; i < HID * W3LD; i += kNnspeedPcThreads) w3_s[i] = (i & 7) < NOUT ? W3g[(i >> 3) * ld3 + (i & 7)] : 0.0f;
+    float c = 0.0f;
+
+    if (role == 0) {
+        // ================================================================================= wave N: noise, network, velocities
+        const int j = lane & 31, hh = lane >> 5;
+        const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
+        const unsigned long long seed = C->seed;
+        const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)kk;
+        auto unit_of = [](int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); };
+        const bool row_live = j < HID; // lane (j, hh) supplies row j of the A operand: output unit j of the layer
+        float a1[K1H];
+#pragma unroll
+        for (int s1 = 0; s1 < K1H; ++s1) a1[s1] = (row_live && 2 * s1 + hh < NIN) ? M->Wl[0][(2 * s1 + hh) * HID + j] : 0.0f;
+        f32x16 b1t, bht[2];
+        float ah[2][NP];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b1t[r] = unit_of(r, hh) < HID ? M->bl[0][unit_of(r, hh)] : 0.0f;
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const bool have = l + 2 <= n_hidden;
+            const float *Wl = have ? M->Wl[l + 1] : M->Wl[0], *bl = have ? M->bl[l + 1] : M->bl[0];
+#pragma unroll
+            for (int s1 = 0; s1 < NP; ++s1) ah[l][s1] = (have && row_live) ? Wl[unit_of(s1, hh) * HID + j] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bht[l][r] = (have && unit_of(r, hh) < HID) ? bl[unit_of(r, hh)] : 0.0f;
+        }
+        const float *b3g = M->bl[n_hidden];
+        float xm[NIN + 1], xr[NIN + 1], b3v[NOUT], ysd[NOUT], ymn[NOUT];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) { xm[i] = M->xmean[i]; xr[i] = 1.0f / M->xstd[i]; }
+        xm[NIN] = 0.0f; xr[NIN] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) { b3v[i] = b3g[i]; ysd[i] = M->ystd[i]; ymn[i] = M->ymean[i]; }
+        PcProducerConsts<A> pcst; // Sigma, Sigma^-1, lambda: a kernel-local copy (no re-fetch behind the barriers)
+        pcst.template load<DIAG>(C);
+        float vel[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vel[i] = x_dev[7 + i];
+        __syncthreads(); // w3_s
+        __syncthreads(); // the Euler angles of x0
+
+        // output layer of both column blocks + vel' = vel + delta
+        auto finish = [&](const f32x16 &hA, const f32x16 &hB) {
+            f32x2 pA[NOUT / 2], pB[NOUT / 2];
+#pragma unroll
+            for (int r = 0; r < NP; ++r) { // the lane half's units u(r, hh)
+                const float *wp = w3_s + (8 * (r >> 2) + 4 * hh + (r & 3)) * W3LD;
+                const f32x4 t0 = *static_cast<const f32x4 *>(__builtin_assume_aligned(wp, 16));
+                const f32x4 t1 = *static_cast<const f32x4 *>(__builtin_assume_aligned(wp + 4, 16));
+                const f32x2 w01 = {t0.x, t0.y}, w23 = {t0.z, t0.w}, w45 = {t1.x, t1.y};
+                const f32x2 a2 = {hA[r], hA[r]}, b2 = {hB[r], hB[r]};
+                pA[0] = r == 0 ? a2 * w01 : __builtin_elementwise_fma(a2, w01, pA[0]);
+                pA[1] = r == 0 ? a2 * w23 : __builtin_elementwise_fma(a2, w23, pA[1]);
+                pA[2] = r == 0 ? a2 * w45 : __builtin_elementwise_fma(a2, w45, pA[2]);
+                pB[0] = r == 0 ? b2 * w01 : __builtin_elementwise_fma(b2, w01, pB[0]);
+                pB[1] = r == 0 ? b2 * w23 : __builtin_elementwise_fma(b2, w23, pB[1]);
+                pB[2] = r == 0 ? b2 * w45 : __builtin_elementwise_fma(b2, w45, pB[2]);
+            }
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) {
+                float lo = (n & 1) ? pA[n / 2].y : pA[n / 2].x, up = (n & 1) ? pB[n / 2].y : pB[n / 2].x;
+                permlane32_swap(lo, up); // lane l: lo = the lower half's partial of ITS rollout, up = the upper half's
+                const float y = (lo + up) + b3v[n];
+                vel[n] = vel[n] + (y * ysd[n] + ymn[n]);
+            }
+        };
+
+        for (int g = 0; g < NG; ++g) {
+            float z[4 * A];
+            if (SRC == SRC_PHILOX) normals_group<A>(seed, gk, base + (unsigned long long)g, z);
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                const int t = 4 * g + tl;
+                if (t < H) { // (wave-uniform)
+                    float u[A], e[A], v[A];
+                    if (SRC == SRC_PHILOX) {
+                        float z1[A];
+#pragma unroll
+                        for (int i = 0; i < A; ++i) z1[i] = z[tl * A + i];
+                        scale_noise<A, DIAG>(&pcst, z1, e);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
+                    const float ac = action_cost<A, DIAG>(&pcst, u, e);
+                    // inputs (prepare_data, nn_model.py:438-461): Euler angles (from P), body velocities, forces; input 15 = zero padding
+                    float in[NIN + 1];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) in[i] = eu_s[pair][t & 1][i][lane];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { in[3 + i] = vel[i]; in[9 + i] = v[i]; }
+                    in[NIN] = 0.0f;
+                    float ba[K1H], bb[K1H];
+#pragma unroll
+                    for (int s1 = 0; s1 < K1H; ++s1) {
+                        float ev = (in[2 * s1] - xm[2 * s1]) * xr[2 * s1], od = (in[2 * s1 + 1] - xm[2 * s1 + 1]) * xr[2 * s1 + 1];
+                        permlane32_swap(ev, od); // ev: (even, odd) input of rollouts 0..31 in the lane halves; od: of rollouts 32..63
+                        ba[s1] = ev; bb[s1] = od;
+                    }
+                    f32x16 accA, accB;
+                    mfma32x2_layer1_8<NP>(accA, accB, a1, ba, bb, b1t);
+                    if (n_hidden >= 2) {
+                        f32x16 hA, hB;
+                        if constexpr (HID == 16) mfma32x2_hidden8_lo_hi(hA, hB, accA, accB, ah[0], bht[0]);
+                        else mfma32x2_hidden_lo_hi(hA, hB, accA, accB, ah[0], bht[0]);
+                        if (n_hidden >= 3) {
+                            if constexpr (HID == 16) mfma32x2_hidden8_hi_lo(accA, accB, hA, hB, ah[1], bht[1]);
+                            else mfma32x2_hidden_hi_lo(accA, accB, hA, hB, ah[1], bht[1]);
+                            finish(accA, accB);
+                        } else {
+                            finish(hA, hB);
+                        }
+                    } else {
+                        finish(accA, accB);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) vel_s[pair][t & 1][i][lane] = vel[i];
+                    vel_s[pair][t & 1][6][lane] = ac;
+                    __syncthreads(); // step t handed over
+                }
+            }
+        }
+    } else {
+        // ================================================================================= wave P: cost, pose, Euler angles
+        GenQuadConsts qc;
+        const bool quad_diag = C->state_cost_kind == MPPI_STATE_COST_QUADRATIC && !C->q_full;
+#pragma unroll
+        for (int i = 0; i < S; ++i) { qc.goal[i] = C->goal[i]; qc.qdiag[i] = C->qdiag[i]; }
+        const float dt = C->dt;
+        float x[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+        auto cost_of = [&](const float (&xs)[S]) { return quad_diag ? state_cost<S, false>(&qc, xs) : gen_state_cost(C, G, xs); };
+        {
+            const float q4[4] = {x[3], x[4], x[5], x[6]};
+            float eu[3];
+            euler_from_quat(q4, eu);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) eu_s[pair][0][i][lane] = eu[i];
+        }
+        __syncthreads(); // w3_s
+        __syncthreads(); // the Euler angles of x0
+        const float zero6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int t = 0; t < H; ++t) {
+            if (t >= 1) { // the state step t-1 produced: its pose is here, its velocities and the step's action cost come from N
+#pragma unroll
+                for (int i = 0; i < 6; ++i) x[7 + i] = vel_s[pair][(t - 1) & 1][i][lane];
+                const float ac = vel_s[pair][(t - 1) & 1][6][lane];
+                const float sc = cost_of(x); // cost on the POST-step state
+                const float tmp = sc + ac;   // Step_cost_result cost_base.cpp:49
+                c = c + tmp;                 // path_cost        controller_base.cpp:268
+            }
+            nnauv_speed_next_state(dt, x, zero6); // the pose from the OLD velocities (nn_model.py:463-472); x[7..12] + 0 is exact
+            if (t + 1 < H) {
+                const float q4[4] = {x[3], x[4], x[5], x[6]};
+                float eu[3];
+                euler_from_quat(q4, eu);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) eu_s[pair][(t + 1) & 1][i][lane] = eu[i];
+            }
+            __syncthreads(); // step t handed over
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[7 + i] = vel_s[pair][(H - 1) & 1][i][lane];
+        const float sc = cost_of(x);
+        c = c + (sc + vel_s[pair][(H - 1) & 1][6][lane]);
+        c = c + sc; // terminal cost: x_H counted a second time, controller_base.cpp:271-272
+        cost_s[pair][lane] = c;
+        if (valid) cost[k0 + lane] = c;
+    }
+    __syncthreads();
+    if (MODE == MODE_COST_ONLY || !tile_ok) return;
+    const float ct = cost_s[pair][lane];
+    mlp_tile_record<A, DIAG, 2>(C, ct, valid, role, lane, kk, H, NG, SRC, eps_hbm, C->seed, (unsigned long long)C->k_offset + (unsigned long long)kk,
+                                step_ctr[0] * (unsigned long long)NG, partials + (size_t)record_slot(tile, rsc) * rsb, rsc);
+}
+
 // k_rollout_nnauv32_bx3: the same NNAUVModel network on the BF16 matrix cores at fp32-class accuracy (opt-in MPPI_FLAG_MLP_BF16X3), the
 // design of k_rollout_mlp32_bx3 (mppi_mlp32b.hip.h): every operand split x = hi + lo (two bf16), three products per term, a 32-wide
 // layer = 6 v_mfma_f32_32x32x16_bf16, registers 8 kb .. 8 kb + 7 of a lane (relu'd, split) are the next layer's B fragment of k-block

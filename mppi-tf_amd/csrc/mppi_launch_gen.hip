@@ -183,9 +183,21 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
     }
     // NNAUVModelSpeed: the matrix-core kernel for rollouts and cost-only passes (r04); the other modes and MPPI_TUNE_MLP32_VALU stay
     // on the lane-per-rollout kernel
-    if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED && !h->mlp32_valu && (mode == MODE_ROLLOUT || mode == MODE_COST_ONLY) && noise_out == nullptr) {
-        if (h->mlp_small == 16) { if (h->sigma_diag) MPPI_NNAUV32_L((k_rollout_nnspeed32<16, true>)); else MPPI_NNAUV32_L((k_rollout_nnspeed32<16, false>)); }
-        else { if (h->sigma_diag) MPPI_NNAUV32_L((k_rollout_nnspeed32<32, true>)); else MPPI_NNAUV32_L((k_rollout_nnspeed32<32, false>)); }
+    if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED && h->mlp32_valu != 1 && (mode == MODE_ROLLOUT || mode == MODE_COST_ONLY) && noise_out == nullptr) {
+        if (h->mlp32_valu == 2) { // MPPI_TUNE_MLP32_VALU = 2: the one-wave-per-32-rollouts matrix-core kernel (A/B timing)
+            if (h->mlp_small == 16) { if (h->sigma_diag) MPPI_NNAUV32_L((k_rollout_nnspeed32<16, true>)); else MPPI_NNAUV32_L((k_rollout_nnspeed32<16, false>)); }
+            else { if (h->sigma_diag) MPPI_NNAUV32_L((k_rollout_nnspeed32<32, true>)); else MPPI_NNAUV32_L((k_rollout_nnspeed32<32, false>)); }
+            return hipGetLastError();
+        }
+        // default: the two-wave pipeline (network wave + pose wave per tile, two tiles per workgroup)
+        const int wgs = (h->nb + 1) / 2;
+        const int balance = wgs <= 2 * h->n_cu ? 1 : 0; // SIMD-true roles only while the whole grid is resident in one round
+#define MPPI_NNSPEED_PC_L(KERN)                                                                                                    \
+    hipExtLaunchKernelGGL(KERN, dim3(wgs), dim3(kNnspeedPcThreads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG, \
+                          (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp, h->nb, balance)
+        if (h->mlp_small == 16) { if (h->sigma_diag) MPPI_NNSPEED_PC_L((k_rollout_nnspeed_pc<16, true>)); else MPPI_NNSPEED_PC_L((k_rollout_nnspeed_pc<16, false>)); }
+        else { if (h->sigma_diag) MPPI_NNSPEED_PC_L((k_rollout_nnspeed_pc<32, true>)); else MPPI_NNSPEED_PC_L((k_rollout_nnspeed_pc<32, false>)); }
+#undef MPPI_NNSPEED_PC_L
         return hipGetLastError();
     }
 #undef MPPI_NNAUV32_L
@@ -204,7 +216,10 @@ const char *mppi_gen_kernel_name(const mppi_handle *h)
     const bool d = h->sigma_diag != 0; // the last template argument: exactly diagonal Sigma (as the profiler spells the instance)
     if (h->hc.model_kind == MPPI_MODEL_AUV) return d ? "mppi::k_rollout_gen<0, 32, true>" : "mppi::k_rollout_gen<0, 32, false>";
     if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED) {
-        if (!h->mlp32_valu)
+        if (h->mlp32_valu == 0)
+            return h->mlp_small == 16 ? (d ? "mppi::k_rollout_nnspeed_pc<16, true>" : "mppi::k_rollout_nnspeed_pc<16, false>")
+                                      : (d ? "mppi::k_rollout_nnspeed_pc<32, true>" : "mppi::k_rollout_nnspeed_pc<32, false>");
+        if (h->mlp32_valu == 2)
             return h->mlp_small == 16 ? (d ? "mppi::k_rollout_nnspeed32<16, true>" : "mppi::k_rollout_nnspeed32<16, false>")
                                       : (d ? "mppi::k_rollout_nnspeed32<32, true>" : "mppi::k_rollout_nnspeed32<32, false>");
         return h->mlp_small == 16 ? (d ? "mppi::k_rollout_gen<2, 16, true>" : "mppi::k_rollout_gen<2, 16, false>")

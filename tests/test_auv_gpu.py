@@ -197,24 +197,27 @@ def test_nnauv_speed_single_step_and_data_preparation(m, hid, n_hidden):
         m.Handle(k=64, tau=4, s_dim=13, a_dim=6, sigma=np.eye(6), goal=np.zeros(13), nnauv_speed=bad)
 
 
-@pytest.mark.parametrize("hid,n_hidden,valu", [(16, 3, False), (32, 2, False), (16, 1, False), (32, 3, False), (16, 3, True), (32, 2, True)],
-                         ids=["16x3-mfma", "32x2-mfma", "16x1-mfma", "32x3-mfma", "16x3-valu", "32x2-valu"])
+SPEED_KERNELS = {0: "mppi::k_rollout_nnspeed_pc<%d, true>", 1: "mppi::k_rollout_gen<2, %d, true>", 2: "mppi::k_rollout_nnspeed32<%d, true>"}  # (true: the diagonal-Sigma instance)
+
+
+@pytest.mark.parametrize("hid,n_hidden,valu", [(16, 3, 0), (32, 2, 0), (16, 1, 0), (32, 3, 0), (16, 2, 0), (16, 3, 2), (32, 2, 2), (16, 1, 2), (32, 3, 2), (16, 3, 1), (32, 2, 1)],
+                         ids=["16x3-pc", "32x2-pc", "16x1-pc", "32x3-pc", "16x2-pc", "16x3-mfma32", "32x2-mfma32", "16x1-mfma32", "32x3-mfma32", "16x3-valu", "32x2-valu"])
 @pytest.mark.parametrize("cost", ["quadratic", "quat"])
 def test_nnauv_speed_control_step_against_oracle(m, hid, n_hidden, valu, cost):
-    """NNAUVModelSpeed in the full path — on the matrix cores (k_rollout_nnspeed32<hid>, r04: the Dense stack as v_mfma_f32_32x32x2_f32
-    layers, Euler angles and quaternion kinematics on the vector ALU) and, with MPPI_TUNE_MLP32_VALU, on the lane-per-rollout kernel
-    (k_rollout_gen<2, hid>): costs as close to fp64 as an fp32 CPU evaluation is (4x), U' at 1e-5 on unit noise; the fused Philox step on
-    its own exported noise; 4-way sharding; ControllerBase(model=NNAUVModelSpeed, ...)."""
+    """NNAUVModelSpeed in the full path — on the matrix cores as a two-wave pipeline per tile (k_rollout_nnspeed_pc<hid>, r04: a network
+    wave runs the Dense stack as v_mfma_f32_32x32x2_f32 layers on two column blocks, a pose wave the cost, the quaternion kinematics and
+    the Euler angles), on the one-wave-per-32-rollouts matrix-core kernel (k_rollout_nnspeed32<hid>, MPPI_TUNE_MLP32_VALU = 2) and on the
+    lane-per-rollout kernel (k_rollout_gen<2, hid>, = 1): costs as close to fp64 as an fp32 CPU evaluation is (4x), U' at 1e-5 on unit
+    noise; the fused Philox step on its own exported noise; 4-way sharding; ControllerBase(model=NNAUVModelSpeed, ...)."""
     import torch
     K, H = 2048, 10
     mlp = make_nnauv_speed(7, hid, n_hidden)
     sigma = 0.25 * np.eye(6)
     goal_q = GOAL13[:3] + [0.0, 0.0, np.sin(0.5), np.cos(0.5)] + [0.0] * 6
     ck = dict(goal=GOAL13, Q=np.array([10.0] * 3 + [5.0] * 4 + [1.0] * 6)) if cost == "quadratic" else dict(goal=goal_q, Q=Q10 / 10, quat_cost=True)
-    cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv_speed=mlp, seed=9, tuning={"mlp32_valu": 1} if valu else None, **ck)
+    cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv_speed=mlp, seed=9, tuning={"mlp32_valu": valu} if valu else None, **ck)
     h = m.Handle(**cfg)
-    kernel = ("mppi::k_rollout_gen<2, %d, true>" if valu else "mppi::k_rollout_nnspeed32<%d, true>") % hid  # (true: the diagonal-Sigma instance)
-    assert h.rollout_kernel_name() == kernel
+    assert h.rollout_kernel_name() == SPEED_KERNELS[valu] % hid
     mk = lambda dt: orc.Problem(tau=H, s=13, a=6, dt=0.1, lam=1.0, sigma=sigma, nnauv_speed=mlp, threads=0, dtype=dt, **ck)
     p32, p64 = mk(F32), mk(np.float64)
     rng = np.random.default_rng(1)
@@ -260,7 +263,7 @@ def test_nnauv_speed_control_step_against_oracle(m, hid, n_hidden, valu, cost):
         nn.set_Ymean_Ystd(mlp["ymean"], mlp["ystd"])
         ctl = m.ControllerBase(model=nn, cost=m.StaticQuatCost(1.0, 1.0, 1.0, sigma, np.array(goal_q)[:, None], Q10 / 10), k=K, tau=H, sDim=13, aDim=6,
                                lam=1.0, sigma=sigma, seed=9)
-        assert ctl._h.rollout_kernel_name() == "mppi::k_rollout_nnspeed32<%d, true>" % hid
+        assert ctl._h.rollout_kernel_name() == SPEED_KERNELS[0] % hid
         assert np.isfinite(ctl.next(x0[:, None])).all()
 
 
@@ -592,7 +595,7 @@ def test_python_entry_point_learns_the_plant_online():
     assert np.isfinite(float(re.search(r"goal_p\| = ([0-9.]+) m", r.stdout).group(1)))
 
 
-@pytest.mark.parametrize("kind,K,H", [("bf16x3", 300, 7), ("bf16x3", 65, 5), ("speed", 300, 7), ("speed", 1, 3), ("mfma", 65, 5)])
+@pytest.mark.parametrize("kind,K,H", [("bf16x3", 300, 7), ("bf16x3", 65, 5), ("speed", 300, 7), ("speed", 1, 3), ("speed", 129, 6), ("speed", 64, 1), ("mfma", 65, 5)])
 def test_learned_13_state_kernels_with_ragged_tiles(m, kind, K, H):
     """K that is no multiple of the 64-rollout tile (partial last tile, a single rollout) and a horizon that is no multiple of the 4-step
     Philox group, for the learned 13-state kernels: k_rollout_nnauv32(_bx3) and NNAUVModelSpeed's k_rollout_gen<2, .> — the fused step
@@ -769,7 +772,7 @@ def test_full_size_learned_13_state_models(m, kind):
     cfg, ok, x0 = full_size_cfg(kind)
     h = m.Handle(k=FULL_K, **cfg)
     name = h.rollout_kernel_name()
-    assert name.startswith({"mfma": "mppi::k_rollout_nnauv32<true>", "bf16x3": "mppi::k_rollout_nnauv32_bx3<true>", "speed": "mppi::k_rollout_nnspeed32<16, true>"}[kind]), name
+    assert name.startswith({"mfma": "mppi::k_rollout_nnauv32<true>", "bf16x3": "mppi::k_rollout_nnauv32_bx3<true>", "speed": "mppi::k_rollout_nnspeed_pc<16, true>"}[kind]), name
     p32, p64 = orc.Problem(threads=0, **ok), orc.Problem(threads=0, dtype=np.float64, **ok)
     U_in = (100.0 * np.random.default_rng(1).standard_normal((FULL_H, 6))).astype(F32)
     h.set_action_sequence(U_in)

@@ -39,6 +39,58 @@ def hidden(src, dst, pairs=16):
             % (body, dst, dst + 15, ins, src, src + 15))
 
 
+def relu2(ba, bb, n):
+    """relu of the first n accumulator registers of two column blocks (a 16-wide layer's units live in registers 0..7)"""
+    return "s_nop 15\\n\\ts_nop 1\\n\\t" + "\\n\\t".join("v_max_f32 v%d, 0, v%d" % (b + i, b + i) for b in (ba, bb) for i in range(n))
+
+
+def layer1_x2(k1h, n):
+    """layer 1 of TWO column blocks (rollouts 0..31 and 32..63 of the wave) with one set of weights: accA = v[64:79], accB = v[96:111]"""
+    ops = []
+    for s in range(k1h):
+        ca = "%[bias]" if s == 0 else "v[64:79]"
+        cb = "%[bias]" if s == 0 else "v[96:111]"
+        ops.append("s_nop 1\\n\\tv_mfma_f32_32x32x2_f32 v[64:79], %%[a%d], %%[p%d], %s\\n\\tv_mfma_f32_32x32x2_f32 v[96:111], %%[a%d], %%[q%d], %s" % (s, s, ca, s, s, cb))
+    body = "\\n\\t".join(ops) + "\\n\\t" + relu2(64, 96, n)
+    ins = ", ".join('[a%d] "v"(a[%d]), [p%d] "v"(ba[%d]), [q%d] "v"(bb[%d])' % (s, s, s, s, s, s) for s in range(k1h))
+    return ('    if constexpr (NR == %d) {\n        asm volatile("%s"\n                     : "=&{v[64:79]}"(accA), "=&{v[96:111]}"(accB)\n                     : %s, [bias] "v"(bias));\n    }'
+            % (n, body, ins))
+
+
+def hidden_x2(sa, da, sb, db, pairs):
+    n = pairs  # a 16-wide layer (8 pairs): 8 live registers; a 32-wide one: 16
+    ops = []
+    for s in range(pairs):
+        ca = "%[bias]" if s == 0 else "v[%d:%d]" % (da, da + 15)
+        cb = "%[bias]" if s == 0 else "v[%d:%d]" % (db, db + 15)
+        ops.append("s_nop 1\\n\\tv_mfma_f32_32x32x2_f32 v[%d:%d], %%[a%d], v%d, %s\\n\\tv_mfma_f32_32x32x2_f32 v[%d:%d], %%[a%d], v%d, %s"
+                   % (da, da + 15, s, sa + s, ca, db, db + 15, s, sb + s, cb))
+    body = "\\n\\t".join(ops) + "\\n\\t" + relu2(da, db, n)
+    ins = ", ".join('[a%d] "v"(a[%d])' % (s, s) for s in range(pairs))
+    return ('    asm volatile("%s"\n                 : "=&{v[%d:%d]}"(outA), "=&{v[%d:%d]}"(outB)\n                 : %s, [bias] "v"(bias), "{v[%d:%d]}"(inA), "{v[%d:%d]}"(inB));'
+            % (body, da, da + 15, db, db + 15, ins, sa, sa + 15, sb, sb + 15))
+
+
+def hidden_x2_fn(name, sa, da, sb, db, pairs):
+    return ('__device__ __forceinline__ void %s(f32x16_l &outA, f32x16_l &outB, const f32x16_l &inA, const f32x16_l &inB, const float (&a)[%d], const f32x16_l &bias)\n{\n%s\n}\n'
+            % (name, pairs, hidden_x2(sa, da, sb, db, pairs)))
+
+
+X2 = '''
+// ---- two column blocks per wave (k_rollout_nnspeed_pc: lane l = rollout l, 64 rollouts per wave): every weight register feeds two
+// MFMAs, block A (rollouts 0..31) on v[64:79] / v[80:95], block B (rollouts 32..63) on v[96:111] / v[112:127]; the B operands of a
+// k pair come from ONE v_permlane32_swap of the lane's (even, odd) inputs. NR = the accumulator registers that carry live units
+// (16: a 32-wide layer; 8: a 16-wide one, whose units 0..15 are registers 0..7 of the two lane halves).
+template <int NR>
+__device__ __forceinline__ void mfma32x2_layer1_8(f32x16_l &accA, f32x16_l &accB, const float (&a)[8], const float (&ba)[8], const float (&bb)[8], const f32x16_l &bias)
+{
+    static_assert(NR == 8 || NR == 16, "live accumulator registers");
+''' + layer1_x2(8, 8) + "\n" + layer1_x2(8, 16) + '''
+}
+
+''' + hidden_x2_fn("mfma32x2_hidden_lo_hi", 64, 80, 96, 112, 16) + "\n" + hidden_x2_fn("mfma32x2_hidden_hi_lo", 80, 64, 112, 96, 16) + "\n" \
+    + hidden_x2_fn("mfma32x2_hidden8_lo_hi", 64, 80, 96, 112, 8) + "\n" + hidden_x2_fn("mfma32x2_hidden8_hi_lo", 80, 64, 112, 96, 8)
+
 text = '''// mppi_mfma32.hip.h — GENERATED by tools/gen_mfma32_layers.py (edit the generator, not this file).
 // A 32-wide Dense(relu) layer on the matrix cores as ONE inline-asm statement on fixed physical registers: every
 // v_mfma_f32_32x32x2_f32 of the layer (s_nop 1 in front: its B operand may just have been written by a vector instruction), the
@@ -85,7 +137,7 @@ __device__ __forceinline__ void mfma32_hidden8_80_64(f32x16_l &out, const f32x16
 {
 ''' + hidden(80, 64, 8) + '''
 }
-
+''' + X2 + '''
 } // namespace mppi
 '''
 open(OUT, "w").write(text)
