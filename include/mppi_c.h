@@ -361,7 +361,8 @@ enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instea
         * its step with tf.profiler.experimental.start/stop, controller_base.py:241-248, 587-595). libroctx64.so is dlopen'ed on first use —
         * the library has no link dependency on it; the call fails with MPPI_ERR_UNSUPPORTED when it cannot be found. Shows in
         * `rocprofv3 --marker-trace`. */
-       MPPI_TUNE_TRACE = 8 };
+       MPPI_TUNE_TRACE = 8,
+       MPPI_TUNE_GEN_ONE_WAVE = 9 };    /* 1: the Fossen AUVModel on k_rollout_gen<0> (one wave per 64-rollout tile) instead of k_rollout_auv_pc (pose wave + velocity wave per tile) */
 mppi_status mppi_set_tuning(mppi_handle *h, int what, int value);
 
 /* ---- measurement (the reference only has a commented-out chrono loop, main.cpp:55-64) ------ */

@@ -1207,6 +1207,9 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
     case MPPI_TUNE_P2P_FAULT:
         if (value < 0 || value > 2) return fail(h, MPPI_ERR_INVALID_ARG, "fault: 0 none, 1 export, 2 probe");
         h->p2p_fault = value; break;
+    case MPPI_TUNE_GEN_ONE_WAVE:
+        if (h->hc.model_kind != MPPI_MODEL_AUV) return fail(h, MPPI_ERR_INVALID_ARG, "not an AUVModel handle");
+        h->gen_one_wave = value != 0; break;
     case MPPI_TUNE_TRACE:
         if (value != 0 && !g_roctx.load()) return fail(h, MPPI_ERR_UNSUPPORTED, "MPPI_TUNE_TRACE: neither librocprofiler-sdk-roctx.so nor libroctx64.so could be loaded");
         h->trace = value != 0; break;

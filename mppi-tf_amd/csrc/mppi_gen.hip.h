@@ -161,24 +161,29 @@ __device__ __forceinline__ void matvec_n(const float *__restrict__ M, const floa
     }
 }
 
-// auv_model.py:308-351 state_dot = (J(eta) nu, invM (tau - C nu - D nu - g)); the zero blocks of the reference's dense products are skipped
+// auv_model.py:308-351 state_dot = (J(eta) nu, invM (tau - C nu - D nu - g)); the zero blocks of the reference's dense products are skipped.
+// In two halves, so that k_rollout_auv_pc can give them to two waves (same expressions, same order: what either kernel computes per
+// component is what auv_state_dot computes):
+//   auv_pose_rates  xd[0..6] = J(eta) nu: position rates rot . v_lin, quaternion rates T . v_ang          (needs q, all 6 velocities)
+//   auv_vel_rates   xd[7..12] = invM (tau - C nu - D nu - g(eta))                                        (needs q — rot's third row —, vel, tau)
 // pieces: NULL, or 18 floats that receive C nu [6], D nu [6], g [6] (what the reference's tests look at one by one)
-template <class GT>
-__device__ __forceinline__ void auv_state_dot(const GT *__restrict__ G, const float (&x)[kGenS], const float (&u)[kGenA],
-                                              float (&xd)[kGenS], float *pieces = nullptr)
+__device__ __forceinline__ void auv_pose_rates(const float (&q)[4], const float (&vel)[6], float (&xd)[7])
 {
-    const float q[4] = {x[3], x[4], x[5], x[6]};
     float rot[9], T[12];
     auv_b2i(q, rot, T);
-    float vel[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) vel[i] = x[7 + i];
-    // pose rates: J = [[rot, 0], [0, T]] (:335-351); the zero blocks contribute exact zeros
+    // J = [[rot, 0], [0, T]] (:335-351); the zero blocks contribute exact zeros
 #pragma unroll
     for (int i = 0; i < 3; ++i) xd[i] = (rot[i * 3] * vel[0] + rot[i * 3 + 1] * vel[1]) + rot[i * 3 + 2] * vel[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) xd[3 + i] = (T[i * 3] * vel[3] + T[i * 3 + 1] * vel[4]) + T[i * 3 + 2] * vel[5];
+}
 
+template <class GT>
+__device__ __forceinline__ void auv_vel_rates(const GT *__restrict__ G, const float (&q)[4], const float (&vel)[6], const float (&u)[kGenA],
+                                              float (&xdv)[6], float *pieces = nullptr)
+{
+    float rot[9], T[12];
+    auv_b2i(q, rot, T); // only rot's third row is used here (the rest is dead code to the compiler)
     // damping (:482-510): D = (-lin - v0*fwd) + (-(diag(quad) |diag(v)|)); D v as the dense row sum
     float Dv[6];
     const float v0 = vel[0];
@@ -221,7 +226,7 @@ __device__ __forceinline__ void auv_state_dot(const GT *__restrict__ G, const fl
     const float cog[3] = {G->cog[0], G->cog[1], G->cog[2]}, cob[3] = {G->cob[0], G->cob[1], G->cob[2]};
     cross3(cog, fbg, mbg);
     cross3(cob, fbb, mbb);
-    float rhs[6], acc6[6];
+    float rhs[6];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float g_f = -(fbg[i] + fbb[i]), g_m = -(mbg[i] + mbb[i]);
@@ -233,9 +238,23 @@ __device__ __forceinline__ void auv_state_dot(const GT *__restrict__ G, const fl
 #pragma unroll
         for (int i = 0; i < 6; ++i) { pieces[i] = Cv[i]; pieces[6 + i] = Dv[i]; }
     }
-    G->inv_mass_times(rhs, acc6);
+    G->inv_mass_times(rhs, xdv);
+}
+
+template <class GT>
+__device__ __forceinline__ void auv_state_dot(const GT *__restrict__ G, const float (&x)[kGenS], const float (&u)[kGenA],
+                                              float (&xd)[kGenS], float *pieces = nullptr)
+{
+    const float q[4] = {x[3], x[4], x[5], x[6]};
+    float vel[6], xp[7], xv[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) xd[7 + i] = acc6[i];
+    for (int i = 0; i < 6; ++i) vel[i] = x[7 + i];
+    auv_pose_rates(q, vel, xp);
+    auv_vel_rates(G, q, vel, u, xv, pieces);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) xd[i] = xp[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xd[7 + i] = xv[i];
 }
 
 // tf.math.l2_normalize on the quaternion (auv_model.py:422-448): q * (1 / sqrt(max(sum q^2, 1e-12)))
@@ -1209,6 +1228,229 @@ __global__ __launch_bounds__(kNnspeedPcThreads) void k_rollout_nnspeed_pc(
         for (int i = 0; i < 6; ++i) x[7 + i] = vel_s[pair][(H - 1) & 1][i][lane];
         const float sc = cost_of(x);
         c = c + (sc + vel_s[pair][(H - 1) & 1][6][lane]);
+        c = c + sc; // terminal cost: x_H counted a second time, controller_base.cpp:271-272
+        cost_s[pair][lane] = c;
+        if (valid) cost[k0 + lane] = c;
+    }
+    __syncthreads();
+    if (MODE == MODE_COST_ONLY || !tile_ok) return;
+    const float ct = cost_s[pair][lane];
+    mlp_tile_record<A, DIAG, 2>(C, ct, valid, role, lane, kk, H, NG, SRC, eps_hbm, C->seed, (unsigned long long)C->k_offset + (unsigned long long)kk,
+                                step_ctr[0] * (unsigned long long)NG, partials + (size_t)record_slot(tile, rsc) * rsb, rsc);
+}
+
+// k_rollout_auv_pc: the Fossen AUVModel (auv_model.py:282-562) as a two-wave pipeline per 64-rollout tile (r04).
+// k_rollout_gen<0> is one wave per tile = ONE wave per SIMD at K = 65536, and a lone wave issues a vector instruction every ~5.4 cycles
+// where two issue one every ~2.7 (profiles/r02_valu_issue.json): the kernel ran at half the issue rate by construction (0.19 ms, 980
+// vector instructions per wave and step). state_dot splits by ROWS without touching any row's arithmetic:
+//   wave A (pose):     lane = rollout. xd[0..6] = J(eta) nu (auv_pose_rates), the pose's Runge-Kutta update, the quaternion
+//                      normalisation, the cost of the state a step produced, and the noise: v = u + eps and the action cost of the NEXT step;
+//   wave B (velocity): lane = rollout. xd[7..12] = invM (tau - C nu - D nu - g(eta)) (auv_vel_rates: the two 6x6 products, damping,
+//                      Coriolis, restoring forces from rot's third row), the velocities' Runge-Kutta update.
+// Each needs the other's half of every Runge-Kutta stage state: A the 6 velocities, B the quaternion — handed over through double-
+// buffered LDS with ONE workgroup barrier per stage (2 per step at rk2); the perturbed action travels A -> B once per step, a step ahead.
+// Every row keeps the oracle's operations in the oracle's order (the pieces are the ones auv_state_dot is made of; the cost is summed by
+// wave A alone, in index order): sample costs stay BIT-IDENTICAL to the fp32 CPU restatement.
+// A workgroup is two tiles (4 waves, one per SIMD); roles by the SIMD a wave runs on, as in k_rollout_nnspeed_pc.
+constexpr int kAuvPcThreads = 256;
+
+template <bool DIAG>
+__global__ __launch_bounds__(kAuvPcThreads) void k_rollout_auv_pc(
+    const DevConsts *__restrict__ C, const GenConsts *__restrict__ G, const float *__restrict__ x_dev, const float *__restrict__ U_dev,
+    const float *__restrict__ eps_hbm, const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
+    const int SRC, const int MODE, const int rsb, const int rsc, const int n_tiles, const int balance)
+{
+    constexpr int S = kGenS, A = kGenA;
+    __shared__ float q_s[2][2][4][64];    // [tile of the workgroup][barrier parity][quaternion of the stage state][rollout]      A -> B
+    __shared__ float vel_s[2][2][6][64];  // [tile][barrier parity][velocities of the stage state][rollout]                       B -> A
+    __shared__ float act_s[2][2][7][64];  // [tile][step parity][perturbed action v, action cost][rollout]                        A -> B (v), A keeps the cost
+    __shared__ float cost_s[2][64];
+    __shared__ int simd_s[4];
+    const int H = C->H, HA = H * A, K = C->K_local;
+    const int NG = (H + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int pair = wave_hw >> 1, role = wave_hw & 1; // role 0 = velocity wave (the heavier one), 1 = pose wave
+    {
+        const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); // HW_REG_HW_ID[5:4]
+        if (lane == 0) simd_s[wave_hw] = simd;
+        __syncthreads();
+        const int s0 = simd_s[0], s1 = simd_s[1], s2 = simd_s[2], s3 = simd_s[3];
+        if (balance && ((1 << s0) | (1 << s1) | (1 << s2) | (1 << s3)) == 15) {
+            const int gen = (int)(blockIdx.x >> 8);
+            pair = simd & 1;
+            role = ((simd >> 1) ^ gen) & 1;
+        }
+        pair = __builtin_amdgcn_readfirstlane(pair);
+        role = __builtin_amdgcn_readfirstlane(role);
+    }
+    const int tile = 2 * (int)blockIdx.x + pair;
+    const bool tile_ok = tile < n_tiles; // the second tile of the last workgroup may not exist: its waves still keep every barrier
+    const int k0 = tile * 64;
+    const bool valid = tile_ok && (k0 + lane) < K;
+    const int kk = min(k0 + lane, K - 1);
+    const int rk = G->rk;
+    const float dt = G->dt;
+    int nbar = 0; // barriers passed so far: the parity of the stage hand-off buffers (the same sequence in both waves)
+
+    if (role == 0) {
+        // ================================================================================= wave B: velocities
+        AuvLocal al;
+        al.load(G);
+        float vel[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vel[i] = x_dev[7 + i];
+        // stage hand-off: publish the stage state's velocities, barrier, fetch its quaternion
+        auto swap_stage = [&](const float (&vs)[6], float (&qs)[4]) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) vel_s[pair][nbar & 1][i][lane] = vs[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qs[i] = q_s[pair][nbar & 1][i][lane];
+            ++nbar;
+        };
+        for (int t = 0; t < H; ++t) {
+            float q[4], v[A], k1[6], tmp[6];
+            swap_stage(vel, q);
+#pragma unroll
+            for (int i = 0; i < A; ++i) v[i] = act_s[pair][t & 1][i][lane]; // to_apply of step t (wave A prepared it a step ahead)
+            auv_vel_rates(&al, q, vel, v, k1);
+            if (rk == 2) {
+                float vs[6], k2[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) vs[i] = vel[i] + dt * k1[i];
+                swap_stage(vs, q);
+                auv_vel_rates(&al, q, vs, v, k2);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) tmp[i] = (dt / 2.0f) * (k1[i] + k2[i]);
+            } else if (rk == 4) { // the reference's formula, k4*dt inside the sum (:299-300)
+                float vs[6], k2[6], k3[6], k4[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) vs[i] = vel[i] + (dt * k1[i]) / 2.0f;
+                swap_stage(vs, q);
+                auv_vel_rates(&al, q, vs, v, k2);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) vs[i] = vel[i] + (dt * k2[i]) / 2.0f;
+                swap_stage(vs, q);
+                auv_vel_rates(&al, q, vs, v, k3);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) vs[i] = vel[i] + dt * k3[i];
+                swap_stage(vs, q);
+                auv_vel_rates(&al, q, vs, v, k4);
+                const float sixth = (float)(1.0 / 6.0);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) tmp[i] = (sixth * ((k1[i] + 2.0f * k2[i]) + (2.0f * k3[i] + k4[i] * dt))) * dt;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) tmp[i] = k1[i] * dt;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) vel[i] = vel[i] + tmp[i];
+        }
+        float q_unused[4];
+        swap_stage(vel, q_unused); // the velocities of x_H for wave A's last step cost and the terminal cost
+    } else {
+        // ================================================================================= wave A: pose, cost, noise
+        GenQuadConsts qc;
+        const bool quad_diag = C->state_cost_kind == MPPI_STATE_COST_QUADRATIC && !C->q_full;
+#pragma unroll
+        for (int i = 0; i < S; ++i) { qc.goal[i] = C->goal[i]; qc.qdiag[i] = C->qdiag[i]; }
+        PcProducerConsts<A> pcst; // Sigma, Sigma^-1, lambda: a kernel-local copy (no re-fetch behind the barriers)
+        pcst.template load<DIAG>(C);
+        const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
+        const unsigned long long seed = C->seed;
+        const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)kk;
+        auto cost_of = [&](const float (&xs)[S]) { return quad_diag ? state_cost<S, false>(&qc, xs) : gen_state_cost(C, G, xs); };
+        float x[S], c = 0.0f, z[4 * A];
+#pragma unroll
+        for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+        // v = u + eps and the action cost of step t -> act_s[t & 1] (mPrepareAction / mPrepareNoise, controller_base.cpp:205-213, :258)
+        auto prepare = [&](int t) {
+            float e[A], u[A];
+            if (SRC == SRC_PHILOX) {
+                if ((t & 3) == 0) normals_group<A>(seed, gk, base + (unsigned long long)(t >> 2), z);
+                float z1[A];
+                const int tl = t & 3; // wave-uniform: four statically indexed copies instead of a dynamically indexed register array
+                if (tl == 0) { _Pragma("unroll") for (int i = 0; i < A; ++i) z1[i] = z[i]; }
+                else if (tl == 1) { _Pragma("unroll") for (int i = 0; i < A; ++i) z1[i] = z[A + i]; }
+                else if (tl == 2) { _Pragma("unroll") for (int i = 0; i < A; ++i) z1[i] = z[2 * A + i]; }
+                else { _Pragma("unroll") for (int i = 0; i < A; ++i) z1[i] = z[3 * A + i]; }
+                scale_noise<A, DIAG>(&pcst, z1, e);
+            } else {
+#pragma unroll
+                for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
+            }
+#pragma unroll
+            for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; act_s[pair][t & 1][i][lane] = u[i] + e[i]; }
+            act_s[pair][t & 1][6][lane] = action_cost<A, DIAG>(&pcst, u, e);
+        };
+        // stage hand-off: publish the stage state's quaternion, barrier, fetch its velocities
+        auto swap_stage = [&](const float (&ps)[7], float (&vs)[6]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q_s[pair][nbar & 1][i][lane] = ps[3 + i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) vs[i] = vel_s[pair][nbar & 1][i][lane];
+            ++nbar;
+        };
+        prepare(0);
+        for (int t = 0; t < H; ++t) {
+            float pose[7], vel[6], k1[7], tmp[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) pose[i] = x[i];
+            swap_stage(pose, vel);
+            if (t >= 1) { // the state step t-1 produced is complete now: its cost, with that step's action cost
+#pragma unroll
+                for (int i = 0; i < 6; ++i) x[7 + i] = vel[i];
+                const float sc = cost_of(x);                           // cost on the POST-step state
+                const float step_c = sc + act_s[pair][(t - 1) & 1][6][lane]; // Step_cost_result cost_base.cpp:49
+                c = c + step_c;                                        // path_cost        controller_base.cpp:268
+            }
+            const float q0[4] = {pose[3], pose[4], pose[5], pose[6]};
+            auv_pose_rates(q0, vel, k1);
+            if (rk == 2) {
+                float ps[7], vs[6], k2[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) ps[i] = pose[i] + dt * k1[i];
+                swap_stage(ps, vs);
+                const float q1[4] = {ps[3], ps[4], ps[5], ps[6]};
+                auv_pose_rates(q1, vs, k2);
+#pragma unroll
+                for (int i = 0; i < 7; ++i) tmp[i] = (dt / 2.0f) * (k1[i] + k2[i]);
+            } else if (rk == 4) {
+                float ps[7], vs[6], k2[7], k3[7], k4[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) ps[i] = pose[i] + (dt * k1[i]) / 2.0f;
+                swap_stage(ps, vs);
+                { const float qq[4] = {ps[3], ps[4], ps[5], ps[6]}; auv_pose_rates(qq, vs, k2); }
+#pragma unroll
+                for (int i = 0; i < 7; ++i) ps[i] = pose[i] + (dt * k2[i]) / 2.0f;
+                swap_stage(ps, vs);
+                { const float qq[4] = {ps[3], ps[4], ps[5], ps[6]}; auv_pose_rates(qq, vs, k3); }
+#pragma unroll
+                for (int i = 0; i < 7; ++i) ps[i] = pose[i] + dt * k3[i];
+                swap_stage(ps, vs);
+                { const float qq[4] = {ps[3], ps[4], ps[5], ps[6]}; auv_pose_rates(qq, vs, k4); }
+                const float sixth = (float)(1.0 / 6.0);
+#pragma unroll
+                for (int i = 0; i < 7; ++i) tmp[i] = (sixth * ((k1[i] + 2.0f * k2[i]) + (2.0f * k3[i] + k4[i] * dt))) * dt;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) tmp[i] = k1[i] * dt;
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) x[i] = x[i] + tmp[i];
+            normalize_quat(x);
+            if (t + 1 < H) prepare(t + 1); // a step ahead: wave B reads it right behind the next step's first barrier
+        }
+        float pose[7], vel[6];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose[i] = x[i];
+        swap_stage(pose, vel);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[7 + i] = vel[i];
+        const float sc = cost_of(x);
+        c = c + (sc + act_s[pair][(H - 1) & 1][6][lane]);
         c = c + sc; // terminal cost: x_H counted a second time, controller_base.cpp:271-272
         cost_s[pair][lane] = c;
         if (valid) cost[k0 + lane] = c;

@@ -46,6 +46,7 @@ struct mppi_handle {
     int sync_spin = 1;    // MPPI_TUNE_SYNC_SPIN: the synchronous step watches the pinned u slot (0: waits for the stream)
     int p2p_fault = 0;    // MPPI_TUNE_P2P_FAULT: 1 = inbox export refused, 2 = probe reports failure (fallback tests)
     int trace = 0;        // MPPI_TUNE_TRACE: roctx ranges around what a step enqueues
+    int gen_one_wave = 0; // MPPI_TUNE_GEN_ONE_WAVE: the Fossen AUVModel on k_rollout_gen<0> (one wave per tile) instead of k_rollout_auv_pc
     float *d_x = nullptr, *d_u = nullptr, *d_cost = nullptr, *d_cost2 = nullptr;
     // The nominal sequence lives in one of two buffers of tau*a + a floats whose last a floats stay zero. A step
     // reads U from ubuf[u_cur] + u_off and writes U' to the other buffer at offset 0; the shifted sequence

@@ -201,6 +201,19 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
         return hipGetLastError();
     }
 #undef MPPI_NNAUV32_L
+    // Fossen AUVModel: the two-wave pipeline (pose wave + velocity wave per tile, r04) for rollouts and cost-only passes; the other modes
+    // and MPPI_TUNE_GEN_ONE_WAVE stay on the one-wave-per-tile kernel
+    if (h->hc.model_kind == MPPI_MODEL_AUV && !h->gen_one_wave && (mode == MODE_ROLLOUT || mode == MODE_COST_ONLY) && noise_out == nullptr) {
+        const int wgs = (h->nb + 1) / 2;
+        const int balance = wgs <= 2 * h->n_cu ? 1 : 0;
+        if (h->sigma_diag)
+            hipExtLaunchKernelGGL(k_rollout_auv_pc<true>, dim3(wgs), dim3(kAuvPcThreads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,
+                                  x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp, h->nb, balance);
+        else
+            hipExtLaunchKernelGGL(k_rollout_auv_pc<false>, dim3(wgs), dim3(kAuvPcThreads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,
+                                  x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp, h->nb, balance);
+        return hipGetLastError();
+    }
     if (h->hc.model_kind == MPPI_MODEL_AUV) MPPI_GEN_L(GEN_MODEL_AUV, 32);
     else if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED) {
         if (h->mlp_small == 16) MPPI_GEN_L(GEN_MODEL_NNAUV_SPEED, 16);
@@ -214,7 +227,10 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
 const char *mppi_gen_kernel_name(const mppi_handle *h)
 {
     const bool d = h->sigma_diag != 0; // the last template argument: exactly diagonal Sigma (as the profiler spells the instance)
-    if (h->hc.model_kind == MPPI_MODEL_AUV) return d ? "mppi::k_rollout_gen<0, 32, true>" : "mppi::k_rollout_gen<0, 32, false>";
+    if (h->hc.model_kind == MPPI_MODEL_AUV) {
+        if (!h->gen_one_wave) return d ? "mppi::k_rollout_auv_pc<true>" : "mppi::k_rollout_auv_pc<false>";
+        return d ? "mppi::k_rollout_gen<0, 32, true>" : "mppi::k_rollout_gen<0, 32, false>";
+    }
     if (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED) {
         if (h->mlp32_valu == 0)
             return h->mlp_small == 16 ? (d ? "mppi::k_rollout_nnspeed_pc<16, true>" : "mppi::k_rollout_nnspeed_pc<16, false>")

@@ -337,13 +337,23 @@ def auv_case(m, G, K, H, cost="quadratic", seed=0, **kw):
     return h, mk(F32), mk(np.float64), x0, U, eps
 
 
+AUV_KERNELS = {False: "mppi::k_rollout_auv_pc<true>", True: "mppi::k_rollout_gen<0, 32, true>"}  # r04: pose wave + velocity wave per tile | one wave per tile
+ONE_WAVE = pytest.mark.parametrize("one_wave", [False, True], ids=["pc", "onewave"])
+
+
+def auv_tuning(one_wave):
+    return dict(tuning={"gen_one_wave": 1}) if one_wave else {}
+
+
+@ONE_WAVE
 @pytest.mark.parametrize("cost", ["quadratic", "dense", "quat", "ellipse3d"])
-@pytest.mark.parametrize("K,H", [(1024, 16), (100, 7)])
-def test_auv_rollout_costs_against_oracle(m, G, K, H, cost):
+@pytest.mark.parametrize("K,H", [(1024, 16), (100, 7), (129, 5)])
+def test_auv_rollout_costs_against_oracle(m, G, K, H, cost, one_wave):
     """mBuildModelGraph with the Fossen model: sample costs bit-identical to the fp32 oracle for the quadratic costs (diagonal and
-    dense Q), within 3e-6 relative for the quaternion / 3D-ellipse costs (acos); ragged K and a horizon that is no multiple of 4."""
-    h, p32, p64, x0, U, eps = auv_case(m, G, K, H, cost)
-    assert h.rollout_kernel_name().startswith("mppi::k_rollout_gen<0, 32, ")
+    dense Q), within 3e-6 relative for the quaternion / 3D-ellipse costs (acos); ragged K (an odd tile count: the two-tile workgroup of
+    k_rollout_auv_pc runs half empty) and a horizon that is no multiple of 4. On both kernels: the two-wave pipeline and the one-wave-per-tile one."""
+    h, p32, p64, x0, U, eps = auv_case(m, G, K, H, cost, **auv_tuning(one_wave))
+    assert h.rollout_kernel_name() == AUV_KERNELS[one_wave]
     got = h.rollout_cost(x0, U, eps)
     ref = p32.rollout_cost(x0, U, eps)
     if cost in ("quadratic", "dense"):
@@ -354,12 +364,13 @@ def test_auv_rollout_costs_against_oracle(m, G, K, H, cost):
     assert (np.abs(got - truth) / np.abs(truth)).max() < 4 * max((np.abs(ref - truth) / np.abs(truth)).max(), 1e-6)
 
 
+@ONE_WAVE
 @pytest.mark.parametrize("cost", ["quadratic", "quat", "ellipse3d"])
-def test_auv_control_step_against_oracle(m, G, cost):
+def test_auv_control_step_against_oracle(m, G, cost, one_wave):
     """One control step with injected noise, then the fused Philox step on its own exported noise: U' within 1e-5 x the noise
     scale of the fp64 oracle; device noise = the oracle's Philox stream for a = 6; weights sum to 1."""
     K, H = 2048, 12
-    h, p32, p64, x0, U, eps = auv_case(m, G, K, H, cost, seed=3)
+    h, p32, p64, x0, U, eps = auv_case(m, G, K, H, cost, seed=3, **auv_tuning(one_wave))
     h.set_action_sequence(U)
     u = h.next_with_noise(x0, eps)
     u64, U64, c64 = p64.next_with_noise(x0, U, eps)
@@ -728,13 +739,15 @@ def update_is_the_recombination(m, h, U_in, c, eps, u, lam=1.0, scale=1500.0):
     np.testing.assert_array_equal(u, Uupd[0].astype(F32))
 
 
-def test_full_size_fossen_auv_costs_bit_identical(m):
-    """k_rollout_gen<0, 32, true> (AUVModel rk2, rexrov2) at the bench's size, fused Philox step: ALL 65536 sample costs bit-identical
-    to the fp32 oracle on the exported noise (auv_model.py:282-333), the noise is the oracle's Philox stream for a = 6, U' is the fp64
-    recombination, and the 8-way sharded step is the unsharded one."""
+@ONE_WAVE
+def test_full_size_fossen_auv_costs_bit_identical(m, one_wave):
+    """k_rollout_auv_pc<true> / k_rollout_gen<0, 32, true> (AUVModel rk2, rexrov2) at the bench's size, fused Philox step: ALL 65536 sample
+    costs bit-identical to the fp32 oracle on the exported noise (auv_model.py:282-333), the noise is the oracle's Philox stream for a = 6,
+    U' is the fp64 recombination, and the 8-way sharded step is the unsharded one."""
     cfg, ok, x0 = full_size_cfg("auv")
+    cfg.update(auv_tuning(one_wave))
     h = m.Handle(k=FULL_K, **cfg)
-    assert h.rollout_kernel_name() == "mppi::k_rollout_gen<0, 32, true>"
+    assert h.rollout_kernel_name() == AUV_KERNELS[one_wave]
     p32 = orc.Problem(threads=0, **ok)
     U_in = (100.0 * np.random.default_rng(1).standard_normal((FULL_H, 6))).astype(F32)
     h.set_action_sequence(U_in)
@@ -747,10 +760,13 @@ def test_full_size_fossen_auv_costs_bit_identical(m):
     shards_agree_with(m, cfg, x0, U_in, u, c)
 
 
-def test_multi_round_fossen_auv_costs_bit_identical(m):
-    """K = 200001 (3126 tiles: several rounds per SIMD, a ragged last tile, the 16:1 record fold in front of the finish), rk2:
-    costs bit-identical to the fp32 oracle, U' the fp64 recombination."""
+@pytest.mark.parametrize("rk", [2, 4, 1])
+def test_multi_round_fossen_auv_costs_bit_identical(m, rk):
+    """K = 200001 (3126 tiles: several rounds per SIMD, a ragged last tile, the 16:1 record fold in front of the finish), rk2 / rk4 / rk1
+    (1, 3 or no stage hand-offs inside a step of the two-wave pipeline): costs bit-identical to the fp32 oracle, U' the fp64 recombination."""
     cfg, ok, x0 = full_size_cfg("auv")
+    cfg["auv"] = dict(cfg["auv"], rk=rk)
+    ok["auv"] = cfg["auv"]
     K, H = 200001, 16
     cfg["tau"], ok["tau"] = H, H
     h = m.Handle(k=K, **cfg)
