@@ -128,7 +128,9 @@ def self_launch(args):
     t_start = time.time()
     budget = float(os.environ.get("MPPI_BENCH_BUDGET_S", "540"))
     if os.environ.get("MPPI_BENCH_ONE_GPU") == "1":
-        modes = ["p2p"]   # the one-GPU rehearsal: RCCL refuses two ranks on one device
+        # the one-GPU rehearsal: RCCL refuses two ranks on one device, so the "rccl" job exchanges its records with gloo's all-gather
+        # (three calls + one collective per step, the torch path, staged through the host) — it walks this function's two-job logic, not RCCL
+        modes = ["rccl", "p2p"]
     elif os.environ.get("MPPI_EXCHANGE"):
         modes = [os.environ["MPPI_EXCHANGE"]]
     else:
@@ -510,7 +512,7 @@ def roofline_of(r):
 
 def sub_record(s):
     name = CONFIG_NAME.get((s["workload"], s["K_per_gpu"], s["H"], 1)) or CONFIG_NAME.get((s["workload"], s["K_per_gpu"], s["H"], 8)) or \
-        {"mlp32": "ref Dense(32)x3", "nnauv": "ref NNAUVModel s13 a6", "auv": "ref Fossen AUVModel rk2"}.get(s["workload"], "")
+        {"mlp32": "ref Dense(32)x3", "nnauv": "ref NNAUVModel s13 a6", "auv": "ref Fossen AUVModel rk2", "nnspeed": "ref NNAUVModelSpeed Dense(16)x3"}.get(s["workload"], "")
     if "bx3" in s["kernel"]:
         name += " +BF16X3"
     rf = roofline_of(s)
@@ -548,7 +550,7 @@ def main():
     rehearsal = os.environ.get("MPPI_BENCH_ONE_GPU") == "1" and world > 1
     if rehearsal:
         local_rank = 0
-        os.environ["MPPI_EXCHANGE"] = "p2p"
+        os.environ.setdefault("MPPI_EXCHANGE", "p2p")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("MPPI_FORCE_EXCHANGE") == "1":
@@ -578,7 +580,7 @@ def main():
             subs.append(rn.run("mlp", 65536, 64, 20, 3, 0.0, mlp_bf16x3=True))
             subs.append(rn.run("mlp32", 65536, 64, 50, 5, 0.0))
             subs.append(rn.run("mlp32", 65536, 64, 50, 5, 0.0, mlp_bf16x3=True))
-            for w, kw in (("nnauv", {}), ("nnauv", dict(mlp_bf16x3=True)), ("auv", {})):
+            for w, kw in (("nnauv", {}), ("nnauv", dict(mlp_bf16x3=True)), ("auv", {}), ("nnspeed", {})):
                 try:
                     subs.append(rn.run(w, 65536, 64, 20, 3, 0.0, **kw))
                 except Exception as e:  # a sub-record must never cost the headline

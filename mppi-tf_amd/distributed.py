@@ -238,7 +238,14 @@ class ShardedController:
         else:
             self.backend.partial(x, self.record)
         if collective:
-            dist.all_gather_into_tensor(self.records, self.record, group=self.group)
+            if self.records.is_cuda and dist.get_backend(self.group) != "nccl":
+                # (the one-GPU rehearsal of bench.py: GPU shards, gloo rendezvous — the records take the host's all-gather)
+                torch.cuda.current_stream(self.backend.device).synchronize()
+                host = torch.empty(self.records.shape, dtype=torch.float32)
+                dist.all_gather_into_tensor(host, self.record.cpu(), group=self.group)
+                self.records.copy_(host)
+            else:
+                dist.all_gather_into_tensor(self.records, self.record, group=self.group)
             self.backend.finish(self.records, self.world, self.u)
         else:
             self.backend.finish(self.record, 1, self.u)
