@@ -445,7 +445,8 @@ class Runner:
                 ctl.next(x)
         torch.cuda.synchronize(self.dev)
         roll_ms, fin_ms, n_prof = h.profile_end()
-        assert np.isfinite(ctl.u.cpu().numpy()).all()
+        assert np.isfinite(ctl.u.cpu().numpy()).all(), "non-finite control after %d profiled steps of %s (exchange %s): u = %s, first record (beta, eta) = %s" % (
+            n_prof, workload, ctl.exchange, ctl.u.cpu().numpy(), ctl.records[:2].cpu().numpy())
         bytes_ss, flop_ss = work_per_state_step(workload)
         state_steps = K * H
         res = {"workload": workload, "K_per_gpu": K, "H": H, "a_dim": a, "s_dim": cfg["s_dim"], "steps": steps, "batches_s": batches,

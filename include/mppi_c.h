@@ -11,7 +11,9 @@
  *
  * Conventions
  *  - plain C, no torch / HIP types in signatures; `void *stream` is a hipStream_t (NULL = the
- *    handle's own stream);
+ *    handle's own, non-blocking stream; to enqueue on the legacy default stream — torch's default — pass
+ *    hipStreamLegacy, (hipStream_t)1: a step must run on a stream that is ordered against whatever produces
+ *    x_dev and consumes u_dev / the records);
  *  - all host buffers are caller-owned, fp32, row-major, with the reference's trailing
  *    singleton dropped:  x[s]  U[tau,a]  eps[K,tau,a]  cost[K];
  *  - pointers named *_dev are DEVICE pointers on the handle's GPU;

@@ -1556,6 +1556,22 @@ def test_direct_exchange_across_processes_over_hipipc():
     assert r.stdout.count("P2P_WORKER_OK") == 2, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_allgather_path_across_processes_is_stream_ordered():
+    """Two processes on this GPU (gloo): ShardedController's torch path on torch's default stream gives, step for step and bit for bit,
+    the single-process result — it used to gather records one step stale (tests/gather_worker.py says why)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("MPPI_EXCHANGE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "gather_worker.py")], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("GATHER_WORKER_OK") == 2, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 # =============================================================== options of the Python update (SURVEY §8f row 2)
 def test_action_limits_clip_the_updated_sequence(m):
     """clip_act (controller_base.py:500-504): U' = clip(U + Σ w eps, a_min, a_max) row-wise, u = U'[0]."""
