@@ -564,6 +564,11 @@ def main():
 
     import mppi_tf_amd as m
 
+    if world > 1 or dist.is_initialized():
+        # the sharded step and its collective run on torch's CURRENT stream: make that an ordinary stream of its own, so that RCCL is
+        # never handed the legacy default stream's handle (ShardedController would pass hipStreamLegacy for it)
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
+
     headline = args.workload or "pm3d"
     a, net = WORKLOADS[headline]
     is_mlp = net is not None
