@@ -30,7 +30,7 @@ for SPEC in "$@"; do
   rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC --kernel-trace --output-format csv -d $D/pmc_sq3 -- $BENCH > $D/pmc_sq3.log 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVES --kernel-trace --output-format csv -d $D/pmc_sq -- $BENCH > $D/pmc_sq.log 2>&1
   rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $D/pmc_grbm -- $BENCH > $D/pmc_grbm.log 2>&1
-  case $WL in pm3d|pm2d|pm1d|auv|nnspeed) ;; *)  # matrix-core occupancy of the learned-model kernels (a refused counter only loses this pass)
+  case $WL in pm3d|pm2d|pm1d|auv) ;; *)  # matrix-core occupancy of the learned-model kernels (a refused counter only loses this pass)
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --kernel-trace --output-format csv -d $D/pmc_mfma -- $BENCH > $D/pmc_mfma.log 2>&1;;
   esac
   case $WL in pm3d|mlp)
