@@ -24,8 +24,15 @@ cases = [
  ("mlp32 bx3", dict(k=65536, mlp=mlp([9,32,32,32,6]), mlp_bf16x3=True, **pm), np.zeros(6, np.float32), 3000),
  ("nnauv32 bx3", dict(k=65536, nnauv=mlp([16,32,32,32,13]), mlp_bf16x3=True, **at), x13, 2000),
  ("nnauv32", dict(k=65536, nnauv=mlp([16,32,32,32,13]), **at), x13, 1500),
- ("nnspeed", dict(k=65536, nnauv_speed=mlp([15,16,16,16,6]), **at), x13, 1500),
- ("auv", dict(k=65536, **auv_task(64)), x13, 2000),
+ ("nnspeed pc", dict(k=65536, nnauv_speed=mlp([15,16,16,16,6]), **at), x13, 3000),            # r04: k_rollout_nnspeed_pc (network wave + pose wave)
+ ("nnspeed pc 32", dict(k=65536, nnauv_speed=mlp([15,32,32,6]), **at), x13, 1500),
+ ("nnspeed pc ragged", dict(k=200001, nnauv_speed=mlp([15,16,16,16,6]), **at), x13, 500),        # several rounds, an odd tile count, a partial tile
+ ("nnspeed mfma32", dict(k=65536, nnauv_speed=mlp([15,16,16,16,6]), tuning={"mlp32_valu": 2}, **at), x13, 1000),
+ ("nnspeed valu", dict(k=65536, nnauv_speed=mlp([15,16,16,16,6]), tuning={"mlp32_valu": 1}, **at), x13, 500),
+ ("auv pc", dict(k=65536, **auv_task(64)), x13, 4000),                                           # r04: k_rollout_auv_pc (pose wave + velocity wave)
+ ("auv pc ragged", dict(k=200001, **auv_task(64)), x13, 600),
+ ("auv pc rk4", dict(k=65536, **dict(auv_task(64), auv=dict(auv_task(64)["auv"], rk=4))), x13, 1000),
+ ("auv one wave", dict(k=65536, tuning={"gen_one_wave": 1}, **auv_task(64)), x13, 1000),
 ]
 for name, kw, x0, n in cases:
     kw = dict(kw); kw.pop("x0", None)
