@@ -358,7 +358,8 @@ enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instea
        MPPI_TUNE_MLP_V1 = 6,            /* 1: exact-fp32 MLP rollouts on the first kernel (8 waves per workgroup) instead of k_rollout_mlp2 */
        MPPI_TUNE_MLP32_VALU = 7,        /* 1: a Dense(32) network on k_rollout_mlp_small (vector ALU, scalar-cache weights) instead of k_rollout_mlp32 (matrix cores);
                                            NNAUVModelSpeed (Dense(16|32)): 1 = k_rollout_gen<2, HID> (vector ALU), 2 = k_rollout_nnspeed32<HID> (matrix cores, one wave per
-                                           32 rollouts) instead of k_rollout_nnspeed_pc<HID> (matrix cores, network wave + pose wave per tile) */
+                                           32 rollouts) instead of k_rollout_nnspeed_pc<HID> (matrix cores, network wave + pose wave per tile); NNAUVModel Dense(32):
+                                           1 = k_rollout_gen<1, 32>, 2 = k_rollout_nnauv32 instead of k_rollout_nnauv_pc (network wave + cost wave per tile) */
        /* 1: roctx ranges "mppi:step" > "mppi:rollout" / "mppi:exchange" / "mppi:finish" around what every step enqueues (the reference brackets
         * its step with tf.profiler.experimental.start/stop, controller_base.py:241-248, 587-595). libroctx64.so is dlopen'ed on first use —
         * the library has no link dependency on it; the call fails with MPPI_ERR_UNSUPPORTED when it cannot be found. Shows in

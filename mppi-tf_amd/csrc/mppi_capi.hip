@@ -1202,7 +1202,8 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
     case MPPI_TUNE_MLP32_VALU:
         if (!(h->mlp_small == 32 || (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED && h->mlp_small == 16)) || h->mlp_bx3)
             return fail(h, MPPI_ERR_INVALID_ARG, "not an exact-fp32 Dense(32) MLP handle (or an NNAUVModelSpeed one)");
-        if (value < 0 || value > 2 || (value == 2 && h->hc.model_kind != MPPI_MODEL_NN_AUV_SPEED)) return fail(h, MPPI_ERR_INVALID_ARG, "0, 1 (vector-ALU kernel) or, NNAUVModelSpeed only, 2 (one wave per 32 rollouts)");
+        if (value < 0 || value > 2 || (value == 2 && h->hc.model_kind != MPPI_MODEL_NN_AUV_SPEED && h->hc.model_kind != MPPI_MODEL_NN_AUV))
+            return fail(h, MPPI_ERR_INVALID_ARG, "0, 1 (vector-ALU kernel) or, NNAUVModel / NNAUVModelSpeed only, 2 (matrix cores, one wave per 32 rollouts)");
         h->mlp32_valu = value; break;
     case MPPI_TUNE_P2P_FAULT:
         if (value < 0 || value > 2) return fail(h, MPPI_ERR_INVALID_ARG, "fault: 0 none, 1 export, 2 probe");

@@ -171,11 +171,20 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
                           (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp)
     // Dense(32) NNAUVModel: the matrix-core kernel (rollouts and cost-only passes; the record-from-given-costs / noise-export modes
     // and MPPI_TUNE_MLP32_VALU stay on the vector-ALU kernel)
-    if (h->hc.model_kind == MPPI_MODEL_NN_AUV && h->mlp_small == 32 && !h->mlp32_valu && (mode == MODE_ROLLOUT || mode == MODE_COST_ONLY) && noise_out == nullptr) {
+    if (h->hc.model_kind == MPPI_MODEL_NN_AUV && h->mlp_small == 32 && h->mlp32_valu != 1 && (mode == MODE_ROLLOUT || mode == MODE_COST_ONLY) && noise_out == nullptr) {
         if (h->mlp_bx3) { // MPPI_FLAG_MLP_BF16X3: the bf16 matrix cores, every operand split in two
             if (h->sigma_diag) MPPI_NNAUV32_L(k_rollout_nnauv32_bx3<true>);
             else MPPI_NNAUV32_L(k_rollout_nnauv32_bx3<false>);
-        } else {
+        } else if (h->mlp32_valu == 0) { // default (r04): the two-wave pipeline (network wave + cost wave per tile, two tiles per workgroup)
+            const int wgs = (h->nb + 1) / 2;
+            const int balance = wgs <= 2 * h->n_cu ? 1 : 0;
+            if (h->sigma_diag)
+                hipExtLaunchKernelGGL(k_rollout_nnauv_pc<true>, dim3(wgs), dim3(kNnauvPcThreads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,
+                                      (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp, h->nb, balance);
+            else
+                hipExtLaunchKernelGGL(k_rollout_nnauv_pc<false>, dim3(wgs), dim3(kNnauvPcThreads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,
+                                      (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp, h->nb, balance);
+        } else { // MPPI_TUNE_MLP32_VALU = 2: one wave per 32 rollouts (A/B timing)
             if (h->sigma_diag) MPPI_NNAUV32_L(k_rollout_nnauv32<true>);
             else MPPI_NNAUV32_L(k_rollout_nnauv32<false>);
         }
@@ -241,9 +250,11 @@ const char *mppi_gen_kernel_name(const mppi_handle *h)
         return h->mlp_small == 16 ? (d ? "mppi::k_rollout_gen<2, 16, true>" : "mppi::k_rollout_gen<2, 16, false>")
                                   : (d ? "mppi::k_rollout_gen<2, 32, true>" : "mppi::k_rollout_gen<2, 32, false>");
     }
-    if (h->mlp_small == 32 && !h->mlp32_valu)
-        return h->mlp_bx3 ? (d ? "mppi::k_rollout_nnauv32_bx3<true>" : "mppi::k_rollout_nnauv32_bx3<false>")
-                          : (d ? "mppi::k_rollout_nnauv32<true>" : "mppi::k_rollout_nnauv32<false>");
+    if (h->mlp_small == 32 && h->mlp32_valu != 1) {
+        if (h->mlp_bx3) return d ? "mppi::k_rollout_nnauv32_bx3<true>" : "mppi::k_rollout_nnauv32_bx3<false>";
+        if (h->mlp32_valu == 0) return d ? "mppi::k_rollout_nnauv_pc<true>" : "mppi::k_rollout_nnauv_pc<false>";
+        return d ? "mppi::k_rollout_nnauv32<true>" : "mppi::k_rollout_nnauv32<false>";
+    }
     return h->mlp_small == 16 ? (d ? "mppi::k_rollout_gen<1, 16, true>" : "mppi::k_rollout_gen<1, 16, false>")
                               : (d ? "mppi::k_rollout_gen<1, 32, true>" : "mppi::k_rollout_gen<1, 32, false>");
 }

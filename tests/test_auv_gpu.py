@@ -459,8 +459,8 @@ def test_auv_sharded_normalize_cost(m, G):
 
 
 @pytest.mark.parametrize("hid,n_hidden,tuning", [(32, 3, None), (32, 3, {"mlp32_valu": 1}), (16, 2, None), (32, 1, None), (32, 2, None),
-                                                 (32, 3, "bf16x3"), (32, 1, "bf16x3")],
-                         ids=["32x3-mfma", "32x3-valu", "16x2", "32x1-mfma", "32x2-mfma", "32x3-bf16x3", "32x1-bf16x3"])
+                                                 (32, 3, {"mlp32_valu": 2}), (32, 1, {"mlp32_valu": 2}), (32, 2, {"mlp32_valu": 2}), (32, 3, "bf16x3"), (32, 1, "bf16x3")],
+                         ids=["32x3-pc", "32x3-valu", "16x2", "32x1-pc", "32x2-pc", "32x3-mfma32", "32x1-mfma32", "32x2-mfma32", "32x3-bf16x3", "32x1-bf16x3"])
 @pytest.mark.parametrize("cost", ["quadratic", "quat"])
 def test_nnauv_control_step_against_oracle(m, hid, n_hidden, tuning, cost):
     """The learned 13-state model in the full path: NNAUVModel (input 16, output 13) with the quadratic or the quaternion cost —
@@ -482,8 +482,12 @@ def test_nnauv_control_step_against_oracle(m, hid, n_hidden, tuning, cost):
     fac, bar = (8, 2e-5) if bx3 else (4, 1e-5)
     cfg = dict(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, nnauv=mlp, seed=9, tuning=None if bx3 else tuning, mlp_bf16x3=bx3, **ck)
     h = m.Handle(**cfg)
-    # Dense(32): the matrix cores (k_rollout_nnauv32, the accumulators of one layer are the next layer's B operands) unless tuned onto the vector ALU
-    assert h.rollout_kernel_name() == ("mppi::k_rollout_nnauv32_bx3<true>" if bx3 else "mppi::k_rollout_nnauv32<true>" if hid == 32 and not tuning else "mppi::k_rollout_gen<1, %d, true>" % hid)
+    # Dense(32): the matrix cores — the two-wave pipeline k_rollout_nnauv_pc (r04) by default, k_rollout_nnauv32 (one wave per 32 rollouts, the
+    # accumulators of one layer are the next layer's B operands in both) with MPPI_TUNE_MLP32_VALU = 2 — unless tuned onto the vector ALU (= 1)
+    tv = (tuning or {}).get("mlp32_valu", 0) if not bx3 else 0
+    want = ("mppi::k_rollout_nnauv32_bx3<true>" if bx3 else "mppi::k_rollout_gen<1, %d, true>" % hid if (hid != 32 or tv == 1)
+            else "mppi::k_rollout_nnauv32<true>" if tv == 2 else "mppi::k_rollout_nnauv_pc<true>")
+    assert h.rollout_kernel_name() == want
     mk = lambda dt: orc.Problem(tau=H, s=13, a=6, lam=1.0, sigma=sigma, nnauv=mlp, threads=0, dtype=dt, **ck)
     p32, p64 = mk(F32), mk(np.float64)
     rng = np.random.default_rng(1)
@@ -606,7 +610,8 @@ def test_python_entry_point_learns_the_plant_online():
     assert np.isfinite(float(re.search(r"goal_p\| = ([0-9.]+) m", r.stdout).group(1)))
 
 
-@pytest.mark.parametrize("kind,K,H", [("bf16x3", 300, 7), ("bf16x3", 65, 5), ("speed", 300, 7), ("speed", 1, 3), ("speed", 129, 6), ("speed", 64, 1), ("mfma", 65, 5)])
+@pytest.mark.parametrize("kind,K,H", [("bf16x3", 300, 7), ("bf16x3", 65, 5), ("speed", 300, 7), ("speed", 1, 3), ("speed", 129, 6), ("speed", 64, 1), ("mfma", 65, 5),
+                                      ("mfma", 129, 6), ("mfma", 1, 2)])
 def test_learned_13_state_kernels_with_ragged_tiles(m, kind, K, H):
     """K that is no multiple of the 64-rollout tile (partial last tile, a single rollout) and a horizon that is no multiple of the 4-step
     Philox group, for the learned 13-state kernels: k_rollout_nnauv32(_bx3) and NNAUVModelSpeed's k_rollout_gen<2, .> — the fused step
@@ -788,7 +793,7 @@ def test_full_size_learned_13_state_models(m, kind):
     cfg, ok, x0 = full_size_cfg(kind)
     h = m.Handle(k=FULL_K, **cfg)
     name = h.rollout_kernel_name()
-    assert name.startswith({"mfma": "mppi::k_rollout_nnauv32<true>", "bf16x3": "mppi::k_rollout_nnauv32_bx3<true>", "speed": "mppi::k_rollout_nnspeed_pc<16, true>"}[kind]), name
+    assert name.startswith({"mfma": "mppi::k_rollout_nnauv_pc<true>", "bf16x3": "mppi::k_rollout_nnauv32_bx3<true>", "speed": "mppi::k_rollout_nnspeed_pc<16, true>"}[kind]), name
     p32, p64 = orc.Problem(threads=0, **ok), orc.Problem(threads=0, dtype=np.float64, **ok)
     U_in = (100.0 * np.random.default_rng(1).standard_normal((FULL_H, 6))).astype(F32)
     h.set_action_sequence(U_in)

@@ -23,7 +23,9 @@ cases = [
  ("mlp 2x256", dict(k=65536, mlp=mlp([9,256,256,6]), **pm), np.zeros(6, np.float32), 300),
  ("mlp32 bx3", dict(k=65536, mlp=mlp([9,32,32,32,6]), mlp_bf16x3=True, **pm), np.zeros(6, np.float32), 3000),
  ("nnauv32 bx3", dict(k=65536, nnauv=mlp([16,32,32,32,13]), mlp_bf16x3=True, **at), x13, 2000),
- ("nnauv32", dict(k=65536, nnauv=mlp([16,32,32,32,13]), **at), x13, 1500),
+ ("nnauv pc", dict(k=65536, nnauv=mlp([16,32,32,32,13]), **at), x13, 2500),                      # r04: k_rollout_nnauv_pc (network wave + cost wave)
+ ("nnauv pc ragged", dict(k=200001, nnauv=mlp([16,32,32,32,13]), **at), x13, 400),
+ ("nnauv32", dict(k=65536, nnauv=mlp([16,32,32,32,13]), tuning={"mlp32_valu": 2}, **at), x13, 1000),
  ("nnspeed pc", dict(k=65536, nnauv_speed=mlp([15,16,16,16,6]), **at), x13, 3000),            # r04: k_rollout_nnspeed_pc (network wave + pose wave)
  ("nnspeed pc 32", dict(k=65536, nnauv_speed=mlp([15,32,32,6]), **at), x13, 1500),
  ("nnspeed pc ragged", dict(k=200001, nnauv_speed=mlp([15,16,16,16,6]), **at), x13, 500),        # several rounds, an odd tile count, a partial tile
