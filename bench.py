@@ -36,6 +36,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T_START = time.time()
 
 HID = 256                                 # BASELINE configs[3]: learned 2x256 MLP model_base
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -176,6 +177,68 @@ def self_launch(args):
     sys.stdout.write(json.dumps(line) + "\n")
     sys.stdout.flush()
     sys.exit(0)
+
+
+def direct_exchange_in_children(args, world, rank, dist):
+    """Rank mode (the driver's own `torch.distributed.run ... bench.py --gpus N`): this process IS a rank, there is no parent of ours to
+    run two jobs. The ranks have just measured the all-gather path (MPPI_EXCHANGE=rccl) in-process; the direct exchange — peer stores
+    over xGMI inside the finish kernel, never run between two real devices so far — is now tried in CHILD processes, one per rank (same
+    RANK / LOCAL_RANK / WORLD_SIZE, a rendezvous port of their own, MPPI_EXCHANGE=auto, headline only), with a time limit: a fault, a
+    hang or a bad exit there costs a field of the line, not the line. The ranks wait for their child (the GPU is theirs
+    meanwhile), the group is killed on the limit. -> (rank 0: the child job's parsed line or None, outcome text); other ranks (None, "")"""
+    import signal
+    import tempfile
+    left = float(os.environ.get("MPPI_BENCH_BUDGET_S", "540")) - (time.time() - T_START)
+    limit = min(float(os.environ.get("MPPI_BENCH_P2P_LIMIT_S", "150")), left - 30)
+    box = [None]
+    if rank == 0:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            box[0] = (so.getsockname()[1], limit)
+    dist.broadcast_object_list(box, src=0)
+    port, limit = box[0]  # every rank takes rank 0's decision
+    if limit < 45:
+        return None, "skipped: %d s left of the budget" % max(left, 0)
+    env = dict(os.environ, MPPI_EXCHANGE="auto", MPPI_BENCH_CHILD="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+        del env[k]  # (TORCHELASTIC_USE_AGENT_STORE would make the children look for the launcher's store on the new port)
+    drop = {"--no-subrecords", "--no-cpu-baseline"}
+    cmd = [sys.executable, os.path.abspath(__file__)] + [a_ for a_ in sys.argv[1:] if a_ not in drop] + ["--no-subrecords", "--no-cpu-baseline"]
+    if rank == 0:
+        sys.stderr.write("bench.py: the direct exchange in %d child processes, limit %d s\n" % (world, limit))
+        sys.stderr.flush()
+    with tempfile.TemporaryFile() as err:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=err, env=env, start_new_session=True)
+        out, timed_out = b"", False
+        try:
+            out, _ = p.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            for sig, wait in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
+                try:
+                    os.killpg(p.pid, sig)  # the group this call started, nothing else
+                except ProcessLookupError:
+                    pass
+                try:
+                    out, _ = p.communicate(timeout=wait)
+                    break
+                except subprocess.TimeoutExpired:
+                    out = b""
+        err.seek(0)
+        etxt = err.read().decode(errors="replace")
+    if rank != 0:
+        return None, ""
+    sys.stderr.write(etxt)
+    lines = [l for l in (out or b"").decode(errors="replace").splitlines() if l.startswith("{") and '"metric"' in l]
+    tail = " | ".join(l.strip() for l in etxt.splitlines()[-4:] if l.strip())[-300:]
+    if timed_out:
+        return None, "failed: no line within %d s (children killed); %s" % (limit, tail)
+    if not lines:
+        return None, "failed: rc=%d; %s" % (p.returncode, tail)
+    try:
+        return json.loads(lines[-1]), "ok"
+    except ValueError:
+        return None, "failed: unparsable line"
 
 
 def cfg_of(workload, H):
@@ -554,6 +617,11 @@ def main():
     # bookkeeping over gloo, records over the direct exchange (hipIpc inboxes). RCCL refuses two ranks on one device, so this is
     # the only way to walk the self-launch / per-rank / sub-record code before an 8-GPU node does. The line says "rehearsal".
     rehearsal = os.environ.get("MPPI_BENCH_ONE_GPU") == "1" and world > 1
+    # rank mode with nobody having chosen an exchange: the all-gather path first, in-process (its line is kept), the direct exchange
+    # afterwards in child processes (direct_exchange_in_children)
+    two_phase = world > 1 and not os.environ.get("MPPI_EXCHANGE") and os.environ.get("MPPI_BENCH_CHILD") != "1"
+    if two_phase:
+        os.environ["MPPI_EXCHANGE"] = "rccl"
     if rehearsal:
         local_rank = 0
         os.environ.setdefault("MPPI_EXCHANGE", "p2p")
@@ -600,6 +668,13 @@ def main():
             # (rehearsal on one GPU: the analytic model — two MLP shards cannot be co-resident on one device, k_rollout_mlp2 owns whole CUs)
             subs.append(rn.run("pm3d" if rehearsal else "mlp", 65536, 128, 10, 2, 0.0))
 
+    p2p_line, p2p_outcome = (None, None)
+    if two_phase:
+        try:
+            p2p_line, p2p_outcome = direct_exchange_in_children(args, world, rank, dist)
+        except Exception as e:  # whatever happens there, the measured line is printed
+            p2p_line, p2p_outcome = None, "failed: %s" % e
+
     if rank == 0:
         name = CONFIG_NAME.get((headline, K, H, world), CONFIG_NAME.get((headline, K, H, 1), "not a BASELINE configuration"))
         s_dim = r["s_dim"]
@@ -636,6 +711,26 @@ def main():
             out["ms_per_control_step_sync"] = {"median": r4(med), "p95": r4(p95)}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(headline, H, K, r["mlp"])
+        if two_phase:  # both outcomes; the better headline is the line's
+            ex = dict(out.get("exchange") or {})
+            ex["rccl"] = {"value": r4(out["value"]), "ms_per_step": r4(out["ms_per_step"]), "used": r["exchange"]}
+            if p2p_line is not None:
+                used = (p2p_line.get("exchange") or {}).get("used")
+                ex["p2p"] = {"value": r4(p2p_line["value"]), "ms_per_step": r4(p2p_line["ms_per_step"]), "used": used}
+                if used != "p2p":
+                    ex["p2p"]["note"] = "direct exchange not used: %s" % (p2p_line.get("exchange") or {}).get("direct_exchange_bring_up")
+                if p2p_line["value"] > out["value"]:
+                    for key in ("value", "ms_per_step", "batches", "roofline", "rank_ms_per_step", "steps"):
+                        if key in p2p_line:
+                            out[key] = p2p_line[key]
+                    out["config"]["exchange"] = p2p_line["config"].get("exchange")
+                    ex["used"], ex["direct_exchange_bring_up"] = used, (p2p_line.get("exchange") or {}).get("direct_exchange_bring_up")
+                    ex["printed"] = "p2p"
+                else:
+                    ex["printed"] = "rccl"
+            else:
+                ex["p2p"], ex["printed"] = p2p_outcome, "rccl"
+            out["exchange"] = ex
         line = json.dumps(out)
         sys.stdout.flush()
         os.write(real_stdout, (line + "\n").encode())

@@ -42,3 +42,28 @@ def test_cpu_baseline_rides_along(workload, extra):
     out = run_bench("--workload", workload, "--no-subrecords", *extra)
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+def test_rank_mode_measures_the_allgather_path_first_and_the_direct_exchange_in_children():
+    """How the driver runs N > 1: `python -m torch.distributed.run ... bench.py --gpus N` — bench.py IS a rank. The ranks measure the
+    all-gather path in-process (that line is safe), then try the direct exchange in CHILD processes with a time limit, and rank 0 prints
+    ONE line with both outcomes (first contact with the direct exchange must not cost the curve). Rehearsed on the one GPU
+    (MPPI_BENCH_ONE_GPU=1: gloo rendezvous, both ranks and their children on cuda:0 = 4 GPU processes)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MPPI_BENCH_ONE_GPU="1")
+    env.pop("MPPI_EXCHANGE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3", "--min-time", "0",
+                        "--samples", "8192", "--no-subrecords"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    ex = out["exchange"]
+    assert ex["rccl"]["used"] == "rccl" and ex["rccl"]["value"] > 0
+    assert isinstance(ex["p2p"], dict) and ex["p2p"]["used"] == "p2p", ex
+    assert ex["printed"] in ("rccl", "p2p") and out["n_gpus"] == 2
+    assert out["value"] == max(ex["rccl"]["value"], ex["p2p"]["value"]) or abs(out["value"] - max(ex["rccl"]["value"], ex["p2p"]["value"])) < 1e-3 * out["value"]
