@@ -1249,7 +1249,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
 //                      Coriolis, restoring forces from rot's third row), the velocities' Runge-Kutta update.
 // Each needs the other's half of every Runge-Kutta stage state: A the 6 velocities, B the quaternion — handed over through double-
 // buffered LDS with ONE workgroup barrier per stage (2 per step at rk2); the perturbed action travels A -> B once per step, a step ahead.
-// Every row keeps the oracle's operations in the oracle's order (the pieces are the ones auv_state_dot is made of; the cost is summed by
+// Every row keeps the reference's operations in the reference's order (the pieces are the ones auv_state_dot is made of; the cost is summed by
 // wave A alone, in index order): sample costs stay BIT-IDENTICAL to the fp32 CPU restatement.
 // A workgroup is two tiles (4 waves, one per SIMD); roles by the SIMD a wave runs on, as in k_rollout_nnspeed_pc.
 constexpr int kAuvPcThreads = 256;
