@@ -160,11 +160,12 @@ def main():
         learner = m.LearnerBase(model, bufferSize=max(args.steps, 1), logPath=os.path.join(args.log_dir, "learner") if args.log_dir else None)
         trained_steps = 0
         if args.train and args.log_dir:  # resume: the newest weights_step<N> a previous --train run left (weights, normalisation, Adam state)
-            saved = sorted(glob.glob(os.path.join(learner.logdir, "weights_step*")), key=lambda f: int(f.rsplit("step", 1)[1]))
+            saved = sorted((f for f in glob.glob(os.path.join(learner.logdir, "weights_step*")) if f.rsplit("step", 1)[1].isdigit()),
+                           key=lambda f: int(f.rsplit("step", 1)[1]))
             if saved:
                 learner.load_params(saved[-1])
-                trained_steps = learner.step
-                print("resumed the learned model from %s (%d Adam steps so far)" % (saved[-1], trained_steps))
+                learner.step = trained_steps = int(saved[-1].rsplit("step", 1)[1])  # the run's count of training epochs (train_all starts a new Adam every round)
+                print("resumed the learned model from %s (%d training epochs so far)" % (saved[-1], trained_steps))
     sim = AUVSimulation(plant if learned else model, conf.get("x0"), conf["dt"]) if auv else Simulation(conf.get("env"), s_dim, a_dim, None, False,
                                                                                                          dt=conf["dt"], mass=model_dict.get("mass", 1.0))
     cost = get_cost(args.task, conf["lambda"], conf.get("gamma", 1.0), conf.get("upsilon", 1.0), conf["noise"])

@@ -610,6 +610,31 @@ def test_python_entry_point_learns_the_plant_online():
     assert np.isfinite(float(re.search(r"goal_p\| = ([0-9.]+) m", r.stdout).group(1)))
 
 
+def test_python_entry_point_resumes_what_it_learned(tmp_path):
+    """examples/main.py --train N --log_dir D (r04): every training round saves <D>/learner/weights_step<N> (LearnerBase.save_params,
+    learner_base.py:66-68 — weights, normalisation, Adam moments, step count in one flat file) and a second run with the same --log_dir
+    resumes from the newest one: its first training round starts where the first run's last one ended, not from scratch."""
+    import re
+    import subprocess
+    import sys
+    cfgdir = os.path.join(ROOT, "examples", "config")
+    cmd = [sys.executable, os.path.join(ROOT, "examples", "main.py"), "--new", "--config", os.path.join(cfgdir, "uuv_sim.yaml"),
+           "--model", os.path.join(cfgdir, "auv_nn_model.yaml"), "--plant", os.path.join(cfgdir, "rexrov2.yaml"),
+           "--task", os.path.join(cfgdir, "static_task_auv.yaml"), "-s", "80", "-t", "40", "--log_dir", str(tmp_path)]
+    first = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert first.returncode == 0, first.stderr[-2000:]
+    saved = re.findall(r"saved (\S+weights_step(\d+))", first.stdout)
+    assert [int(n) for _, n in saved] == [200, 400] and all(os.path.exists(f) for f, _ in saved), first.stdout
+    assert "resumed" not in first.stdout
+    second = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert second.returncode == 0, second.stderr[-2000:]
+    assert re.search(r"resumed the learned model from \S+weights_step400 \(400 training epochs so far\)", second.stdout), second.stdout
+    l1 = [float(a) for a, _ in re.findall(r"normalised loss ([0-9.e+-]+) -> ([0-9.e+-]+)", first.stdout)]
+    l2 = [float(a) for a, _ in re.findall(r"normalised loss ([0-9.e+-]+) -> ([0-9.e+-]+)", second.stdout)]
+    assert l2[0] < l1[0], (l1, l2)  # the resumed network starts from a trained state, not from scratch
+    assert [int(n) for _, n in re.findall(r"saved (\S+weights_step(\d+))", second.stdout)] == [600, 800]
+
+
 @pytest.mark.parametrize("kind,K,H", [("bf16x3", 300, 7), ("bf16x3", 65, 5), ("speed", 300, 7), ("speed", 1, 3), ("speed", 129, 6), ("speed", 64, 1), ("mfma", 65, 5),
                                       ("mfma", 129, 6), ("mfma", 1, 2)])
 def test_learned_13_state_kernels_with_ragged_tiles(m, kind, K, H):
