@@ -866,3 +866,66 @@ def test_static_quat_cost_at_the_goal_attitude_is_finite(m):
     for _ in range(3):
         assert np.isfinite(hh.next(x)).all()
     assert np.isfinite(hh.get_action_sequence()).all()
+
+
+# ------------------------------------------------------------------------------------------------ random shapes through the two-wave pipelines (r04)
+def _random_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(1, 700)), int(rng.integers(1, 23))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("K,H", _random_shapes(10, 41))
+def test_auv_pipeline_random_shapes_bit_identical(m, G, K, H):
+    """k_rollout_auv_pc at random (K, H) — partial tiles, odd tile counts (the second tile of the last workgroup missing), horizons that are no
+    multiple of the Philox group, down to K = 1 or H = 1 — and a random rk: the fused Philox step's costs bit-identical to the fp32 oracle on the
+    exported noise, its U' within 1e-5 of sigma of the fp64 update."""
+    rk = (1, 2, 4)[(K + H) % 3]
+    P = dict(G["params"], rk=rk)
+    sigma = 200.0 * np.eye(6)
+    ck = dict(goal=GOAL13, Q=np.array([100.0] * 3 + [10.0] * 4 + [1.0] * 6))
+    h = m.Handle(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, auv=P, seed=K, **ck)
+    assert h.rollout_kernel_name() == AUV_KERNELS[False]
+    p32 = orc.Problem(tau=H, s=13, a=6, dt=0.1, lam=1.0, sigma=sigma, auv=P, threads=0, **ck)
+    p64 = orc.Problem(tau=H, s=13, a=6, dt=0.1, lam=1.0, sigma=sigma, auv=P, threads=0, dtype=np.float64, **ck)
+    x0 = np.array([0.5, -0.5, 0.2, 0.0, 0.0, 0.0, 1.0, 0.3, 0.0, -0.1, 0.0, 0.05, 0.0], F32)
+    U = (50.0 * np.random.default_rng(H).standard_normal((H, 6))).astype(F32)
+    h.set_action_sequence(U)
+    u = h.next(x0)
+    c, eps = h.debug_get(m.DBG_COSTS), h.debug_get(m.DBG_NOISE)
+    np.testing.assert_array_equal(c, p32.rollout_cost(x0, U, eps))
+    u64, U64, _ = p64.next_with_noise(x0, U, eps)
+    u32, U32, _ = p32.next_with_noise(x0, U, eps)
+    bar = max(1e-5, 4 * np.abs(np.asarray(U32, np.float64) - U64).max() / 200.0)
+    assert np.abs(h.get_action_sequence() - U64).max() / 200.0 <= bar and np.abs(u - u64).max() / 200.0 <= bar
+
+
+@pytest.mark.parametrize("kind", ["nnauv", "speed16", "speed32"])
+@pytest.mark.parametrize("K,H", _random_shapes(6, 43))
+def test_learned_pipelines_random_shapes(m, kind, K, H):
+    """k_rollout_nnauv_pc / k_rollout_nnspeed_pc<16|32> at random (K, H) and a random number of hidden layers: the fused Philox step against the
+    fp64 oracle on the exported noise (costs 2e-5 relative, U' 1e-5 or 4x the fp32 CPU evaluation's own error)."""
+    n_hidden = 1 + (K + H) % 3
+    sigma = 0.25 * np.eye(6)
+    ck = dict(goal=GOAL13, Q=np.array([10.0] * 3 + [5.0] * 4 + [1.0] * 6))
+    if kind == "nnauv":
+        mlp = make_nnauv(K, 32, n_hidden)
+        mkw, want = dict(nnauv=mlp), "mppi::k_rollout_nnauv_pc<true>"
+    else:
+        hid = 16 if kind == "speed16" else 32
+        mlp = make_nnauv_speed(K, hid, n_hidden)
+        mkw, want = dict(nnauv_speed=mlp), SPEED_KERNELS[0] % hid
+    h = m.Handle(k=K, tau=H, s_dim=13, a_dim=6, dt=0.1, lam=1.0, sigma=sigma, seed=H, **mkw, **ck)
+    assert h.rollout_kernel_name() == want
+    p64 = orc.Problem(tau=H, s=13, a=6, dt=0.1, lam=1.0, sigma=sigma, threads=0, dtype=np.float64, **mkw, **ck)
+    x0 = np.array([0.5, -0.5, 0.2, 0.0, 0.0, 0.0, 1.0, 0.3, 0.0, -0.1, 0.0, 0.05, 0.0], F32)
+    U_in = h.get_action_sequence()
+    u = h.next(x0)
+    noise = h.debug_get(m.DBG_NOISE)
+    np.testing.assert_allclose(noise, orc.noise(H, 0, 0, K, H, 6, sigma), rtol=0, atol=5e-6)
+    u64, U64, c64 = p64.next_with_noise(x0, U_in, noise)
+    p32 = orc.Problem(tau=H, s=13, a=6, dt=0.1, lam=1.0, sigma=sigma, threads=0, **mkw, **ck)
+    _, U32, _ = p32.next_with_noise(x0, U_in, noise)
+    np.testing.assert_allclose(h.debug_get(m.DBG_COSTS), c64, rtol=2e-5)
+    # few samples at lambda = 1: the fp32 CPU evaluation itself is the yardstick where it cannot hold 1e-5 (as for the other learned-model kernels)
+    bar = max(1e-5, 4 * float(np.abs(np.asarray(U32, np.float64) - U64).max()))
+    assert np.abs(h.get_action_sequence() - U64).max() <= bar and np.abs(u - u64).max() <= bar
