@@ -170,9 +170,19 @@ class ShardedController:
         if dist.is_initialized() and self.world > 1 and dist.get_backend(self.group) != "nccl":
             return None, "the job's backend is not RCCL"
         comm, note = None, ""
+        # two votes: ncclCommInitRank is itself a collective — a rank that cannot even load the library must say so BEFORE the others
+        # enter it, or they would wait in it for a rank that never comes
+        try:
+            from .rccl import load
+            load()
+            have = True
+        except Exception as e:
+            have, note = False, "librccl: %s" % e
+        if not self._vote(have):
+            return None, note or "a peer's process holds no librccl"
         try:
             comm = self.backend.make_collectives(self.rank, self.world, self.group)
-        except Exception as e:  # no librccl in the process, ncclCommInitRank refused, ...
+        except Exception as e:  # ncclCommInitRank refused, ...
             note = "RCCL communicator: %s" % e
         if not self._vote(comm is not None):
             if comm is not None:
