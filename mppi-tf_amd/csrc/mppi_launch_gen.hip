@@ -177,7 +177,7 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
             else MPPI_NNAUV32_L(k_rollout_nnauv32_bx3<false>);
         } else if (h->mlp32_valu == 0) { // default (r04): the two-wave pipeline (network wave + cost wave per tile, two tiles per workgroup)
             const int wgs = (h->nb + 1) / 2;
-            const int balance = wgs <= 2 * h->n_cu ? 1 : 0;
+            const int balance = (wgs <= 2 * h->n_cu && !h->pc_no_balance) ? 1 : 0; // (MPPI_TUNE_PC_BALANCE = 0: roles by wave index, A/B)
             if (h->sigma_diag)
                 hipExtLaunchKernelGGL(k_rollout_nnauv_pc<true>, dim3(wgs), dim3(kNnauvPcThreads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,
                                       (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp, h->nb, balance);
@@ -200,7 +200,7 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
         }
         // default: the two-wave pipeline (network wave + pose wave per tile, two tiles per workgroup)
         const int wgs = (h->nb + 1) / 2;
-        const int balance = wgs <= 2 * h->n_cu ? 1 : 0; // SIMD-true roles only while the whole grid is resident in one round
+        const int balance = (wgs <= 2 * h->n_cu && !h->pc_no_balance) ? 1 : 0; // (MPPI_TUNE_PC_BALANCE = 0: roles by wave index, A/B) // SIMD-true roles only while the whole grid is resident in one round
 #define MPPI_NNSPEED_PC_L(KERN)                                                                                                    \
     hipExtLaunchKernelGGL(KERN, dim3(wgs), dim3(kNnspeedPcThreads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG, \
                           (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp, h->nb, balance)
@@ -214,7 +214,7 @@ hipError_t mppi_launch_gen(mppi_handle *h, hipStream_t st, int src, int mode, co
     // and MPPI_TUNE_GEN_ONE_WAVE stay on the one-wave-per-tile kernel
     if (h->hc.model_kind == MPPI_MODEL_AUV && !h->gen_one_wave && (mode == MODE_ROLLOUT || mode == MODE_COST_ONLY) && noise_out == nullptr) {
         const int wgs = (h->nb + 1) / 2;
-        const int balance = wgs <= 2 * h->n_cu ? 1 : 0;
+        const int balance = (wgs <= 2 * h->n_cu && !h->pc_no_balance) ? 1 : 0; // (MPPI_TUNE_PC_BALANCE = 0: roles by wave index, A/B)
         if (h->sigma_diag)
             hipExtLaunchKernelGGL(k_rollout_auv_pc<true>, dim3(wgs), dim3(kAuvPcThreads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC, (const GenConsts *)g->dG,
                                   x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, part, src, mode, 1, h->nbp, h->nb, balance);
