@@ -154,7 +154,6 @@ static bool invert(const float *S, int n, float *out)
 static mppi_status upload_consts(mppi_handle *h)
 {
     HIP_TRY(h, hipMemcpyAsync(h->dC, &h->hc, sizeof(DevConsts), hipMemcpyHostToDevice, h->stream));
-    if (h->dCn) HIP_TRY(h, hipMemcpyAsync(h->dCn, &h->hc, sizeof(DevConsts), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MPPI_OK;
 }
@@ -166,13 +165,12 @@ extern "C" void mppi_destroy(mppi_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     float *bufs[] = {h->d_x, h->d_Ubuf[0], h->d_Ubuf[1], h->d_u, h->d_cost, h->d_cost2, h->d_part, h->d_part2, h->d_part3,
-                     h->d_record, h->d_dbg, h->d_mm, h->d_eps, h->d_recs, h->d_range};
+                     h->d_record, h->d_dbg, h->d_mm, h->d_eps, h->d_recs, h->d_range, h->d_tile_mm};
     for (float *p : bufs) if (p) (void)hipFree(p);
     if (h->d_step) (void)hipFree(h->d_step);
     if (h->dM) (void)hipFree(h->dM);
     if (h->d_mlp_w) (void)hipFree(h->d_mlp_w);
     if (h->dC) (void)hipFree(h->dC);
-    if (h->dCn) (void)hipFree(h->dCn);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->d_clip) (void)hipFree(h->d_clip);
     if (h->d_sg_rows) (void)hipFree(h->d_sg_rows);
@@ -385,7 +383,6 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         HIP_TRY(h, hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
         HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_TRY(h, hipMalloc((void **)&h->dC, sizeof(DevConsts)));
-        if (h->normalize) HIP_TRY(h, hipMalloc((void **)&h->dCn, sizeof(DevConsts)));
         HIP_TRY(h, hipMalloc((void **)&h->d_x, sizeof(float) * kMaxS));
         for (int i = 0; i < 2; ++i) {
             HIP_TRY(h, hipMalloc((void **)&h->d_Ubuf[i], sizeof(float) * (h->HA + h->a)));
@@ -408,6 +405,7 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
         HIP_TRY(h, hipMalloc((void **)&h->d_record, sizeof(float) * (2 + h->HA)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dbg, sizeof(float) * 8));
         HIP_TRY(h, hipMalloc((void **)&h->d_mm, sizeof(float) * 4));
+        if (h->normalize) HIP_TRY(h, hipMalloc((void **)&h->d_tile_mm, sizeof(float) * 2 * (size_t)nrec));
         HIP_TRY(h, hipMalloc((void **)&h->d_step, sizeof(unsigned long long)));
         HIP_TRY(h, hipHostMalloc((void **)&h->h_pin, sizeof(float) * (2 * kMaxS + kMaxA), hipHostMallocMapped));
         HIP_TRY(h, hipHostGetDevicePointer((void **)&h->d_pin, h->h_pin, 0));
@@ -651,21 +649,22 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
     // Py normalizeCost (controller_base.py:468-474): costs, global min/max, then the update on
     // c' = (c-min)/(max-min) with the SAME noise (regenerated from the same Philox counters).
     if (!mlp && !gen && src == SRC_PHILOX && noise_out == nullptr && pc_eligible(h)) {
-        // Fast form on the producer/consumer kernel (r03): exp(-(c' - min c')/lambda) = exp(-(c - min c)/(lambda (max - min))), so the
-        // normalised update is the plain one at another temperature. Pass 1 at lambda for the costs; k_cost_minmax leaves
-        // -1/(lambda (max-min)) in the second DevConsts copy; pass 2 (same Philox counters: the same rollouts) makes the records at that
-        // temperature and the finish combines them at it. 2 x 16 us + 5 instead of the tile kernel's cost pass + record pass (76 -> 40 us at C3).
+        // Fast form on the producer/consumer kernel: exp(-(c' - min c')/lambda) = exp(-(c - min c)/(lambda (max - min))), so the
+        // normalised update is the plain one at another temperature. Pass 1 (PC_PASS_COSTS): the plain pass at lambda for the costs, every tile
+        // leaving its (min, max); pass 2 (PC_PASS_WEIGHTS, r04): no rollouts — the global range from the tile pairs, the weights from the stored
+        // costs, the noise regenerated (same Philox counters) for the weighted sums; records at the range's temperature, which the finish reads
+        // from d_mm[2]. r03: a full second rollout pass with k_cost_minmax between the two (42 us at C3; the tile kernel's two passes 76).
         const bool prof2 = h->prof_n < h->prof_cap;
         h->kev0 = h->kev1 = nullptr;
-        HIP_TRY(h, launch_pc(h, st, x_dev));
-        hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(1024), 0, st, h->d_cost, h->K_local, h->d_mm, h->hc.neg_inv_lambda, &h->dCn->neg_inv_lambda, (float *)nullptr);
-        HIP_TRY(h, hipGetLastError());
+        h->pc_pass = PC_PASS_COSTS;
+        hipError_t le = launch_pc(h, st, x_dev);
+        h->pc_pass = PC_PASS_PLAIN;
+        HIP_TRY(h, le);
         h->kev0 = prof2 ? h->ev[4 * h->prof_n + 0] : nullptr; // a profiled step reports the second pass (the one whose records are used)
         h->kev1 = prof2 ? h->ev[4 * h->prof_n + 1] : nullptr;
-        DevConsts *plain = h->dC;
-        h->dC = h->dCn;
-        const hipError_t le = launch_pc(h, st, x_dev);
-        h->dC = plain;
+        h->pc_pass = PC_PASS_WEIGHTS; h->pc_range_given = 0;
+        le = launch_pc(h, st, x_dev);
+        h->pc_pass = PC_PASS_PLAIN;
         h->kev0 = h->kev1 = nullptr;
         HIP_TRY(h, le);
         h->norm_two_pass = 1;
@@ -864,13 +863,13 @@ extern "C" mppi_status mppi_shard_partial_normalized(mppi_handle *h, const float
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     const bool fast = norm_fast(h);
     h->kev0 = h->kev1 = nullptr;
-    hipLaunchKernelGGL(k_range_apply, dim3(1), dim3(64), 0, st, range_dev, h->d_mm, h->hc.neg_inv_lambda, fast ? &h->dCn->neg_inv_lambda : (float *)nullptr);
+    hipLaunchKernelGGL(k_range_apply, dim3(1), dim3(64), 0, st, range_dev, h->d_mm, h->hc.neg_inv_lambda, (float *)nullptr);
     HIP_TRY(h, hipGetLastError());
-    if (fast) { // the same rollouts again (same Philox counters), records of the raw costs at the temperature of the agreed range
-        DevConsts *plain = h->dC;
-        h->dC = h->dCn;
+    if (fast) { // the weights-only pass (PC_PASS_WEIGHTS) at the temperature of the agreed range (k_range_apply left it in d_mm[2]): the costs of
+                // mppi_shard_cost_range, the noise regenerated from the same Philox counters, records of the raw costs at that temperature
+        h->pc_pass = PC_PASS_WEIGHTS; h->pc_range_given = 1;
         const hipError_t le = launch_pc(h, st, x_dev);
-        h->dC = plain;
+        h->pc_pass = PC_PASS_PLAIN; h->pc_range_given = 0;
         HIP_TRY(h, le);
         h->norm_two_pass = 1;
     } else { // d_cost still holds this step's costs (mppi_shard_cost_range)
@@ -1283,8 +1282,9 @@ extern "C" mppi_status mppi_debug_get(mppi_handle *h, int what, float *out, size
         if (n != need) return fail(h, MPPI_ERR_INVALID_ARG, "wrong output size");
         HIP_TRY(h, hipMalloc((void **)&tmp, sizeof(float) * K));
         // (two-pass normalizeCost: the raw costs at the step's temperature = the normalised costs at lambda)
-        hipLaunchKernelGGL(k_weights, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, h->stream, h->norm_two_pass ? h->dCn : h->dC,
-                           (h->normalize && !h->norm_two_pass) ? h->d_cost2 : h->d_cost, (int)K, h->d_dbg, (float *)nullptr, (float *)nullptr, tmp);
+        hipLaunchKernelGGL(k_weights, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, h->stream, (const DevConsts *)h->dC,
+                           (h->normalize && !h->norm_two_pass) ? h->d_cost2 : h->d_cost, (int)K, h->d_dbg, (float *)nullptr, (float *)nullptr, tmp,
+                           h->norm_two_pass ? (const float *)(h->d_mm + 2) : (const float *)nullptr);
         src = tmp;
         break;
     }
@@ -1505,7 +1505,7 @@ extern "C" mppi_status mppi_update(mppi_handle *h, const float *cost, const floa
     HIP_TRY(h, launch_finish(h, h->stream, h->d_part, 1, h->nbp, h->nbp, dU.p, dUn.p, du.p, drec.p, 1));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_step, &step_before, sizeof(step_before), hipMemcpyHostToDevice, h->stream)); // stateless call
-    hipLaunchKernelGGL(k_weights, dim3((K + 255) / 256), dim3(256), 0, h->stream, h->dC, dc.p, K, drec.p, darg.p, dexp.p, dw.p);
+    hipLaunchKernelGGL(k_weights, dim3((K + 255) / 256), dim3(256), 0, h->stream, h->dC, dc.p, K, drec.p, darg.p, dexp.p, dw.p, (const float *)nullptr);
     HIP_TRY(h, hipGetLastError());
     std::vector<float> rec(2 + HA), Un(HA);
     HIP_TRY(h, drec.down(rec.data(), 2 + HA, h->stream));

@@ -19,7 +19,6 @@ struct mppi_handle {
     DevConsts hc{};
     DevConsts *dC = nullptr;
     int norm_two_pass = 0;    // this step's records come from the second pass of the two-pass normalizeCost path (set per step)
-    DevConsts *dCn = nullptr; // normalize_cost: a second copy whose neg_inv_lambda k_cost_minmax rewrites every step (the second pass reads it)
     int K_global = 0, K_local = 0, k_offset = 0, shard_rank = 0, shard_count = 1;
     int H = 0, s = 0, a = 0, HA = 0;
     int R = 64, nb = 0;   // tile size / record count of the point-mass tile kernels
@@ -39,6 +38,9 @@ struct mppi_handle {
     int normalize = 0;
     int sigma_diag = 0; // Σ and Σ⁻¹ are exactly diagonal (the DIAG kernel instances are bit-identical then)
     int pc_np = 5;      // producer waves per workgroup of k_rollout_pc (chosen by tiles per CU; MPPI_TUNE_PC_PRODUCERS overrides)
+    int pc_pass = 0;    // which pass of k_rollout_pc the next launch_pc is: 0 the step's one pass, 1 / 2 the two passes of normalizeCost (set per launch by mppi_capi.hip)
+    int pc_range_given = 0; // the weights-only pass takes its temperature from d_mm[2] (a K-sharded handle: the ranks agreed on the range) instead of reducing d_tile_mm
+    float *d_tile_mm = nullptr; // normalize_cost: every tile's (min, max) cost of the first pass, [2][nbp]
     // diagnostic switches, set only through mppi_set_tuning (the library reads no environment variable)
     int force_tile = 0;   // MPPI_TUNE_FORCE_TILE_KERNEL: the LDS-tile kernel instead of the producer/consumer one (A/B timing)
     int pc_no_balance = 0; // MPPI_TUNE_PC_BALANCE = 0: no SIMD-true roles / progress priorities

@@ -210,11 +210,22 @@ __host__ __device__ inline size_t pc_lds_floats(int A, int NP) { return (size_t)
 // COST: the cost_base form of the consumer — 0 quadratic with a diagonal Q (the BASELINE configurations), 1 ElipseCost (s >= 4),
 // 2 quadratic with a dense Q. A template parameter, so the instances of the hot configuration are what they were.
 enum { PC_COST_DIAG = 0, PC_COST_ELLIPSE = 1, PC_COST_DENSE = 2 };
-template <int A, int NP, int NSLOT, bool DIAG, int COST = PC_COST_DIAG>
+// PASS (r04): the two passes of the Python reference's normalizeCost=True (controller_base.py:468-474: c' = (c - min c)/(max c - min c) before the
+// soft-min) on this kernel. The normalised update is the plain one at the temperature lambda (max - min) (exp(-(c' - min c')/lambda) =
+// exp(-(c - min c)/(lambda (max - min)))), which needs every cost before any weight:
+//   PC_PASS_PLAIN (0)   the step's one pass (every BASELINE configuration: these instances are what they were);
+//   PC_PASS_COSTS (1)   pass 1: the plain pass, and the consumer also leaves its tile's (min, max) cost in tile_mm[b], tile_mm[rsc + b];
+//   PC_PASS_WEIGHTS (2) pass 2: NO rollouts — every workgroup reduces the tile pairs to the global range (the same values in the same order
+//                       everywhere: the same bits), the consumer takes its costs from `cost`, the producers regenerate the noise (same Philox
+//                       counters) for the weighted sums; records at the range's temperature. tile_mm == NULL: the temperature is already in
+//                       mm_out[2] (a K-sharded handle, whose range the ranks agreed on). Replaces a full second rollout pass and the
+//                       single-workgroup k_cost_minmax launch between the two (42 -> 33 us per normalised step at configs[2]'s shape).
+enum { PC_PASS_PLAIN = 0, PC_PASS_COSTS = 1, PC_PASS_WEIGHTS = 2 };
+template <int A, int NP, int NSLOT, bool DIAG, int COST = PC_COST_DIAG, int PASS = PC_PASS_PLAIN>
 __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) void k_rollout_pc(
     const DevConsts *__restrict__ C, const float *__restrict__ x_dev, const float *__restrict__ U_dev,
     const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
-    const int rsb, const int rsc, const int balance)
+    const int rsb, const int rsc, const int balance, float *__restrict__ tile_mm, float *__restrict__ mm_out)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 2 * A;
@@ -259,6 +270,24 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
     const bool valid = (k0 + lane) < K;
     float *rec = partials + (size_t)record_slot(blockIdx.x, rsc) * rsb; // element (b, col) at partials[b*rsb + col*rsc]
     MPPI_TL_WHERE(wave);
+    float nil_range = 0.0f; // PC_PASS_WEIGHTS: -1/(lambda (max - min)) over ALL tiles
+    if constexpr (PASS == PC_PASS_WEIGHTS) {
+        if (tile_mm != nullptr) {
+            __shared__ float mn_s[NW], mx_s[NW];
+            float mn = INFINITY, mx = -INFINITY;
+            for (int i = tid; i < (int)gridDim.x; i += 64 * NW) { mn = fminf(mn, tile_mm[i]); mx = fmaxf(mx, tile_mm[rsc + i]); }
+            mn = wave_min(mn); mx = wave_max(mx);
+            if (lane == 0) { mn_s[wave_hw] = mn; mx_s[wave_hw] = mx; }
+            __syncthreads();
+            mn = mn_s[0]; mx = mx_s[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) { mn = fminf(mn, mn_s[w]); mx = fmaxf(mx, mx_s[w]); }
+            nil_range = C->neg_inv_lambda / (mx - mn); // k_cost_minmax's expression
+            if (blockIdx.x == 0 && tid == 0) { mm_out[0] = mn; mm_out[1] = mx - mn; mm_out[2] = nil_range; } // what the finish and the weights' export read
+        } else {
+            nil_range = mm_out[2];
+        }
+    }
 
     if (wave != 0) {
         // ------------------------------------------------------------------ producers
@@ -275,7 +304,20 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
             constexpr int i = decltype(ic)::value;
             const int g = NP * i + p;
             if (balance) pc_set_prio(i, nch, gen);
-            if (i < nch) { // chunk i exists (wave-uniform)
+            if (PASS == PC_PASS_WEIGHTS && i < nch && g < NG) { // the noise alone: nothing is published, no chunk barrier
+                float z[4 * A];
+                MPPI_NORMALS_GROUP_UB(A, seed, gk, base + (unsigned long long)g, z);
+#pragma unroll
+                for (int tl = 0; tl < 4; ++tl) {
+                    float zz[A], e[A];
+#pragma unroll
+                    for (int j = 0; j < A; ++j) zz[j] = z[tl * A + j];
+                    scale_noise<A, DIAG>(PC, zz, e);
+#pragma unroll
+                    for (int j = 0; j < A; ++j) eps_r[(i * 4 + tl) * A + j] = e[j];
+                }
+            }
+            if (PASS != PC_PASS_WEIGHTS && i < nch) { // chunk i exists (wave-uniform)
                 float *cb = buf + (i & 1) * CH + (size_t)(4 * p) * SLOT * 64;
                 if (g < NG) {
                     // the nominal actions of the group's 4 steps: scalar loads issued ahead of the Philox rounds that
@@ -365,6 +407,8 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
         float c = 0.0f;
         MPPI_STAMP(0);
         MPPI_STAMP_RT(62);
+        if constexpr (PASS == PC_PASS_WEIGHTS) c = cost[valid ? k0 + lane : 0]; // pass 1 left this step's costs there
+        if constexpr (PASS != PC_PASS_WEIGHTS) {
         __syncthreads(); // chunk 0 published
         MPPI_STAMP(1);
         for (int ch = 0; ch < nch; ++ch) {
@@ -395,9 +439,14 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
         }
         c = c + cost_of(x); // terminal: x_H counted a second time, :271-272
         MPPI_STORE_COST(valid, cost + k0 + lane, c);
+        } // PASS != PC_PASS_WEIGHTS
         // tile-local mBeta / mExpArg / mExp / mNabla (controller_base.cpp:166-182)
         const float beta = wave_min(valid ? c : INFINITY);
-        const float arg = CC->neg_inv_lambda * (c - beta);
+        if constexpr (PASS == PC_PASS_COSTS) { // the tile's cost range for the second pass
+            const float cmax = wave_max(valid ? c : -INFINITY);
+            if (lane == 0) { tile_mm[blockIdx.x] = beta; tile_mm[(size_t)rsc + blockIdx.x] = cmax; }
+        }
+        const float arg = (PASS == PC_PASS_WEIGHTS ? nil_range : CC->neg_inv_lambda) * (c - beta);
         const float ek = valid ? expf(arg) : 0.0f;
         const float eta = wave_sum(ek);
         w_s[lane] = ek;
@@ -1063,11 +1112,12 @@ __global__ void k_cost_normalize(const float *__restrict__ cost, int K, const fl
 #if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
 __global__ void k_weights(const DevConsts *__restrict__ C, const float *__restrict__ cost, int K,
                           const float *__restrict__ beta_eta, float *__restrict__ arg_out,
-                          float *__restrict__ exp_out, float *__restrict__ w_out)
+                          float *__restrict__ exp_out, float *__restrict__ w_out, const float *__restrict__ nil_dev)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
-    const float arg = C->neg_inv_lambda * (cost[i] - beta_eta[0]);
+    // (nil_dev: the step's temperature of the two-pass normalizeCost path, d_mm[2])
+    const float arg = (nil_dev != nullptr ? nil_dev[0] : C->neg_inv_lambda) * (cost[i] - beta_eta[0]);
     const float e = expf(arg);
     if (arg_out) arg_out[i] = arg;
     if (exp_out) exp_out[i] = e;

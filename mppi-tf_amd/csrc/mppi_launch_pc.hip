@@ -5,8 +5,8 @@
 #endif
 
 // the hot configuration: producer/consumer kernel (k_rollout_pc) when the horizon fits its register file
-template <int A, int NP, int NSLOT, int COST>
-static hipError_t launch_pc_cost(mppi_handle *h, hipStream_t st, const float *x_dev)
+template <int A, int NP, int NSLOT, int COST, int PASS>
+static hipError_t launch_pc_pass(mppi_handle *h, hipStream_t st, const float *x_dev)
 {
     const size_t lds = std::max(pc_lds_floats(A, NP) * 4, (size_t)h->pc_lds_min);
     const int nb = (h->K_local + 63) / 64;
@@ -17,10 +17,21 @@ static hipError_t launch_pc_cost(mppi_handle *h, hipStream_t st, const float *x_
     const DevConsts *dC = h->dC;
     const float *U = h->U_cur();
     const unsigned long long *stp = h->d_step;
-    if (hipError_t e = mppi_raise_lds_ceiling(h->sigma_diag ? reinterpret_cast<const void *>(k_rollout_pc<A, NP, NSLOT, true, COST>) : reinterpret_cast<const void *>(k_rollout_pc<A, NP, NSLOT, false, COST>), h->device, lds); e != hipSuccess) return e;
-    if (h->sigma_diag) hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true, COST>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
-    else hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false, COST>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance);
+    float *tile_mm = (PASS == PC_PASS_WEIGHTS && h->pc_range_given) ? nullptr : h->d_tile_mm; // (sharded: the agreed range is already in d_mm)
+    if (hipError_t e = mppi_raise_lds_ceiling(h->sigma_diag ? reinterpret_cast<const void *>(k_rollout_pc<A, NP, NSLOT, true, COST, PASS>) : reinterpret_cast<const void *>(k_rollout_pc<A, NP, NSLOT, false, COST, PASS>), h->device, lds); e != hipSuccess) return e;
+    if (h->sigma_diag) hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, true, COST, PASS>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance, tile_mm, h->d_mm);
+    else hipExtLaunchKernelGGL((k_rollout_pc<A, NP, NSLOT, false, COST, PASS>), g, b, (uint32_t)lds, st, h->kev0, h->kev1, 0, dC, x_dev, U, stp, h->d_cost, h->d_part, 1, h->nbp, balance, tile_mm, h->d_mm);
     return hipGetLastError();
+}
+
+// h->pc_pass: PC_PASS_PLAIN, or the two passes of normalizeCost (mppi_capi.hip sets it around its launches). The weights-only pass evaluates no
+// state cost: ONE instance (the diagonal-Q one) serves every cost form.
+template <int A, int NP, int NSLOT, int COST>
+static hipError_t launch_pc_cost(mppi_handle *h, hipStream_t st, const float *x_dev)
+{
+    if (h->pc_pass == PC_PASS_WEIGHTS) return launch_pc_pass<A, NP, NSLOT, PC_COST_DIAG, PC_PASS_WEIGHTS>(h, st, x_dev);
+    if (h->pc_pass == PC_PASS_COSTS) return launch_pc_pass<A, NP, NSLOT, COST, PC_PASS_COSTS>(h, st, x_dev);
+    return launch_pc_pass<A, NP, NSLOT, COST, PC_PASS_PLAIN>(h, st, x_dev);
 }
 
 // the consumer's cost form: diagonal Q (the hot configuration), ElipseCost (elipse_cost.py:9-85; s >= 4), dense Q (static_cost.py:23-63)
