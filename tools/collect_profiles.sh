@@ -27,6 +27,7 @@ for SPEC in "$@"; do
   # the stats pass times the kernel in steady state: batches repeated for 0.3 s, as bench.py's timed region does (a 100-step run alone is over
   # before the clocks have ramped: 18.1 us for the headline kernel against 15.7-16.0 us here, profiles/r04_philox_ab_rocprofv3.txt)
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- ${BENCH/--min-time 0/--min-time 0.3} > $D/stats.log 2>&1
+  find $D/stats -name '*kernel_trace.csv' -delete   # tens of thousands of dispatch rows: only the stats summary travels back (gpurun merges <= 64 MiB)
   # VALU instructions by class (the issue-rate floor) and the busy cycles of the issue ports: own passes
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --kernel-trace --output-format csv -d $D/pmc_sq2 -- $BENCH > $D/pmc_sq2.log 2>&1
   rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC --kernel-trace --output-format csv -d $D/pmc_sq3 -- $BENCH > $D/pmc_sq3.log 2>&1
