@@ -376,7 +376,7 @@ mppi_status mppi_profile_begin(mppi_handle *h, int max_steps);
  * n_steps recorded steps (any output may be NULL). Both are the dispatches' own begin/end (what rocprofv3 reports). */
 mppi_status mppi_profile_end(mppi_handle *h, float *rollout_ms_avg, float *finish_ms_avg, int *n_steps);
 /* Name of the rollout kernel instance a fused step of this handle launches, as rocprofv3 prints it
- * (e.g. "mppi::k_rollout_pc<3, 3, 6, true>"): what a roofline figure of this handle refers to. */
+ * (e.g. "mppi::k_rollout_pc<3, 3, 6, true, 0, 0>"): what a roofline figure of this handle refers to. */
 mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf, size_t n);
 
 /* ---- the learner of the learned model_base (replaces LearnerBase.train / _train_step, learners/learner_base.py:324-358,

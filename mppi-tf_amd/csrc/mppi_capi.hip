@@ -722,8 +722,9 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
     else if (pc_eligible(h)) // (normalizeCost: two passes of it on the fused path; injected noise runs the tile kernel)
     {
         const int ck = h->hc.state_cost_kind == MPPI_STATE_COST_ELLIPSE ? 1 : (h->hc.q_full ? 2 : 0); // PC_COST_* (spelled out as the profiler spells it)
-        std::snprintf(buf, n, "mppi::k_rollout_pc<%d, %d, %d, %s, %d>", h->a, h->pc_np,
-                      h->pc_np == 3 ? (NG <= 18 ? 6 : 11) : (NG <= 20 ? 4 : 8), h->sigma_diag ? "true" : "false", ck);
+        // (normalizeCost: the records come from the weights-only second pass, PC_PASS_WEIGHTS = 2, whose one instance is the diagonal-Q one)
+        std::snprintf(buf, n, "mppi::k_rollout_pc<%d, %d, %d, %s, %d, %d>", h->a, h->pc_np,
+                      h->pc_np == 3 ? (NG <= 18 ? 6 : 11) : (NG <= 20 ? 4 : 8), h->sigma_diag ? "true" : "false", h->normalize ? 0 : ck, h->normalize ? 2 : 0);
     }
     else
         std::snprintf(buf, n, "mppi::k_rollout_tile<%d, %d, %s, 0, %d>", h->a, h->R, h->hc.q_full ? "true" : "false", h->normalize ? 2 : 0);
