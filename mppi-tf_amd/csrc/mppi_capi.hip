@@ -662,9 +662,16 @@ static mppi_status enqueue_partials(mppi_handle *h, hipStream_t st, int src, con
         HIP_TRY(h, le);
         h->kev0 = prof2 ? h->ev[4 * h->prof_n + 0] : nullptr; // a profiled step reports the second pass (the one whose records are used)
         h->kev1 = prof2 ? h->ev[4 * h->prof_n + 1] : nullptr;
-        h->pc_pass = PC_PASS_WEIGHTS; h->pc_range_given = 0;
+        // every workgroup of the second pass reduces the nb tile pairs itself: nb^2 x 8 bytes of L2 reads in all — 8 MB at 1024 tiles, too much
+        // beyond a few thousand (K > 131072 on one GPU): there the range comes from ONE k_cost_minmax launch over the costs instead
+        const int many_tiles = h->nb > 2048;
+        if (many_tiles) {
+            hipLaunchKernelGGL(k_cost_minmax, dim3(1), dim3(1024), 0, st, h->d_cost, h->K_local, h->d_mm, h->hc.neg_inv_lambda, h->d_mm + 3, (float *)nullptr);
+            HIP_TRY(h, hipGetLastError());
+        }
+        h->pc_pass = PC_PASS_WEIGHTS; h->pc_range_given = many_tiles;
         le = launch_pc(h, st, x_dev);
-        h->pc_pass = PC_PASS_PLAIN;
+        h->pc_pass = PC_PASS_PLAIN; h->pc_range_given = 0;
         h->kev0 = h->kev1 = nullptr;
         HIP_TRY(h, le);
         h->norm_two_pass = 1;

@@ -218,7 +218,8 @@ def test_next_with_noise_normalize_cost(m):
     np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=U_TOL)
 
 
-@pytest.mark.parametrize("K,H,a,lam", [(2000, 20, 3, 0.05), (65536, 64, 3, 1.0), (4096, 32, 2, 0.2), (300, 7, 1, 0.1), (512, 24, 4, 0.5)])
+@pytest.mark.parametrize("K,H,a,lam", [(2000, 20, 3, 0.05), (65536, 64, 3, 1.0), (4096, 32, 2, 0.2), (300, 7, 1, 0.1), (512, 24, 4, 0.5),
+                                       (140000, 8, 3, 0.3)])  # (2188 tiles: past 2048 the range comes from one k_cost_minmax launch, r04)
 def test_normalize_cost_on_the_fused_path(m, K, H, a, lam):
     """normalizeCost=True on the fused Philox path (what scripts/main.py builds, controller_base.py:468-474). For the point-mass / diagonal-Q
     configuration this is TWO passes of the producer/consumer kernel: exp(-(c'-min c')/lambda) = exp(-(c-min c)/(lambda (max-min))), so the
