@@ -356,7 +356,7 @@ def test_producer_consumer_kernel_with_the_other_cost_forms(m, K, H, a, kind):
     mk = lambda **t: m.Handle(k=K, tau=H, s_dim=s, a_dim=a, lam=1.0, sigma=0.25 * np.eye(a), goal=(GOAL3 + [0.25, 0])[:s], seed=5,
                               Q=kw.get("Q"), q_is_full=kw.get("q_full"), ellipse=kw.get("ellipse"), **t)
     hp, ht = mk(), mk(tuning={"force_tile_kernel": 1})
-    assert hp.rollout_kernel_name().endswith(", 2>" if kind == "dense" else ", 1>") and mk(tuning=None).rollout_kernel_name() != "" and "k_rollout_tile" in ht.rollout_kernel_name()
+    assert hp.rollout_kernel_name().endswith(", 2, 0>" if kind == "dense" else ", 1, 0>") and mk(tuning=None).rollout_kernel_name() != "" and "k_rollout_tile" in ht.rollout_kernel_name()
     p32 = orc.Problem(tau=H, s=s, a=a, lam=1.0, sigma=0.25 * np.eye(a), goal=(GOAL3 + [0.25, 0])[:s], threads=0, **okw)
     for _ in range(2):
         U_in = hp.get_action_sequence()
