@@ -1011,6 +1011,12 @@ __global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnspeed32(
 // A workgroup is TWO tiles (4 waves, one per SIMD); the role comes from the SIMD a wave runs on, flipped for every second workgroup of a
 // CU, so that each SIMD hosts one N and one P wave (as k_rollout_pc places its consumer; falls back to the wave index).
 // Same arithmetic per rollout as k_rollout_nnspeed32 (the output layer's half sums in the same order): same bars.
+// HID = 16 (the reference's NNAUVModelSpeed: Dense(16) x 3) takes v_mfma_f32_16x16x4_f32 tiles: on 32x32x2 tiles half of every layer's 32
+// rows are empty — 48 MFMAs of 64 cycles per tile and step, 3072 of ~8200 cycles. 16 units x 16 rollouts x 4 inputs per instruction, four
+// column blocks per wave, 32 cycles each: 48 MFMAs, 1536 cycles. Lane (n, g): D register i = unit 4 g + i of rollout n — again the next
+// layer's B operand as it stands (k slot (s, g) = unit 4 g + s: the weights are loaded in that order). Inputs reach the four column blocks by
+// a 4 x 4 transpose of 16-lane rows per k step (2 v_permlane32_swap + 2 v_permlane16_swap), the 6 outputs come back by the same butterfly
+// with sums. Through builtins: with 4-register accumulators hipcc's own allocation and hazard padding are fine (145 VGPRs). 0.222 -> 0.192 ms.
 constexpr int kNnspeedPcThreads = 256;
 struct GenQuadConsts { // kernel-local copy of the diagonal quadratic cost (no constant re-fetch behind the per-step barrier)
     float goal[kGenS], qdiag[kGenS];
@@ -1025,6 +1031,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
 {
     static_assert(HID == 16 || HID == 32, "Dense(16) or Dense(32) hidden layers");
     constexpr int S = kGenS, A = kGenA, NIN = kGenSpeedNin, NOUT = 6, K1H = 8, NP = HID / 2, W3LD = 8;
+    constexpr bool MF16 = HID == 16; // Dense(16) layers on v_mfma_f32_16x16x4_f32 (no half-empty 32-row tiles)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float w3_s[HID * W3LD]; // output-layer rows [unit][6 outputs + 2 zeros]
@@ -1070,11 +1077,37 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
         const unsigned long long gk = (unsigned long long)C->k_offset + (unsigned long long)kk;
         auto unit_of = [](int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); };
         const bool row_live = j < HID; // lane (j, hh) supplies row j of the A operand: output unit j of the layer
-        float a1[K1H];
+        // 32x32x2 tiles (HID = 32): weights as (even, odd) k pairs in the lane halves
+        float a1[MF16 ? 1 : K1H];
+        f32x16 b1t, bht[2];
+        float ah[2][MF16 ? 1 : NP];
+        // 16x16x4 tiles (HID = 16): lane = (m = lane & 15, g = lane >> 4). A operand of k step s: W[input of slot (s, g)][unit m]; layer 1 takes
+        // input 4 s + g, a hidden layer unit 4 g + s — where register s of the previous layer's accumulators holds its units (D register i of
+        // lane (n, g) = unit 4 g + i of rollout n): the accumulators ARE the next layer's B operands, as on the 32-wide tiles
+        const int m16 = lane & 15, g16 = lane >> 4;
+        float a1q[4], ahq[2][4], w3q[4][NOUT];
+        f32x4 b1q, bhq[2];
+        if constexpr (MF16) {
+#pragma unroll
+            for (int s1 = 0; s1 < 4; ++s1) a1q[s1] = 4 * s1 + g16 < NIN ? M->Wl[0][(4 * s1 + g16) * HID + m16] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b1q[i] = M->bl[0][4 * g16 + i];
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const bool have = l + 2 <= n_hidden;
+                const float *Wl = have ? M->Wl[l + 1] : M->Wl[0], *bl = have ? M->bl[l + 1] : M->bl[0];
+#pragma unroll
+                for (int s1 = 0; s1 < 4; ++s1) ahq[l][s1] = have ? Wl[(4 * g16 + s1) * HID + m16] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bhq[l][i] = have ? bl[4 * g16 + i] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) w3q[i][o] = W3g[(4 * g16 + i) * ld3 + o];
+        } else {
 #pragma unroll
         for (int s1 = 0; s1 < K1H; ++s1) a1[s1] = (row_live && 2 * s1 + hh < NIN) ? M->Wl[0][(2 * s1 + hh) * HID + j] : 0.0f;
-        f32x16 b1t, bht[2];
-        float ah[2][NP];
 #pragma unroll
         for (int r = 0; r < 16; ++r) b1t[r] = unit_of(r, hh) < HID ? M->bl[0][unit_of(r, hh)] : 0.0f;
 #pragma unroll
@@ -1085,6 +1118,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
             for (int s1 = 0; s1 < NP; ++s1) ah[l][s1] = (have && row_live) ? Wl[unit_of(s1, hh) * HID + j] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) bht[l][r] = (have && unit_of(r, hh) < HID) ? bl[unit_of(r, hh)] : 0.0f;
+        }
         }
         const float *b3g = M->bl[n_hidden];
         float xm[NIN + 1], xr[NIN + 1], b3v[NOUT], ysd[NOUT], ymn[NOUT];
@@ -1154,6 +1188,59 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
 #pragma unroll
                     for (int i = 0; i < 6; ++i) { in[3 + i] = vel[i]; in[9 + i] = v[i]; }
                     in[NIN] = 0.0f;
+                    if constexpr (MF16) {
+                        // B operands of the four 16-rollout column blocks: per k step a 4 x 4 transpose of 16-lane rows across four registers
+                        // (inputs 4 s .. 4 s + 3 of the lane's rollout -> input 4 s + g of rollout 16 c + n in lane (n, g) of register c)
+                        auto relu16 = [](float v) { return __int_as_float(max(__float_as_int(v), 0)); }; // ONE v_max_i32: a float below zero (and -0) is a negative int; fmaxf costs a canonicalising v_max_f32 first, and so does a v_med3_f32 hipcc recognises
+                        f32x4 acc[4];
+#pragma unroll
+                        for (int s1 = 0; s1 < 4; ++s1) {
+                            float xq[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) xq[q] = (in[4 * s1 + q] - xm[4 * s1 + q]) * xr[4 * s1 + q];
+                            permlane32_swap(xq[0], xq[2]);
+                            permlane32_swap(xq[1], xq[3]);
+                            permlane16_swap(xq[0], xq[1]);
+                            permlane16_swap(xq[2], xq[3]);
+#pragma unroll
+                            for (int c4 = 0; c4 < 4; ++c4)
+                                acc[c4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1q[s1], xq[c4], s1 == 0 ? b1q : acc[c4], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int l = 0; l < 2; ++l) {
+                            if (l + 2 <= n_hidden) { // (wave-uniform)
+                                f32x4 nxt[4];
+#pragma unroll
+                                for (int s1 = 0; s1 < 4; ++s1)
+#pragma unroll
+                                    for (int c4 = 0; c4 < 4; ++c4)
+                                        nxt[c4] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahq[l][s1], relu16(acc[c4][s1]), s1 == 0 ? bhq[l] : nxt[c4], 0, 0, 0);
+#pragma unroll
+                                for (int c4 = 0; c4 < 4; ++c4) acc[c4] = nxt[c4];
+                            }
+                        }
+                        // output layer: the lane's four units of each column block, then the sum over the four lane groups, transposed back to
+                        // lane = rollout (two swap levels: the butterfly of the input transpose run backwards)
+                        float part[4][NOUT];
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float hv = relu16(acc[c4][i]);
+#pragma unroll
+                                for (int o = 0; o < NOUT; ++o) part[c4][o] = i == 0 ? hv * w3q[i][o] : fmaf(hv, w3q[i][o], part[c4][o]);
+                            }
+#pragma unroll
+                        for (int o = 0; o < NOUT; ++o) {
+                            float p0 = part[0][o], p1 = part[1][o], p2 = part[2][o], p3 = part[3][o];
+                            permlane32_swap(p0, p2); // p0 = [c0 g0, c0 g1, c2 g0, c2 g1], p2 = [c0 g2, c0 g3, c2 g2, c2 g3]
+                            permlane32_swap(p1, p3);
+                            float s02 = p0 + p2, s13 = p1 + p3; // rows: (c0: g0+g2, c0: g1+g3, c2: .., c2: ..) and the same of c1 / c3
+                            permlane16_swap(s02, s13);           // s02 = [c0, c1, c2, c3] (g0+g2), s13 = [c0, c1, c2, c3] (g1+g3)
+                            const float y = (s02 + s13) + b3v[o];
+                            vel[o] = vel[o] + (y * ysd[o] + ymn[o]);
+                        }
+                    } else {
                     float ba[K1H], bb[K1H];
 #pragma unroll
                     for (int s1 = 0; s1 < K1H; ++s1) {
@@ -1176,6 +1263,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                         }
                     } else {
                         finish(accA, accB);
+                    }
                     }
 #pragma unroll
                     for (int i = 0; i < 6; ++i) vel_s[pair][t & 1][i][lane] = vel[i];

@@ -58,6 +58,11 @@ __device__ __forceinline__ void permlane32_swap(float &a, float &b)
 {
     asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+// the odd 16-lane rows of a <-> the even 16-lane rows of b (v_permlane16_swap)
+__device__ __forceinline__ void permlane16_swap(float &a, float &b)
+{
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 
 template <int A, bool DIAG, int SRC>
 __global__ __launch_bounds__(kMlp2Threads, 1) void k_rollout_mlp2(
