@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnspeed32(
 // column blocks per wave, 32 cycles each: 48 MFMAs, 1536 cycles. Lane (n, g): D register i = unit 4 g + i of rollout n — again the next
 // layer's B operand as it stands (k slot (s, g) = unit 4 g + s: the weights are loaded in that order). Inputs reach the four column blocks by
 // a 4 x 4 transpose of 16-lane rows per k step (2 v_permlane32_swap + 2 v_permlane16_swap), the 6 outputs come back by the same butterfly
-// with sums. Through builtins: with 4-register accumulators hipcc's own allocation and hazard padding are fine (145 VGPRs). 0.222 -> 0.192 ms.
+// with sums. Through builtins: with 4-register accumulators hipcc's own allocation and hazard padding are fine (145 VGPRs); the relu on an accumulator is ONE v_max_i32. 0.222 -> 0.188 ms.
 constexpr int kNnspeedPcThreads = 256;
 struct GenQuadConsts { // kernel-local copy of the diagonal quadratic cost (no constant re-fetch behind the per-step barrier)
     float goal[kGenS], qdiag[kGenS];
