@@ -356,7 +356,8 @@ enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instea
        MPPI_TUNE_SYNC_SPIN = 4,         /* 0: mppi_next waits for the stream instead of watching the pinned u slot      */
        MPPI_TUNE_P2P_FAULT = 5,         /* 1: inbox export fails, 2: probe reports failure (exercise the RCCL fallback) */
        MPPI_TUNE_MLP_V1 = 6,            /* 1: exact-fp32 MLP rollouts on the first kernel (8 waves per workgroup) instead of k_rollout_mlp2 */
-       MPPI_TUNE_MLP32_VALU = 7,        /* 1: a Dense(32) network on k_rollout_mlp_small (vector ALU, scalar-cache weights) instead of k_rollout_mlp32 (matrix cores);
+       MPPI_TUNE_MLP32_VALU = 7,        /* a Dense(32) point-mass network: 1 = k_rollout_mlp_small (vector ALU, scalar-cache weights), 2 = k_rollout_mlp32 (matrix cores, one wave
+                                           per 32 rollouts) instead of k_rollout_mlp32_pc (matrix cores, network wave + cost wave per tile);
                                            NNAUVModelSpeed (Dense(16|32)): 1 = k_rollout_gen<2, HID> (vector ALU), 2 = k_rollout_nnspeed32<HID> (matrix cores, one wave per
                                            32 rollouts) instead of k_rollout_nnspeed_pc<HID> (matrix cores, network wave + pose wave per tile); NNAUVModel Dense(32):
                                            1 = k_rollout_gen<1, 32>, 2 = k_rollout_nnauv32 instead of k_rollout_nnauv_pc (network wave + cost wave per tile) */

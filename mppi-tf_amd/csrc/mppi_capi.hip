@@ -721,7 +721,8 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
     if (h->is_gen) std::snprintf(buf, n, "%s", mppi_gen_kernel_name(h));
     else if (h->hc.model_kind == MPPI_MODEL_MLP)
         if (h->mlp_small == 32 && h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp32_bx3<%d>", h->a);
-        else if (h->mlp_small == 32 && !h->mlp32_valu) std::snprintf(buf, n, "mppi::k_rollout_mlp32<%d>", h->a);
+        else if (h->mlp_small == 32 && h->mlp32_valu == 0) std::snprintf(buf, n, "mppi::k_rollout_mlp32_pc<%d, %s>", h->a, h->sigma_diag ? "true" : "false");
+        else if (h->mlp_small == 32 && h->mlp32_valu == 2) std::snprintf(buf, n, "mppi::k_rollout_mlp32<%d>", h->a);
         else if (h->mlp_small) std::snprintf(buf, n, "mppi::k_rollout_mlp_small<%d, %d>", h->a, h->mlp_small);
         else if (h->mlp_v2 && !h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp2<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
         else if (h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp_bx3<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
@@ -1209,8 +1210,8 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
     case MPPI_TUNE_MLP32_VALU:
         if (!(h->mlp_small == 32 || (h->hc.model_kind == MPPI_MODEL_NN_AUV_SPEED && h->mlp_small == 16)) || h->mlp_bx3)
             return fail(h, MPPI_ERR_INVALID_ARG, "not an exact-fp32 Dense(32) MLP handle (or an NNAUVModelSpeed one)");
-        if (value < 0 || value > 2 || (value == 2 && h->hc.model_kind != MPPI_MODEL_NN_AUV_SPEED && h->hc.model_kind != MPPI_MODEL_NN_AUV))
-            return fail(h, MPPI_ERR_INVALID_ARG, "0, 1 (vector-ALU kernel) or, NNAUVModel / NNAUVModelSpeed only, 2 (matrix cores, one wave per 32 rollouts)");
+        if (value < 0 || value > 2)
+            return fail(h, MPPI_ERR_INVALID_ARG, "0 (matrix cores, two-wave pipeline), 1 (vector-ALU kernel) or 2 (matrix cores, one wave per 32 rollouts)");
         h->mlp32_valu = value; break;
     case MPPI_TUNE_P2P_FAULT:
         if (value < 0 || value > 2) return fail(h, MPPI_ERR_INVALID_ARG, "fault: 0 none, 1 export, 2 probe");

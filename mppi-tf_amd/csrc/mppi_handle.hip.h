@@ -28,7 +28,7 @@ struct mppi_handle {
     int mlp_bx3 = 0;      // MPPI_FLAG_MLP_BF16X3: split-bf16 matrix-core variant of the MLP rollout
     int mlp_small = 0;    // hidden width (16 or 32) of a small learned model served by k_rollout_mlp_small, else 0
     MlpSmallArgs small_args{};
-    int mlp32_valu = 0;   // tuning: a Dense(32) network on k_rollout_mlp_small instead of k_rollout_mlp32
+    int mlp32_valu = 0;   // tuning: a Dense(32) network on 1 = the vector-ALU kernel, 2 = the one-wave-per-32-rollouts matrix-core kernel, instead of the two-wave pipeline
     int n_cu = 256;       // compute units of the device (k_rollout_mlp2 runs one tile-walking workgroup per CU)
     int mlp_v2 = 0;       // exact-fp32 MLP rollouts run k_rollout_mlp2 (one wave per SIMD, two pipelined sets; a_dim <= 3)
     MlpDev hm{};          // learned model: device pointers + normalisation (host copy)

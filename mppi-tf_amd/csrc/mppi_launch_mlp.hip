@@ -18,7 +18,18 @@ static hipError_t launch_mlp_a(mppi_handle *h, hipStream_t st, int src, int mode
                               (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);
         return hipGetLastError();
     }
-    if (h->mlp_small == 32 && !h->mlp32_valu) { // matrix cores, weights stationary in registers: 2 waves x 32 rollouts per tile
+    if (h->mlp_small == 32 && h->mlp32_valu == 0) { // default (r04): the two-wave pipeline (network wave + cost wave per tile, two tiles per workgroup)
+        const int wgs = (h->nb_mlp + 1) / 2;
+        const int balance = (wgs <= 2 * h->n_cu && !h->pc_no_balance) ? 1 : 0; // SIMD-true roles while the whole grid is resident in one round
+        if (h->sigma_diag)
+            hipExtLaunchKernelGGL((k_rollout_mlp32_pc<A, true>), dim3(wgs), dim3(kMlp32PcThreads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC,
+                                  (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp, h->nb_mlp, balance);
+        else
+            hipExtLaunchKernelGGL((k_rollout_mlp32_pc<A, false>), dim3(wgs), dim3(kMlp32PcThreads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC,
+                                  (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp, h->nb_mlp, balance);
+        return hipGetLastError();
+    }
+    if (h->mlp_small == 32 && h->mlp32_valu == 2) { // MPPI_TUNE_MLP32_VALU = 2: one wave per 32 rollouts, 2 waves per tile (A/B timing)
         hipExtLaunchKernelGGL((k_rollout_mlp32<A>), dim3(h->nb_mlp), dim3(kMlp32Threads), 0, st, h->kev0, h->kev1, 0, (const DevConsts *)h->dC,
                               (const MlpDev *)h->dM, x_dev, U_dev, eps, (const unsigned long long *)h->d_step, cost, h->d_part, src, mode, 1, h->nbp);
         return hipGetLastError();

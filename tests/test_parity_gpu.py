@@ -944,17 +944,20 @@ def test_small_mlp_single_step_reference_order_is_bit_exact(m, hid, n_hidden):
     a, s = 3, 6
     mlp = make_mlp(s, a, seed=11, hid=hid, n_hidden=n_hidden)
     h, p32, _ = make_mlp_pair(m, 64, 4, a, mlp)
-    assert h.rollout_kernel_name() == ("mppi::k_rollout_mlp32<3>" if hid == 32 else "mppi::k_rollout_mlp_small<3, %d>" % hid)
+    assert h.rollout_kernel_name().startswith("mppi::k_rollout_mlp32_pc<3, " if hid == 32 else "mppi::k_rollout_mlp_small<3, %d>" % hid)
     rng = np.random.default_rng(0)
     X, V = rng.standard_normal((50, s)).astype(F32), rng.standard_normal((50, a)).astype(F32)
     np.testing.assert_array_equal(h.model_next(X, V), np.stack([p32.mlp_step(X[i], V[i]) for i in range(50)]))
 
 
-# (hidden width, hidden layers, Handle tuning): Dense(32) runs on the matrix cores (k_rollout_mlp32) by default and on the
-# vector ALU (k_rollout_mlp_small) with mlp32_valu; Dense(16) on the vector ALU
+# (hidden width, hidden layers, Handle tuning): Dense(32) runs on the matrix cores — the two-wave pipeline k_rollout_mlp32_pc by default (r04),
+# the one-wave-per-32-rollouts kernel k_rollout_mlp32 with mlp32_valu = 2 — and on the vector ALU (k_rollout_mlp_small) with mlp32_valu = 1;
+# Dense(16) on the vector ALU
 SMALL_KERNELS = [(32, 3, None), (32, 3, {"mlp32_valu": 1}), (16, 3, None), (32, 1, None), (32, 2, None), (16, 2, None), (32, 1, {"mlp32_valu": 1}),
-                 (32, 3, "bf16x3"), (32, 2, "bf16x3"), (32, 1, "bf16x3")]  # "bf16x3": k_rollout_mlp32_bx3 (MPPI_FLAG_MLP_BF16X3)
-SMALL_KERNEL_IDS = ["32x3-mfma", "32x3-valu", "16x3", "32x1-mfma", "32x2-mfma", "16x2", "32x1-valu", "32x3-bf16x3", "32x2-bf16x3", "32x1-bf16x3"]
+                 (32, 3, "bf16x3"), (32, 2, "bf16x3"), (32, 1, "bf16x3"),  # "bf16x3": k_rollout_mlp32_bx3 (MPPI_FLAG_MLP_BF16X3)
+                 (32, 3, {"mlp32_valu": 2}), (32, 2, {"mlp32_valu": 2}), (32, 1, {"mlp32_valu": 2})]
+SMALL_KERNEL_IDS = ["32x3-mfma", "32x3-valu", "16x3", "32x1-mfma", "32x2-mfma", "16x2", "32x1-valu", "32x3-bf16x3", "32x2-bf16x3", "32x1-bf16x3",
+                    "32x3-mfma1w", "32x2-mfma1w", "32x1-mfma1w"]
 
 
 @pytest.mark.parametrize("hid,n_hidden,tuning", SMALL_KERNELS, ids=SMALL_KERNEL_IDS)

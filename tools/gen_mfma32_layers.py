@@ -57,6 +57,19 @@ def layer1_x2(k1h, n):
             % (n, body, ins))
 
 
+def layer1_x2_k(k1h):
+    """layer 1 of two column blocks, K1H k pairs, a 32-wide layer (k_rollout_mlp32_pc: the point-mass shapes)"""
+    ops = []
+    for s in range(k1h):
+        ca = "%[bias]" if s == 0 else "v[64:79]"
+        cb = "%[bias]" if s == 0 else "v[96:111]"
+        ops.append("s_nop 1\\n\\tv_mfma_f32_32x32x2_f32 v[64:79], %%[a%d], %%[p%d], %s\\n\\tv_mfma_f32_32x32x2_f32 v[96:111], %%[a%d], %%[q%d], %s" % (s, s, ca, s, s, cb))
+    body = "\\n\\t".join(ops) + "\\n\\t" + relu2(64, 96, 16)
+    ins = ", ".join('[a%d] "v"(a[%d]), [p%d] "v"(ba[%d]), [q%d] "v"(bb[%d])' % (s, s, s, s, s, s) for s in range(k1h))
+    return ('    if constexpr (K1H == %d) {\n        asm volatile("%s"\n                     : "=&{v[64:79]}"(accA), "=&{v[96:111]}"(accB)\n                     : %s, [bias] "v"(bias));\n    }'
+            % (k1h, body, ins))
+
+
 def hidden_x2(sa, da, sb, db, pairs):
     n = pairs  # a 16-wide layer (8 pairs): 8 live registers; a 32-wide one: 16
     ops = []
@@ -86,6 +99,14 @@ __device__ __forceinline__ void mfma32x2_layer1_8(f32x16_l &accA, f32x16_l &accB
 {
     static_assert(NR == 8 || NR == 16, "live accumulator registers");
 ''' + layer1_x2(8, 8) + "\n" + layer1_x2(8, 16) + '''
+}
+
+// the same with K1H k pairs and a 32-wide layer: the point-mass shapes of k_rollout_mlp32_pc ((s + a + 1) / 2 pairs)
+template <int K1H>
+__device__ __forceinline__ void mfma32x2_layer1(f32x16_l &accA, f32x16_l &accB, const float (&a)[K1H], const float (&ba)[K1H], const float (&bb)[K1H], const f32x16_l &bias)
+{
+    static_assert(K1H == 2 || K1H == 3 || K1H == 5 || K1H == 6, "k pairs of layer 1");
+''' + "\n".join(layer1_x2_k(k) for k in (2, 3, 5, 6)) + '''
 }
 
 ''' + hidden_x2_fn("mfma32x2_hidden_lo_hi", 64, 80, 96, 112, 16) + "\n" + hidden_x2_fn("mfma32x2_hidden_hi_lo", 80, 64, 112, 96, 16) + "\n" \
