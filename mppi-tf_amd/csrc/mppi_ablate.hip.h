@@ -127,3 +127,10 @@ __host__ __device__ constexpr int mlp2_trace_slot(int kp)
 #define MPPI_MLP2_TRACE_AT(Q, kp) do { } while (0)
 #define MPPI_MLP2_TRACE_FLUSH(cond) do { } while (0)
 #endif
+
+// ---- the two-wave pipelines (mppi_gen.hip.h, mppi_mlp32.hip.h): which wave a step waits for. Bit set (wrong results): 1 the network wave skips
+// its Dense stack and output layer, 2 the pose / cost wave skips its per-step work (pose update, Euler angles, state cost) ----
+#ifndef MPPI_PC_ABL
+#define MPPI_PC_ABL 0
+#endif
+

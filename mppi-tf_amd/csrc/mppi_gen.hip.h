@@ -1188,7 +1188,8 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
 #pragma unroll
                     for (int i = 0; i < 6; ++i) { in[3 + i] = vel[i]; in[9 + i] = v[i]; }
                     in[NIN] = 0.0f;
-                    if constexpr (MF16) {
+                    if constexpr ((MPPI_PC_ABL & 1) != 0) { // (timing study, tools/ablate.py pc_*: no network)
+                    } else if constexpr (MF16) {
                         // B operands of the four 16-rollout column blocks: per k step a 4 x 4 transpose of 16-lane rows across four registers
                         // (inputs 4 s .. 4 s + 3 of the lane's rollout -> input 4 s + g of rollout 16 c + n in lane (n, g) of register c)
                         auto relu16 = [](float v) { return __int_as_float(max(__float_as_int(v), 0)); }; // ONE v_max_i32: a float below zero (and -0) is a negative int; fmaxf costs a canonicalising v_max_f32 first, and so does a v_med3_f32 hipcc recognises
@@ -1298,12 +1299,13 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
 #pragma unroll
                 for (int i = 0; i < 6; ++i) x[7 + i] = vel_s[pair][(t - 1) & 1][i][lane];
                 const float ac = vel_s[pair][(t - 1) & 1][6][lane];
-                const float sc = cost_of(x); // cost on the POST-step state
+                const float sc = (MPPI_PC_ABL & 2) ? x[0] : cost_of(x); // cost on the POST-step state
                 const float tmp = sc + ac;   // Step_cost_result cost_base.cpp:49
                 c = c + tmp;                 // path_cost        controller_base.cpp:268
             }
+            if constexpr ((MPPI_PC_ABL & 2) == 0) // (timing study: no pose work)
             nnauv_speed_next_state(dt, x, zero6); // the pose from the OLD velocities (nn_model.py:463-472); x[7..12] + 0 is exact
-            if (t + 1 < H) {
+            if ((MPPI_PC_ABL & 2) == 0 && t + 1 < H) {
                 const float q4[4] = {x[3], x[4], x[5], x[6]};
                 float eu[3];
                 euler_from_quat(q4, eu);

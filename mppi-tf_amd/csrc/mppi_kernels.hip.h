@@ -806,29 +806,32 @@ __device__ __forceinline__ void mlp_tile_record(const DevConsts *__restrict__ C,
     const float ek = valid ? expf(C->neg_inv_lambda * (c - beta)) : 0.0f;
     const float eta = wave_sum(ek);
     if (w == 0 && lane == 0) { rec[0] = beta; rec[(size_t)rsc] = eta; }
+    // the 4 A columns of a horizon group go through ONE transposing butterfly (wave_transpose_sum: ~2.3 instructions per column where a
+    // 64-lane sum per column costs 12, and one store instruction per group): the regenerated noise is a fifth of a 13-state pipeline kernel's
+    // instructions, and this was a third of that
+    const int col = lane_column(lane), ctl = col / A, ci = col - ctl * A; // the column of a group this lane ends up with the total of
     for (int g = w; g < NG; g += NWAVES) {
-        float zz[4 * A];
+        float zz[4 * A], prod[4 * A];
         if (SRC == SRC_PHILOX) normals_group<A>(seed, gk, base + (unsigned long long)g, zz);
 #pragma unroll
         for (int tl = 0; tl < 4; ++tl) {
             const int t = 4 * g + tl;
-            if (t < H) {
-                float z1[A], e[A];
-                if (SRC == SRC_PHILOX) {
+            float z1[A], e[A];
+            if (SRC == SRC_PHILOX) {
 #pragma unroll
-                    for (int i = 0; i < A; ++i) z1[i] = zz[tl * A + i];
-                    scale_noise<A, DIAG>(C, z1, e);
-                } else {
+                for (int i = 0; i < A; ++i) z1[i] = zz[tl * A + i];
+                scale_noise<A, DIAG>(C, z1, e);
+            } else {
 #pragma unroll
-                    for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
-                }
-#pragma unroll
-                for (int i = 0; i < A; ++i) {
-                    const float tot = wave_sum_dpp(ek * e[i]);
-                    if (lane == 0) rec[(size_t)(2 + t * A + i) * rsc] = tot;
-                }
+                for (int i = 0; i < A; ++i) e[i] = t < H ? eps_hbm[(size_t)kk * HA + t * A + i] : 0.0f;
             }
+#pragma unroll
+            for (int i = 0; i < A; ++i) prod[tl * A + i] = ek * e[i]; // (steps past the horizon: summed like the others, never stored)
         }
+        float tot[1];
+        wave_transpose_sum<4 * A>(prod, tot, lane);
+        const int t = 4 * g + ctl;
+        if (col < 4 * A && t < H) rec[(size_t)(2 + t * A + ci) * rsc] = tot[0];
     }
 }
 

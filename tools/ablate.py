@@ -18,6 +18,10 @@ VARIANTS = {
     "only_rollout": ["MPPI_ABLATE_PHILOX", "MPPI_ABLATE_WSUM"],
     "nothing": ["MPPI_ABLATE_PHILOX", "MPPI_ABLATE_ROLLOUT", "MPPI_ABLATE_WSUM"],
     # k_finish_cols stopped after stage n (where do its ~4.3 us go): 0 entry, 1 record loads, 2 min over the records, (full = all)
+    # the two-wave pipelines (k_rollout_nnspeed_pc): which wave a step waits for
+    "pc_no_network": ["MPPI_PC_ABL=1"],
+    "pc_no_pose": ["MPPI_PC_ABL=2"],
+    "pc_neither": ["MPPI_PC_ABL=3"],
     "finish_s0": ["MPPI_FINISH_STAGE=0"],
     "finish_s1": ["MPPI_FINISH_STAGE=1"],
     "finish_s2": ["MPPI_FINISH_STAGE=2"],
