@@ -134,3 +134,28 @@ __host__ __device__ constexpr int mlp2_trace_slot(int kp)
 #define MPPI_PC_ABL 0
 #endif
 
+// ---- phase timeline of a two-wave pipeline (k_rollout_nnspeed_pc; tools/timeline_pc.py): both waves of a tile stamp s_memtime at their
+// phase boundaries in steps MPPI_PCT_STEP and MPPI_PCT_STEP + 1 (slot = 16 * (step - MPPI_PCT_STEP) + 8 * wave kind + phase), and the cost
+// wave writes the 64 stamps where the tile's costs go ----
+#if defined(MPPI_PC_GEN_TIMELINE)
+#ifndef MPPI_PCT_STEP
+#define MPPI_PCT_STEP 20
+#endif
+__device__ __forceinline__ unsigned long long pct_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define MPPI_PCT_DECL() __shared__ float pct_s[2][64]
+#define MPPI_PCT(t, kind, phase) do { if ((t) == MPPI_PCT_STEP || (t) == MPPI_PCT_STEP + 1) { const unsigned long long t_ = pct_stamp(); \
+        if (lane == 0) pct_s[pair][16 * ((t) - MPPI_PCT_STEP) + 8 * (kind) + (phase)] = (float)(t_ & 0xFFFFFFull); } } while (0)
+#define MPPI_PCT_DUMP(valid, ptr, c) do { if (valid) *(ptr) = lane < 32 ? pct_s[pair][lane] : (c); } while (0)
+#else
+#define MPPI_PCT_DECL() do { } while (0)
+#define MPPI_PCT(t, kind, phase) do { } while (0)
+#define MPPI_PCT_DUMP(valid, ptr, c) do { if (valid) *(ptr) = (c); } while (0)
+#endif
+

@@ -1039,6 +1039,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
     __shared__ float vel_s[2][2][7][64];  // [tile][step parity][6 velocities of the NEXT state, action cost][rollout]   N -> P
     __shared__ float cost_s[2][64];
     __shared__ int simd_s[4];
+    MPPI_PCT_DECL(); // (timing study: mppi_ablate.hip.h)
     const int H = C->H, HA = H * A, K = C->K_local;
     const int NG = (H + 3) / 4;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1168,6 +1169,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
             for (int tl = 0; tl < 4; ++tl) {
                 const int t = 4 * g + tl;
                 if (t < H) { // (wave-uniform)
+                    MPPI_PCT(t, 0, 0); // step start
                     float u[A], e[A], v[A];
                     if (SRC == SRC_PHILOX) {
                         float z1[A];
@@ -1181,6 +1183,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
 #pragma unroll
                     for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
                     const float ac = action_cost<A, DIAG>(&pcst, u, e);
+                    MPPI_PCT(t, 0, 1); // noise, action cost done
                     // inputs (prepare_data, nn_model.py:438-461): Euler angles (from P), body velocities, forces; input 15 = zero padding
                     float in[NIN + 1];
 #pragma unroll
@@ -1194,6 +1197,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                         // (inputs 4 s .. 4 s + 3 of the lane's rollout -> input 4 s + g of rollout 16 c + n in lane (n, g) of register c)
                         auto relu16 = [](float v) { return __int_as_float(max(__float_as_int(v), 0)); }; // ONE v_max_i32: a float below zero (and -0) is a negative int; fmaxf costs a canonicalising v_max_f32 first, and so does a v_med3_f32 hipcc recognises
                         f32x4 acc[4];
+                        MPPI_PCT(t, 0, 2); // inputs read
 #pragma unroll
                         for (int s1 = 0; s1 < 4; ++s1) {
                             float xq[4];
@@ -1222,6 +1226,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                         }
                         // output layer: the lane's four units of each column block, then the sum over the four lane groups, transposed back to
                         // lane = rollout (two swap levels: the butterfly of the input transpose run backwards)
+                        MPPI_PCT(t, 0, 3); // the three layers issued
                         float part[4][NOUT];
 #pragma unroll
                         for (int c4 = 0; c4 < 4; ++c4)
@@ -1266,10 +1271,13 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                         finish(accA, accB);
                     }
                     }
+                    MPPI_PCT(t, 0, 4); // network, output layer, velocities done
 #pragma unroll
                     for (int i = 0; i < 6; ++i) vel_s[pair][t & 1][i][lane] = vel[i];
                     vel_s[pair][t & 1][6][lane] = ac;
+                    MPPI_PCT(t, 0, 5); // at the barrier
                     __syncthreads(); // step t handed over
+                    MPPI_PCT(t, 0, 6); // through the barrier
                 }
             }
         }
@@ -1295,6 +1303,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
         __syncthreads(); // the Euler angles of x0
         const float zero6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         for (int t = 0; t < H; ++t) {
+            MPPI_PCT(t, 1, 0); // step start
             if (t >= 1) { // the state step t-1 produced: its pose is here, its velocities and the step's action cost come from N
 #pragma unroll
                 for (int i = 0; i < 6; ++i) x[7 + i] = vel_s[pair][(t - 1) & 1][i][lane];
@@ -1303,8 +1312,10 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                 const float tmp = sc + ac;   // Step_cost_result cost_base.cpp:49
                 c = c + tmp;                 // path_cost        controller_base.cpp:268
             }
+            MPPI_PCT(t, 1, 1); // cost done
             if constexpr ((MPPI_PC_ABL & 2) == 0) // (timing study: no pose work)
             nnauv_speed_next_state(dt, x, zero6); // the pose from the OLD velocities (nn_model.py:463-472); x[7..12] + 0 is exact
+            MPPI_PCT(t, 1, 2); // pose done
             if ((MPPI_PC_ABL & 2) == 0 && t + 1 < H) {
                 const float q4[4] = {x[3], x[4], x[5], x[6]};
                 float eu[3];
@@ -1312,7 +1323,9 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
 #pragma unroll
                 for (int i = 0; i < 3; ++i) eu_s[pair][(t + 1) & 1][i][lane] = eu[i];
             }
+            MPPI_PCT(t, 1, 5); // Euler angles done: at the barrier
             __syncthreads(); // step t handed over
+            MPPI_PCT(t, 1, 6); // through the barrier
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) x[7 + i] = vel_s[pair][(H - 1) & 1][i][lane];
@@ -1320,7 +1333,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
         c = c + (sc + vel_s[pair][(H - 1) & 1][6][lane]);
         c = c + sc; // terminal cost: x_H counted a second time, controller_base.cpp:271-272
         cost_s[pair][lane] = c;
-        if (valid) cost[k0 + lane] = c;
+        MPPI_PCT_DUMP(valid, cost + k0 + lane, c);
     }
     __syncthreads();
     if (MODE == MODE_COST_ONLY || !tile_ok) return;
