@@ -22,6 +22,9 @@ cases = [
  ("mlp 2x256 bx3", dict(k=65536, mlp=mlp([9,256,256,6]), mlp_bf16x3=True, **pm), np.zeros(6, np.float32), 1500),
  ("mlp 2x256", dict(k=65536, mlp=mlp([9,256,256,6]), **pm), np.zeros(6, np.float32), 300),
  ("mlp32 bx3", dict(k=65536, mlp=mlp([9,32,32,32,6]), mlp_bf16x3=True, **pm), np.zeros(6, np.float32), 3000),
+ ("mlp32 pc", dict(k=65536, mlp=mlp([9,32,32,32,6]), **pm), np.zeros(6, np.float32), 3000),       # r04: k_rollout_mlp32_pc (network wave + cost wave)
+ ("mlp32 pc ragged", dict(k=200001, mlp=mlp([9,32,32,6]), **pm), np.zeros(6, np.float32), 500),
+ ("mlp32 one wave", dict(k=65536, mlp=mlp([9,32,32,32,6]), tuning={"mlp32_valu": 2}, **pm), np.zeros(6, np.float32), 1000),
  ("nnauv32 bx3", dict(k=65536, nnauv=mlp([16,32,32,32,13]), mlp_bf16x3=True, **at), x13, 2000),
  ("nnauv pc", dict(k=65536, nnauv=mlp([16,32,32,32,13]), **at), x13, 2500),                      # r04: k_rollout_nnauv_pc (network wave + cost wave)
  ("nnauv pc ragged", dict(k=200001, nnauv=mlp([16,32,32,32,13]), **at), x13, 400),
