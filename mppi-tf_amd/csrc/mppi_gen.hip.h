@@ -178,12 +178,28 @@ __device__ __forceinline__ void auv_pose_rates(const float (&q)[4], const float 
     for (int i = 0; i < 4; ++i) xd[3 + i] = (T[i * 3] * vel[3] + T[i * 3 + 1] * vel[4]) + T[i * 3 + 2] * vel[5];
 }
 
+// the restoring forces and moments g(eta) (:450-480): f_g = R^T (0, 0, fng_z) = R[2][:]*fng_z ; f_b likewise ; moments cog x f_g, cob x f_b.
+// A function of the quaternion alone: k_rollout_auv_pc lets the POSE wave evaluate it (it holds q and has time to spare) and hand the six
+// values to the velocity wave instead of the quaternion
 template <class GT>
-__device__ __forceinline__ void auv_vel_rates(const GT *__restrict__ G, const float (&q)[4], const float (&vel)[6], const float (&u)[kGenA],
-                                              float (&xdv)[6], float *pieces = nullptr)
+__device__ __forceinline__ void auv_restoring(const GT *__restrict__ G, const float (&q)[4], float (&g6)[6])
 {
     float rot[9], T[12];
     auv_b2i(q, rot, T); // only rot's third row is used here (the rest is dead code to the compiler)
+    float fbg[3], fbb[3], mbg[3], mbb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { fbg[i] = rot[6 + i] * G->fng_z; fbb[i] = rot[6 + i] * G->fnb_z; }
+    const float cog[3] = {G->cog[0], G->cog[1], G->cog[2]}, cob[3] = {G->cob[0], G->cob[1], G->cob[2]};
+    cross3(cog, fbg, mbg);
+    cross3(cob, fbb, mbb);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { g6[i] = -(fbg[i] + fbb[i]); g6[3 + i] = -(mbg[i] + mbb[i]); }
+}
+
+template <class GT>
+__device__ __forceinline__ void auv_vel_rates_g(const GT *__restrict__ G, const float (&g6)[6], const float (&vel)[6], const float (&u)[kGenA],
+                                                float (&xdv)[6], float *pieces = nullptr)
+{
     // damping (:482-510): D = (-lin - v0*fwd) + (-(diag(quad) |diag(v)|)); D v as the dense row sum
     float Dv[6];
     const float v0 = vel[0];
@@ -219,17 +235,10 @@ __device__ __forceinline__ void auv_vel_rates(const GT *__restrict__ G, const fl
     Cv[3] = ((a1[2] * vel[1] + (-a1[1]) * vel[2]) + a2[2] * vel[4]) + (-a2[1]) * vel[5];
     Cv[4] = (((-a1[2]) * vel[0] + a1[0] * vel[2]) + (-a2[2]) * vel[3]) + a2[0] * vel[5];
     Cv[5] = ((a1[1] * vel[0] + (-a1[0]) * vel[1]) + a2[1] * vel[3]) + (-a2[0]) * vel[4];
-    // restoring (:450-480): f_g = R^T (0, 0, fng_z) = R[2][:]*fng_z ; f_b likewise ; moments cog x f_g, cob x f_b
-    float fbg[3], fbb[3], mbg[3], mbb[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { fbg[i] = rot[6 + i] * G->fng_z; fbb[i] = rot[6 + i] * G->fnb_z; }
-    const float cog[3] = {G->cog[0], G->cog[1], G->cog[2]}, cob[3] = {G->cob[0], G->cob[1], G->cob[2]};
-    cross3(cog, fbg, mbg);
-    cross3(cob, fbb, mbb);
     float rhs[6];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float g_f = -(fbg[i] + fbb[i]), g_m = -(mbg[i] + mbb[i]);
+        const float g_f = g6[i], g_m = g6[3 + i];
         rhs[i] = ((u[i] - Cv[i]) - Dv[i]) - g_f;
         rhs[3 + i] = ((u[3 + i] - Cv[3 + i]) - Dv[3 + i]) - g_m;
         if (pieces != nullptr) { pieces[12 + i] = g_f; pieces[15 + i] = g_m; }
@@ -239,6 +248,15 @@ __device__ __forceinline__ void auv_vel_rates(const GT *__restrict__ G, const fl
         for (int i = 0; i < 6; ++i) { pieces[i] = Cv[i]; pieces[6 + i] = Dv[i]; }
     }
     G->inv_mass_times(rhs, xdv);
+}
+
+template <class GT>
+__device__ __forceinline__ void auv_vel_rates(const GT *__restrict__ G, const float (&q)[4], const float (&vel)[6], const float (&u)[kGenA],
+                                              float (&xdv)[6], float *pieces = nullptr)
+{
+    float g6[6];
+    auv_restoring(G, q, g6);
+    auv_vel_rates_g(G, g6, vel, u, xdv, pieces);
 }
 
 template <class GT>
@@ -1347,10 +1365,12 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
 // where two issue one every ~2.7 (profiles/r02_valu_issue.json): the kernel ran at half the issue rate by construction (0.19 ms, 980
 // vector instructions per wave and step). state_dot splits by ROWS without touching any row's arithmetic:
 //   wave A (pose):     lane = rollout. xd[0..6] = J(eta) nu (auv_pose_rates), the pose's Runge-Kutta update, the quaternion
-//                      normalisation, the cost of the state a step produced, and the noise: v = u + eps and the action cost of the NEXT step;
-//   wave B (velocity): lane = rollout. xd[7..12] = invM (tau - C nu - D nu - g(eta)) (auv_vel_rates: the two 6x6 products, damping,
-//                      Coriolis, restoring forces from rot's third row), the velocities' Runge-Kutta update.
-// Each needs the other's half of every Runge-Kutta stage state: A the 6 velocities, B the quaternion — handed over through double-
+//                      normalisation, the cost of the state a step produced, the noise: v = u + eps and the action cost of the NEXT step,
+//                      and g(eta) of every stage state (auv_restoring: the one piece of the velocity rates that needs the quaternion alone);
+//   wave B (velocity): lane = rollout. xd[7..12] = invM (tau - C nu - D nu - g(eta)) (auv_vel_rates_g: the two 6x6 products, damping,
+//                      Coriolis), the velocities' Runge-Kutta update.
+// Each needs the other's half of every Runge-Kutta stage state: A the 6 velocities, B the 6 restoring forces and moments (until late r04 the
+// quaternion: B is the wave a stage waits for, A had the time — 0.1396 -> 0.1355 ms, still bit-identical) — handed over through double-
 // buffered LDS with ONE workgroup barrier per stage (2 per step at rk2); the perturbed action travels A -> B once per step, a step ahead.
 // Every row keeps the reference's operations in the reference's order (the pieces are the ones auv_state_dot is made of; the cost is summed by
 // wave A alone, in index order): sample costs stay BIT-IDENTICAL to the fp32 CPU restatement.
@@ -1364,7 +1384,7 @@ __global__ __launch_bounds__(kAuvPcThreads, 2) void k_rollout_auv_pc(
     const int SRC, const int MODE, const int rsb, const int rsc, const int n_tiles, const int balance)
 {
     constexpr int S = kGenS, A = kGenA;
-    __shared__ float q_s[2][2][4][64];    // [tile of the workgroup][barrier parity][quaternion of the stage state][rollout]      A -> B
+    __shared__ float g_s[2][2][6][64];    // [tile of the workgroup][barrier parity][restoring forces g(eta) of the stage state][rollout]   A -> B
     __shared__ float vel_s[2][2][6][64];  // [tile][barrier parity][velocities of the stage state][rollout]                       B -> A
     __shared__ float act_s[2][2][7][64];  // [tile][step parity][perturbed action v, action cost][rollout]                        A -> B (v), A keeps the cost
     __shared__ float cost_s[2][64];
@@ -1403,27 +1423,28 @@ __global__ __launch_bounds__(kAuvPcThreads, 2) void k_rollout_auv_pc(
         float vel[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) vel[i] = x_dev[7 + i];
-        // stage hand-off: publish the stage state's velocities, barrier, fetch its quaternion
-        auto swap_stage = [&](const float (&vs)[6], float (&qs)[4]) {
+        // stage hand-off: publish the stage state's velocities, barrier, fetch its restoring forces (the one piece of the velocity rates that
+        // is a function of the quaternion alone: the pose wave evaluates it)
+        auto swap_stage = [&](const float (&vs)[6], float (&gs)[6]) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) vel_s[pair][nbar & 1][i][lane] = vs[i];
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) qs[i] = q_s[pair][nbar & 1][i][lane];
+            for (int i = 0; i < 6; ++i) gs[i] = g_s[pair][nbar & 1][i][lane];
             ++nbar;
         };
         for (int t = 0; t < H; ++t) {
-            float q[4], v[A], k1[6], tmp[6];
+            float q[6], v[A], k1[6], tmp[6]; // (q: g(eta) of the stage state)
             swap_stage(vel, q);
 #pragma unroll
             for (int i = 0; i < A; ++i) v[i] = act_s[pair][t & 1][i][lane]; // to_apply of step t (wave A prepared it a step ahead)
-            auv_vel_rates(&al, q, vel, v, k1);
+            auv_vel_rates_g(&al, q, vel, v, k1);
             if (rk == 2) {
                 float vs[6], k2[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) vs[i] = vel[i] + dt * k1[i];
                 swap_stage(vs, q);
-                auv_vel_rates(&al, q, vs, v, k2);
+                auv_vel_rates_g(&al, q, vs, v, k2);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) tmp[i] = (dt / 2.0f) * (k1[i] + k2[i]);
             } else if (rk == 4) { // the reference's formula, k4*dt inside the sum (:299-300)
@@ -1431,15 +1452,15 @@ __global__ __launch_bounds__(kAuvPcThreads, 2) void k_rollout_auv_pc(
 #pragma unroll
                 for (int i = 0; i < 6; ++i) vs[i] = vel[i] + (dt * k1[i]) / 2.0f;
                 swap_stage(vs, q);
-                auv_vel_rates(&al, q, vs, v, k2);
+                auv_vel_rates_g(&al, q, vs, v, k2);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) vs[i] = vel[i] + (dt * k2[i]) / 2.0f;
                 swap_stage(vs, q);
-                auv_vel_rates(&al, q, vs, v, k3);
+                auv_vel_rates_g(&al, q, vs, v, k3);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) vs[i] = vel[i] + dt * k3[i];
                 swap_stage(vs, q);
-                auv_vel_rates(&al, q, vs, v, k4);
+                auv_vel_rates_g(&al, q, vs, v, k4);
                 const float sixth = (float)(1.0 / 6.0);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) tmp[i] = (sixth * ((k1[i] + 2.0f * k2[i]) + (2.0f * k3[i] + k4[i] * dt))) * dt;
@@ -1450,7 +1471,7 @@ __global__ __launch_bounds__(kAuvPcThreads, 2) void k_rollout_auv_pc(
 #pragma unroll
             for (int i = 0; i < 6; ++i) vel[i] = vel[i] + tmp[i];
         }
-        float q_unused[4];
+        float q_unused[6];
         swap_stage(vel, q_unused); // the velocities of x_H for wave A's last step cost and the terminal cost
     } else {
         // ================================================================================= wave A: pose, cost, noise
@@ -1487,10 +1508,18 @@ __global__ __launch_bounds__(kAuvPcThreads, 2) void k_rollout_auv_pc(
             for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; act_s[pair][t & 1][i][lane] = u[i] + e[i]; }
             act_s[pair][t & 1][6][lane] = action_cost<A, DIAG>(&pcst, u, e);
         };
-        // stage hand-off: publish the stage state's quaternion, barrier, fetch its velocities
-        auto swap_stage = [&](const float (&ps)[7], float (&vs)[6]) {
+        // stage hand-off: publish the restoring forces g(eta) of the stage state (auv_restoring: a function of its quaternion alone, and this
+        // wave has the time the velocity wave lacks), barrier, fetch its velocities
+        struct { float fng_z, fnb_z, cog[3], cob[3]; } rl;
+        rl.fng_z = G->fng_z; rl.fnb_z = G->fnb_z;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) q_s[pair][nbar & 1][i][lane] = ps[3 + i];
+        for (int i = 0; i < 3; ++i) { rl.cog[i] = G->cog[i]; rl.cob[i] = G->cob[i]; }
+        auto swap_stage = [&](const float (&ps)[7], float (&vs)[6]) {
+            const float q4[4] = {ps[3], ps[4], ps[5], ps[6]};
+            float g6[6];
+            auv_restoring(&rl, q4, g6);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) g_s[pair][nbar & 1][i][lane] = g6[i];
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 6; ++i) vs[i] = vel_s[pair][nbar & 1][i][lane];
