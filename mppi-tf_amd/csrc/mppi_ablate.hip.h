@@ -159,3 +159,8 @@ __device__ __forceinline__ unsigned long long pct_stamp()
 #define MPPI_PCT_DUMP(valid, ptr, c) do { if (valid) *(ptr) = (c); } while (0)
 #endif
 
+// ---- k_rollout_pc: priority levels added to the consumer wave's progress level (A/B: tools/ablate.py consumer_boost) ----
+#ifndef MPPI_PC_CONSUMER_BOOST
+#define MPPI_PC_CONSUMER_BOOST 0
+#endif
+

@@ -187,10 +187,10 @@ __device__ __forceinline__ void static_for(F &&f)
 #if !defined(MPPI_PC_PRIO_BIAS)
 #define MPPI_PC_PRIO_BIAS 3
 #endif
-__device__ __forceinline__ void pc_set_prio(int i, int n, int gen)
+__device__ __forceinline__ void pc_set_prio(int i, int n, int gen, int boost = 0)
 {
     const int bias = MPPI_PC_PRIO_BIAS * (3 - min(gen, 3)); // quarter chunks
-    const int lvl = 3 - min(3, (16 * i + 4 * bias) / (4 * n));
+    const int lvl = min(3, boost + 3 - min(3, (16 * i + 4 * bias) / (4 * n)));
     switch (lvl) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
     case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
         __syncthreads(); // chunk 0 published
         MPPI_STAMP(1);
         for (int ch = 0; ch < nch; ++ch) {
-            if (balance) pc_set_prio(ch, nch, gen);
+            if (balance) pc_set_prio(ch, nch, gen, MPPI_PC_CONSUMER_BOOST);
             const float *cb = buf + (ch & 1) * CH;
             const int tend = min(CS, H - ch * CS);
             for (int tl = 0; tl < MPPI_ABL_CHUNK_STEPS(tend, ch); ++tl) {

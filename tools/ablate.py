@@ -22,6 +22,7 @@ VARIANTS = {
     "pc_no_network": ["MPPI_PC_ABL=1"],
     "pc_no_pose": ["MPPI_PC_ABL=2"],
     "pc_neither": ["MPPI_PC_ABL=3"],
+    "consumer_boost": ["MPPI_PC_CONSUMER_BOOST=1"],  # k_rollout_pc: the consumer wave one priority level above its progress level
     "finish_s0": ["MPPI_FINISH_STAGE=0"],
     "finish_s1": ["MPPI_FINISH_STAGE=1"],
     "finish_s2": ["MPPI_FINISH_STAGE=2"],
