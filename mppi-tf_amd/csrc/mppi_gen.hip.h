@@ -1090,7 +1090,8 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
 
     if (role == 0) {
         // ================================================================================= wave N: noise, network, velocities
-        __builtin_amdgcn_s_setprio(3); // the wave a step waits for goes first on its SIMD (the other kind fills the gaps)
+        if (balance) __builtin_amdgcn_s_setprio(3); // (one round of the grid only: beyond it the age order staggers the workgroups' phases, as in k_rollout_pc)
+        // the wave a step waits for goes first on its SIMD (the other kind fills the gaps)
         const int j = lane & 31, hh = lane >> 5;
         const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
         const unsigned long long seed = C->seed;
@@ -1476,7 +1477,8 @@ __global__ __launch_bounds__(kAuvPcThreads, 2) void k_rollout_auv_pc(
         swap_stage(vel, q_unused); // the velocities of x_H for wave A's last step cost and the terminal cost
     } else {
         // ================================================================================= wave A: pose, cost, noise
-        __builtin_amdgcn_s_setprio(3); // the wave a stage waits for goes first on its SIMD (measured: this one — 0.1366 ms without priorities, 0.1342 with the
+        if (balance) __builtin_amdgcn_s_setprio(3); // (one round of the grid only: beyond it the age order staggers the workgroups' phases, as in k_rollout_pc)
+        // the wave a stage waits for goes first on its SIMD (measured: this one — 0.1366 ms without priorities, 0.1342 with the
                                        // velocity wave first, 0.1278 with this one first; the other kind fills the gaps)
         GenQuadConsts qc;
         const bool quad_diag = C->state_cost_kind == MPPI_STATE_COST_QUADRATIC && !C->q_full;
@@ -1663,7 +1665,8 @@ __global__ __launch_bounds__(kNnauvPcThreads, 2) void k_rollout_nnauv_pc(
 
     if (role == 0) {
         // ================================================================================= wave N: network, state
-        __builtin_amdgcn_s_setprio(3); // the wave a step waits for goes first on its SIMD (the other kind fills the gaps)
+        if (balance) __builtin_amdgcn_s_setprio(3); // (one round of the grid only: beyond it the age order staggers the workgroups' phases, as in k_rollout_pc)
+        // the wave a step waits for goes first on its SIMD (the other kind fills the gaps)
         const int j = lane & 31, hh = lane >> 5;
         auto unit_of = [](int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); };
         float a1[K1H];

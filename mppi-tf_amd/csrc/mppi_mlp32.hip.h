@@ -239,7 +239,8 @@ __global__ __launch_bounds__(kMlp32PcThreads, 2) void k_rollout_mlp32_pc(
 
     if (role == 0) {
         // ================================================================================= wave N: network, state
-        __builtin_amdgcn_s_setprio(3); // the wave a step waits for goes first on its SIMD (the other kind fills the gaps)
+        if (balance) __builtin_amdgcn_s_setprio(3); // (one round of the grid only: beyond it the age order staggers the workgroups' phases, as in k_rollout_pc)
+        // the wave a step waits for goes first on its SIMD (the other kind fills the gaps)
         const int j = lane & 31, hh = lane >> 5;
         auto unit_of = [](int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); };
         float a1[K1H];
