@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak run on the GPU box: thousands of consecutive control steps of every rollout-kernel family (point mass with its option paths,
 the 2x256 and Dense(32) networks in both precisions, the 13-state family); checks the step counter and finite action sequences.
-   python tools/soak.py"""
+   python tools/soak.py [multiplier of the step counts]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -39,7 +39,9 @@ cases = [
  ("auv pc rk4", dict(k=65536, **dict(auv_task(64), auv=dict(auv_task(64)["auv"], rk=4))), x13, 1000),
  ("auv one wave", dict(k=65536, tuning={"gen_one_wave": 1}, **auv_task(64)), x13, 1000),
 ]
+MULT = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # python tools/soak.py 20: twenty times the steps of every case
 for name, kw, x0, n in cases:
+    n *= MULT
     kw = dict(kw); kw.pop("x0", None)
     h = m.Handle(**kw)
     x = torch.tensor(x0, device="cuda"); u = torch.zeros(kw["a_dim"], device="cuda")
