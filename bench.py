@@ -485,16 +485,22 @@ class Runner:
             raise RuntimeError("the all-gather path cannot time out")
 
         steps_timed(warmup)
-        batches = [steps_timed(steps)]
-        n_more = int(min(200, max(0, np.ceil((min_time - batches[0]) / max(batches[0], 1e-9)))))
-        n_more = int(self.max_over_ranks(n_more))
-        for _ in range(n_more):
+        # batches of EXACTLY `steps` steps until --min-time seconds have been TIMED (a cap of 200 batches made the
+        # driver's --steps 20 run 79 ms of GPU work, over before the clocks had settled). The cap is wall time (barriers and Python
+        # frames between batches included), rank 0's decision broadcast so every rank runs the same number of collectives.
+        batches, t_wall = [steps_timed(steps)], time.perf_counter()
+        while True:
+            more = sum(batches) < min_time and time.perf_counter() - t_wall < 4.0 * min_time + 1.0 and len(batches) < 100000
+            if self.max_over_ranks(1.0 if more else 0.0) == 0.0:
+                break
             batches.append(steps_timed(steps))
         el = float(np.median(batches))
         rank_ms = [1e3 * q / steps for q in self.per_rank(rank_el[0])]  # each rank's own time for the last batch, before the barrier
         # kernel durations: the same K steps with HIP events bound to each launch (the dispatches' own begin/end)
         h = ctl.backend.h
-        n_prof = min(steps, 200)
+        # >= 200 launches whatever --steps is (the driver's --steps 20 gave a 20-launch average, 10 % above steady state);
+        # the millisecond-scale learned-model steps keep their batch size (their kernels are long enough to be their own steady state)
+        n_prof = max(steps, 200) if el / steps < 1e-3 else steps
         h.profile_begin(n_prof)
         if self.world == 1 and ctl.exchange == "none":
             # the timed region keeps the GPU's queue full; so must this pass, or the kernels are timed on a GPU that idles between them
