@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 4 /* 4: mppi_shard_step (one call per sharded step, the caller's collectives as function pointers), mppi_learner_save /
+#define MPPI_ABI_VERSION 5 /* 5: MPPI_TUNE_FUSED_STEP / _ARMED_US / _ARMED_ALWAYS (no entry point changed); 4: mppi_shard_step (one call per sharded step, the caller's collectives as function pointers), mppi_learner_save /
                               _load / _peek, MPPI_TUNE_TRACE (roctx ranges); mppi_set_mlp orders against the last step's stream;
                               3: the 13-state AUV family (MPPI_MODEL_AUV / _NN_AUV, mppi_auv_desc), StaticQuatCost / ElipseCost3D state costs,
                               mppi_auv_pieces, the learner (mppi_learner_*); 2: state_cost_kind / ellipse, transition log, tuning */
@@ -366,7 +366,16 @@ enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instea
         * the library has no link dependency on it; the call fails with MPPI_ERR_UNSUPPORTED when it cannot be found. Shows in
         * `rocprofv3 --marker-trace`. */
        MPPI_TUNE_TRACE = 8,
-       MPPI_TUNE_GEN_ONE_WAVE = 9 };    /* 1: the Fossen AUVModel on k_rollout_gen<0> (one wave per 64-rollout tile) instead of k_rollout_auv_pc (pose wave + velocity wave per tile) */
+       MPPI_TUNE_GEN_ONE_WAVE = 9,
+       /* r05 (ABI 5), the point-mass producer/consumer path with the diagonal quadratic cost (mppi_step.hip.h): */
+       MPPI_TUNE_FUSED_STEP = 10,       /* default 1: a handle of <= 128 tiles (K <= 8192) runs its Philox step as ONE launch — tiles and the column waves that
+                                         * finish them in one grid, records handed over as {value, sequence} granules; 0: rollout launch + finish launch */
+       MPPI_TUNE_ARMED_US = 11,         /* default 0 (off). N > 0: once two mppi_next calls have followed each other within N microseconds, a call leaves the NEXT
+                                         * step's launch behind it, armed: resident on the GPU, its noise drawn, waiting up to N us for x. The next mppi_next then
+                                         * only stores x into device memory (large BAR) and watches the pinned u slot — no launch, no dispatch between x and u.
+                                         * While armed the launch occupies the GPU; a launch whose x does not come in time aborts by itself and changes nothing.
+                                         * Controls are bit-identical to the unarmed path. MPPI_ERR_UNSUPPORTED without a large-BAR device. */
+       MPPI_TUNE_ARMED_ALWAYS = 12 };   /* 1: arm behind every mppi_next whatever the gap between the last two calls (tests of the deadline path) */    /* 1: the Fossen AUVModel on k_rollout_gen<0> (one wave per 64-rollout tile) instead of k_rollout_auv_pc (pose wave + velocity wave per tile) */
 mppi_status mppi_set_tuning(mppi_handle *h, int what, int value);
 
 /* ---- measurement (the reference only has a commented-out chrono loop, main.cpp:55-64) ------ */

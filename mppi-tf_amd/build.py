@@ -25,11 +25,12 @@ MLP_FLAGS = ["-fno-slp-vectorize"]
 MLP_ONLY_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 UNITS = ([("mppi_launch_mlp.hip", ["MPPI_UNIT_A=%d" % a], "mlp_a%d" % a) for a in (3, 2, 1, 4)]
          + [("mppi_launch_pc.hip", ["MPPI_UNIT_A=%d" % a], "pc_a%d" % a) for a in (4, 3, 2, 1)]
+         + [("mppi_launch_step.hip", ["MPPI_UNIT_A=%d" % a], "step_a%d" % a) for a in (4, 3, 2, 1)]
          + [("mppi_launch_tile.hip", ["MPPI_UNIT_A=%d" % a], "tile_a%d" % a) for a in (4, 3, 2, 1)]
          + [("mppi_launch_gen.hip", [], "gen"), ("mppi_learner.hip", [], "learner"), ("mppi_capi.hip", [], "capi")])
 SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["mppi_device.hip.h", "mppi_ablate.hip.h", "mppi_kernels.hip.h", "mppi_mlp2.hip.h", "mppi_mlp_small.hip.h", "mppi_mlp32.hip.h",
-           "mppi_handle.hip.h", "mppi_gen.hip.h", "mppi_mfma32.hip.h", "mppi_bx3.hip.h", "mppi_mlp32b.hip.h"]
+           "mppi_handle.hip.h", "mppi_step.hip.h", "mppi_gen.hip.h", "mppi_mfma32.hip.h", "mppi_bx3.hip.h", "mppi_mlp32b.hip.h"]
 ARCH = "gfx950"
 
 

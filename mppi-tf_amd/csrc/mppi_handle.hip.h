@@ -99,6 +99,19 @@ struct mppi_handle {
     unsigned *h_xchg_status = nullptr, *d_xchg_status = nullptr; // pinned, device-mapped: deadline flag for the host
     unsigned *d_xchg_dead = nullptr;                             // the same flag in device memory, read by every launch
     float *d_probe_got = nullptr;
+    // r05: the whole step in one launch / the armed launch (mppi_step.hip.h, mppi_launch_step.hip)
+    int fuse_step = 1;          // MPPI_TUNE_FUSED_STEP: 1 = a handle of <= 128 tiles runs its device-resident step as ONE launch (0: rollout + finish)
+    int arm_us = 0;             // MPPI_TUNE_ARMED_US: soft deadline of an armed launch in microseconds, 0 = mppi_next never arms
+    int arm_always = 0;         // MPPI_TUNE_ARMED_ALWAYS: arm after every mppi_next, whatever the gap between the last two calls was
+    unsigned long long *d_step_recs = nullptr; // record granules of the fused step [(2 + HA)][128]
+    unsigned long long *d_xslot = nullptr;     // x granules, stored by the HOST straight into fine-grained device memory (large BAR); NULL: no armed launches
+    unsigned long long *d_decision = nullptr;  // tile 0's verdict on an armed launch (device)
+    unsigned long long *h_arm = nullptr, *d_arm = nullptr; // pinned, device-mapped: [0] the verdict for the host, [1] the sticky error word
+    unsigned step_seq = 0;      // launch sequence numbers of fused / armed launches: 31 bits, never 0, never reused
+    bool arm_inflight = false;  // an armed launch of sequence number arm_seq sits in the stream, waiting for x
+    unsigned arm_seq = 0;
+    long long last_next_ns = 0; // steady-clock time of the previous mppi_next (the arming rule looks at the gap)
+    unsigned next_seq() { step_seq = (step_seq + 1u) & 0x7fffffffu; if (step_seq == 0u) step_seq = 1u; return step_seq; }
     size_t xchg_step_slots() const { return (size_t)2 * HA * shard_count * 3; }
     size_t xchg_inbox_bytes() const { return sizeof(unsigned long long) * (xchg_step_slots() + (size_t)2 * shard_count); }
 };
@@ -120,6 +133,11 @@ hipError_t mppi_raise_lds_ceiling(const void *kernel, int device, size_t bytes);
 MPPI_DECL_A(mppi_launch_tile_a, MPPI_TILE_PARAMS)
 MPPI_DECL_A(mppi_launch_pc_a, MPPI_PC_PARAMS)
 MPPI_DECL_A(mppi_launch_mlp_a, MPPI_MLP_PARAMS)
+// one launch of k_step_pc (mppi_step.hip.h): mode = STEP_FUSE | STEP_ARM bits; the sequence it reads / writes is given explicitly
+// (an armed launch for step n+1 is enqueued before step n's bookkeeping is committed)
+struct mppi_step_launch { int mode; const float *x_dev, *U_in; float *U_out, *u_out; unsigned seq; };
+#define MPPI_STEP_PARAMS mppi_handle *h, hipStream_t st, const mppi_step_launch *L
+MPPI_DECL_A(mppi_launch_step_a, MPPI_STEP_PARAMS)
 #undef MPPI_DECL_A
 // the 13-state AUV family (mppi_launch_gen.hip)
 const char *mppi_gen_fill(mppi_handle *h, const mppi_config *cfg); // NULL = ok, else why the config is invalid

@@ -589,11 +589,14 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols(
     const float *__restrict__ recs, int sb, int sc, int nb, int /*HA*/, int a, float neg_inv_lambda,
     const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
     float *__restrict__ record_out, int apply, unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg,
-    const float *__restrict__ clip, const float *__restrict__ nil_dev)
+    const float *__restrict__ clip, const float *__restrict__ nil_dev, const unsigned long long *__restrict__ verdict, unsigned seq)
 {
     __shared__ float red_f[kThreads / 64];
     __shared__ double red_d[2][kThreads / 64];
     const int c = blockIdx.x, tid = threadIdx.x;
+    // behind an ARMED rollout launch (mppi_step.hip.h): the update applies only if tile 0 accepted launch `seq` (its verdict word {1, seq});
+    // an aborted launch leaves U, u and the step counter as they were
+    if (verdict != nullptr && verdict[0] != (((unsigned long long)seq << 32) | 1ull)) return;
     if (nil_dev != nullptr) neg_inv_lambda = nil_dev[0]; // two-pass normalizeCost: the temperature of this step (k_cost_minmax)
     const float u_old = U_in[c];
     const unsigned long long step_old = step_ctr[0];

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for n in names:
         assert hasattr(lib, n), "libmppi_hip.so does not export " + n
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert lib.mppi_abi_version() == 4
+    assert lib.mppi_abi_version() == 5
     assert b"gfx950" in lib.mppi_version()
     assert lib.mppi_status_string(4) == b"unsupported shape or option"
 
