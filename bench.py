@@ -350,6 +350,23 @@ def cpu_baseline(workload, H, K, mlp, budget_s=12.0):
             "sample": "%d whole control steps (Philox noise + rollouts + update) of the same workload at K=%d H=%d, OpenMP over samples" % (n, Kc, H)}
 
 
+ARMED_US = 500  # soft deadline of the armed launches in the synchronous loop below (MPPI_TUNE_ARMED_US)
+
+
+def sync_record(m, workload, H, K, mlp, **handle_kw):
+    """The host-synchronous figure of a workload: mppi_next with armed launches where the handle supports them (the point-mass
+    producer/consumer path on a large-BAR system) beside the launch-per-call figure. ms."""
+    med, p95 = sync_latency(m, workload, H, K, mlp, **handle_kw)
+    rec = {"median": r4(med), "p95": r4(p95), "mode": "launch per call"}
+    if mlp is None and workload not in GEN:
+        try:
+            am, ap = sync_latency(m, workload, H, K, mlp, tuning={"armed_us": ARMED_US}, **handle_kw)
+            rec = {"median": r4(am), "p95": r4(ap), "mode": "armed launches (MPPI_TUNE_ARMED_US=%d)" % ARMED_US, "launch_per_call": {"median": r4(med), "p95": r4(p95)}}
+        except Exception as e:  # no large BAR: MPPI_ERR_UNSUPPORTED
+            rec["armed"] = "unavailable: %s" % str(e)[:80]
+    return rec
+
+
 def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20, **handle_kw):
     """Host-synchronous closed loop: mppi_next(x)->u with the plant stepped on the host (the shape of the reference's
     loop, main.cpp:37-43). Median / p95 ms per control step."""
@@ -715,8 +732,15 @@ def main():
                 out["sub_records"][0]["exchange"] = subs[0]["exchange"]
                 out["sub_records"][0]["rank_ms_per_step"] = [r4(q) for q in subs[0]["rank_ms_per_step"]]
         if world == 1:
-            med, p95 = sync_latency(m, headline, H, K, r["mlp"], **(dict(mlp_bf16x3=True) if args.bf16x3 else {}))
-            out["ms_per_control_step_sync"] = {"median": r4(med), "p95": r4(p95)}
+            out["ms_per_control_step_sync"] = sync_record(m, headline, H, K, r["mlp"], **(dict(mlp_bf16x3=True) if args.bf16x3 else {}))
+            for sr, s_ in zip(out.get("sub_records", []), subs):  # configs[1]: the synchronous figure too
+                if s_["workload"] == "pm2d":
+                    try:
+                        q = sync_record(m, "pm2d", s_["H"], s_["K_per_gpu"], None)
+                        sr["sync_ms"] = {k: q[k] for k in ("median", "p95") if k in q}
+                        sr["sync_ms"]["armed"] = q["mode"].startswith("armed")
+                    except Exception as e:
+                        sys.stderr.write("bench.py: pm2d synchronous figure skipped: %s\n" % e)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(headline, H, K, r["mlp"])
         if two_phase:  # both outcomes; the better headline is the line's

@@ -105,12 +105,13 @@ __device__ __forceinline__ void step_column(const StepArgs &sa, int c, int lane)
     if (sa.clip != nullptr) { lo = sa.clip[c % sa.a]; hi = sa.clip[sa.a + c % sa.a]; }
     const u64 *pb = sa.recs, *pe = sa.recs + nbp, *pv = sa.recs + (size_t)(2 + c) * nbp;
     const long long t0 = wall_clock64();
-    // sentinel: lane 0 polls ONE granule (this column's V of tile c mod nb: the last thing a tile stores) and the verdict
+    // sentinel: lane 0 polls ONE granule and the verdict — the beta of tile c mod nb, which its consumer stores at the tile's soft-min,
+    // a butterfly ahead of the V columns: the sweeps below then poll for well under a microsecond, and only once their tile is nearly done
     const int sent = record_slot(c % nb, nbp);
     bool off = false;
     for (unsigned it = 0;; ++it) {
         u64 g = 0ull, d = 0ull;
-        if (lane == 0) { g = gr_load(pv + sent); if (sa.decision != nullptr) d = gr_load(sa.decision); }
+        if (lane == 0) { g = gr_load(pb + sent); if (sa.decision != nullptr) d = gr_load(sa.decision); }
         const unsigned gtag = (unsigned)__builtin_amdgcn_readfirstlane((int)(g >> 32));
         const unsigned dtag = (unsigned)__builtin_amdgcn_readfirstlane((int)(d >> 32)), dval = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
         if (gtag == sa.seq) break;
@@ -120,7 +121,7 @@ __device__ __forceinline__ void step_column(const StepArgs &sa, int c, int lane)
             off = true;
             break;
         }
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(4);
     }
     if (off) return;
     // sweep: the lane's two slots x (beta, eta, V), repeated until every tag of a real slot matches
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : (NSLOT * 4
     float *buf = smem;
     float *w_s = smem;
     float *U_s = smem + 2 * CH; // ARM: the nominal sequence [H A]
-    __shared__ int go_s;
+    __shared__ int go_s;        // ARM: -1 no x yet, 1 x is here (set by the consumer the moment it sees it), 0 the step is off
 
     // role placement: as k_rollout_pc (SIMD-true consumer when the 4 waves sit on 4 SIMDs; speed only)
     const int gen = (int)(blockIdx.x >> 8);
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : (NSLOT * 4
     };
     if constexpr (ARM) { // the nominal sequence into LDS while nothing else can be done (scalar loads after x arrives would sit on the critical path)
         for (int i = tid; i < H * A; i += 64 * NW) U_s[i] = U_dev[i];
+        if (tid == 0) go_s = -1;
         __syncthreads();
     }
 
@@ -323,8 +325,9 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : (NSLOT * 4
                 }
             });
         } else {
-            // armed: everything that does not need x — the whole horizon's noise, and the first two chunks parked in the two LDS buffers
-            static_for<0, NSLOT>(draw);
+            // armed: everything that does not need x — the first two chunks parked in the two LDS buffers, then the rest of the horizon's
+            // noise for as long as x has not come (a host that answers at once finds the consumer started after two groups' worth of
+            // Philox, not six; one that takes its time finds nothing left to draw)
             auto publish_lds = [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 const int g = NP * i + p;
@@ -339,13 +342,23 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : (NSLOT * 4
                     publish(ic, ug);
                 }
             };
+            draw(std::integral_constant<int, 0>{});
             publish_lds(std::integral_constant<int, 0>{});
-            if constexpr (NSLOT > 1) publish_lds(std::integral_constant<int, 1>{});
+            if constexpr (NSLOT > 1) {
+                draw(std::integral_constant<int, 1>{});
+                publish_lds(std::integral_constant<int, 1>{});
+            }
+            int drawn = 2; // slots [0, drawn) hold their noise
+            static_for<2, NSLOT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if (drawn == i && *static_cast<volatile int *>(&go_s) < 0) { draw(ic); drawn = i + 1; }
+            });
             __syncthreads(); // B_go: the consumer has x (or the step is off); chunks 0 and 1 are published
-            if (!go_s) return;
+            if (go_s <= 0) return;
             // chunk i goes into the buffer chunk i - 2 leaves: one barrier per consumed chunk, nch - 1 in all (the consumer's count)
             static_for<2, NSLOT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
+                if (i >= drawn) draw(ic); // (also the zeros of a group beyond the horizon: phase C sums every register)
                 if (i < nch) {
                     __syncthreads(); // chunk i - 2 consumed
                     publish_lds(ic);
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : (NSLOT * 4
         float x[S];
         if constexpr (ARM) {
             const bool go = arm_wait<S>(sa, blockIdx.x == 0, lane, x);
-            if (lane == 0) go_s = go ? 1 : 0;
+            if (lane == 0) *static_cast<volatile int *>(&go_s) = go ? 1 : 0; // (the producers look at it between two groups of noise)
             __syncthreads(); // B_go
             if (!go) return;
         } else {

@@ -12,7 +12,11 @@ import torch
 import mppi_tf_amd as m
 
 K, H, a = (int(v) for v in (sys.argv[1:4] + ["65536", "64", "3"][len(sys.argv) - 1:]))
-h = m.Handle(k=K, tau=H, s_dim=2 * a, a_dim=a, dt=0.1, lam=1.0, sigma=0.25 * np.eye(a), goal=([1, 0, .5, 0, .75, 0, .25, 0])[:2 * a])
+# (the stamps live in k_rollout_pc: the two-launch step; its slot map holds 3 producers — a small K, whose default is 5, needs pc_producers 3)
+tuning = {"fused_step": 0}
+if (K + 63) // 64 <= 512:
+    tuning["pc_producers"] = 3
+h = m.Handle(k=K, tau=H, s_dim=2 * a, a_dim=a, dt=0.1, lam=1.0, sigma=0.25 * np.eye(a), goal=([1, 0, .5, 0, .75, 0, .25, 0])[:2 * a], tuning=tuning)
 x = torch.zeros(2 * a, device="cuda")
 u = torch.zeros(a, device="cuda")
 for _ in range(5):
