@@ -68,8 +68,8 @@ def parse_args():
     return ap.parse_args()
 
 
-def run_ranks(args, exchange, timeout_s, extra=()):
-    """One child job: N ranks under torch.distributed.run with MPPI_EXCHANGE=exchange, at most timeout_s seconds.
+def run_ranks(args, job_env, timeout_s, extra=()):
+    """One child job: N ranks under torch.distributed.run with job_env (MPPI_EXCHANGE, MPPI_RCCL_CALL) set, at most timeout_s seconds.
     -> (parsed JSON line or None, outcome text). The child is its own process group: on a timeout exactly that group is
     killed (SIGTERM, then SIGKILL after 10 s). Nothing is ever re-exec'd and this process never touches a GPU."""
     import signal
@@ -79,10 +79,10 @@ def run_ranks(args, exchange, timeout_s, extra=()):
         port = so.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL and the hipIpc inboxes need on this pool
-    env["MPPI_EXCHANGE"] = exchange
+    env.update(job_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + list(extra)
-    sys.stderr.write("bench.py: %d ranks, MPPI_EXCHANGE=%s, limit %d s\n" % (args.gpus, exchange, timeout_s))
+    sys.stderr.write("bench.py: %d ranks, %s, limit %d s\n" % (args.gpus, " ".join("%s=%s" % kv for kv in sorted(job_env.items())), timeout_s))
     sys.stderr.flush()
     with tempfile.TemporaryFile() as err:
         p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=err, env=env, start_new_session=True)
@@ -117,63 +117,80 @@ def run_ranks(args, exchange, timeout_s, extra=()):
         return None, "failed: unparsable line"
 
 
-def self_launch(args):
-    """`python bench.py --gpus N` typed directly (what the driver's scaling run does): run the N ranks as CHILD jobs and relay one
-    line. Nothing in this process has touched a GPU (torch is not even imported yet).
+# The multi-GPU jobs of a parent run, in order (keep one job on the path that has run before). Job 1 is the all-gather
+# through torch.distributed — three C calls + one collective per step, the path every earlier round measured (two ranks on one GPU over
+# gloo, one rank over RCCL) and the only one with no native bring-up of its own: its line is the one that must come home. Job 2 tries
+# the direct exchange (peer stores over xGMI inside the finish kernel); job 3 the one-call path (mppi_shard_step -> ncclAllGather on the
+# controller's own communicator) — neither has run between two real devices yet, and a hang in either costs a field, not the line.
+JOBS = [("rccl_torch", {"MPPI_EXCHANGE": "rccl", "MPPI_RCCL_CALL": "torch"}),
+        ("p2p", {"MPPI_EXCHANGE": "auto", "MPPI_RCCL_CALL": "c"}),
+        ("rccl_c", {"MPPI_EXCHANGE": "rccl", "MPPI_RCCL_CALL": "c"})]
 
-    VERDICT r03: the first multi-GPU lease must not come back empty. So TWO jobs, one after the other: MPPI_EXCHANGE=rccl first —
-    the all-gather path, nothing but RCCL between the devices; its line is kept — then `auto`, which tries the direct record
-    exchange (peer stores over xGMI inside the finish kernel, never run between two real devices so far). A fault, hang or bad
-    exit of the second job costs a field of the line, not the line. Each job has a time limit well inside the driver's 600 s
-    (MPPI_BENCH_BUDGET_S, default 540 s in all). The better line is printed, with both outcomes under `exchange`."""
+
+def merge_job_lines(got, outcome, order):
+    """got: job name -> parsed line (only the jobs that produced one); outcome: job name -> text for the others. -> the line to print:
+    the best headline, every job's result under `exchange`, sub-records and the parity verdict carried over from the job that has them."""
+    best = max(got, key=lambda j: got[j]["value"])
+    line = dict(got[best])
+    ex = dict(line.get("exchange") or {})
+    for j in order:
+        if j in got:
+            g = got[j]
+            gex = g.get("exchange") or {}
+            ex[j] = {"value": r4(g["value"]), "ms_per_step": r4(g["ms_per_step"]), "used": gex.get("used", g["config"].get("exchange")),
+                     "call": gex.get("rccl_call")}
+            if "parity" in g:
+                ex[j]["parity"] = g["parity"]
+            if j == "p2p" and ex[j]["used"] != "p2p":
+                ex[j]["note"] = "direct exchange not used: %s" % gex.get("direct_exchange_bring_up")
+        elif j in outcome:
+            ex[j] = outcome[j]
+    ex["printed"] = best
+    line["exchange"] = ex
+    for key in ("sub_records", "parity"):
+        if key not in line:
+            for j in order:
+                if j in got and key in got[j]:
+                    line[key] = got[j][key]
+                    if key == "parity":
+                        line["parity"] = dict(got[j][key], measured_by=j)
+                    break
+    return line
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` typed directly (what the driver's scaling run does): run the N ranks as CHILD jobs (JOBS above) and relay
+    one line. Nothing in this process has touched a GPU (torch is not even imported yet). Each job has a time limit well inside the
+    driver's 600 s (MPPI_BENCH_BUDGET_S, default 540 s in all); a job's line is written to stderr the moment it exists."""
     t_start = time.time()
     budget = float(os.environ.get("MPPI_BENCH_BUDGET_S", "540"))
     if os.environ.get("MPPI_BENCH_ONE_GPU") == "1":
         # the one-GPU rehearsal: RCCL refuses two ranks on one device, so the "rccl" job exchanges its records with gloo's all-gather
-        # (three calls + one collective per step, the torch path, staged through the host) — it walks this function's two-job logic, not RCCL
-        modes = ["rccl", "p2p"]
+        # (the torch path, staged through the host) — it walks this function's logic, not RCCL
+        jobs = [("rccl_torch", {"MPPI_EXCHANGE": "rccl", "MPPI_RCCL_CALL": "torch"}), ("p2p", {"MPPI_EXCHANGE": "p2p"})]
     elif os.environ.get("MPPI_EXCHANGE"):
-        modes = [os.environ["MPPI_EXCHANGE"]]
+        jobs = [(os.environ["MPPI_EXCHANGE"], {"MPPI_EXCHANGE": os.environ["MPPI_EXCHANGE"]})]
     else:
-        modes = ["rccl", "auto"]
+        jobs = JOBS
     got, outcome = {}, {}
-    for i, mode in enumerate(modes):
+    for i, (name, env) in enumerate(jobs):
         left = budget - (time.time() - t_start)
-        last = i == len(modes) - 1
-        limit = left - 15 if last else min(300.0, 0.6 * left)
+        last = i == len(jobs) - 1
+        limit = left - 15 if last else min(240.0, 0.55 * left)
         if limit < 45:
-            outcome[mode] = "skipped: %d s left of the %d s budget" % (left, budget)
+            outcome[name] = "skipped: %d s left of the %d s budget" % (left, budget)
             continue
-        # the second job re-measures the headline only: the configs[4] sub-record (8 ms steps) does not depend on the exchange
-        extra = ["--no-subrecords"] if (i > 0 and got) else []
-        got[mode], outcome[mode] = run_ranks(args, mode, int(limit), extra)
-        if got[mode] is None:
-            del got[mode]
+        # later jobs re-measure the headline only: the configs[4] sub-record (8 ms steps) does not depend on the exchange
+        extra = ["--no-subrecords"] if got else []
+        line, outcome[name] = run_ranks(args, env, int(limit), extra)
+        if line is not None:
+            got[name] = line
+            sys.stderr.write("bench.py: job %s: %s\n" % (name, json.dumps(line)))
+            sys.stderr.flush()
     if not got:
         sys.stderr.write("bench.py: no job produced a line: %s\n" % json.dumps(outcome))
         sys.exit(1)
-    best = max(got, key=lambda m: got[m]["value"])
-    line = got[best]
-    if len(modes) > 1:
-        ex = dict(line.get("exchange") or {})
-        for mode in modes:
-            key = "rccl" if mode == "rccl" else "p2p"
-            if mode in got:
-                g = got[mode]
-                used = (g.get("exchange") or {}).get("used", g["config"].get("exchange"))
-                rec = {"value": r4(g["value"]), "ms_per_step": r4(g["ms_per_step"]), "used": used}
-                if mode != "rccl" and used != "p2p":
-                    rec["note"] = "direct exchange not used: %s" % (g.get("exchange") or {}).get("direct_exchange_bring_up")
-                ex[key] = rec
-            else:
-                ex[key] = outcome[mode]
-        ex["printed"] = "rccl" if best == "rccl" else "p2p"
-        line["exchange"] = ex
-        if "sub_records" not in line:  # the second job ran without them
-            for mode in modes:
-                if mode in got and "sub_records" in got[mode]:
-                    line["sub_records"] = got[mode]["sub_records"]
-                    break
+    line = merge_job_lines(got, outcome, [j for j, _ in jobs]) if len(jobs) > 1 else next(iter(got.values()))
     sys.stdout.write(json.dumps(line) + "\n")
     sys.stdout.flush()
     sys.exit(0)
@@ -423,6 +440,46 @@ def valu_floor(v):
     return cyc / (v["simds"] * v["clock_mhz"]), cyc, v["simds"] * v["clock_mhz"] * 1e-3
 
 
+def sharded_parity(rn, workload, K, H, steps=3, normalize=False, unsharded_ref=True):
+    """OUTSIDE every timed region (the first multi-GPU line must carry a correctness verdict, not just a time).
+    A fresh K x world controller takes `steps` steps from (x0, U = 0, step 0); then
+      ranks_bit_identical            every rank's controls and final U, gathered and compared bit for bit (the finish is replicated: SURVEY §8e);
+      sharded_vs_unsharded_max_abs   rank 0 runs the SAME steps on ONE unsharded handle of K x world samples (same seed, global Philox
+                                     counters: the same noise) and reports max |difference| over the controls and the final U (bar 2e-6).
+    A collective: every rank calls it with the same arguments."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import mppi_tf_amd as m
+    from mppi_tf_amd.distributed import ShardedController
+    mlp = mlp_of(workload)
+    cfg = cfg_of(workload, H)
+    x = torch.tensor(cfg.pop("x0"), dtype=torch.float32, device=rn.dev) if "x0" in cfg else torch.zeros(cfg["s_dim"], dtype=torch.float32, device=rn.dev)
+    kw = dict(model_kw_of(workload, mlp), **cfg)
+    if normalize:
+        kw["normalize_cost"] = True
+    ex = os.environ.get("MPPI_EXCHANGE", "auto")
+    ctl = ShardedController(device_index=rn.local_rank, k=K * rn.world, exchange="rccl" if (normalize and ex == "p2p") else ex, p2p_timeout_ms=1000, **kw)
+    us = [ctl.next(x).clone() for _ in range(steps)]
+    torch.cuda.synchronize(rn.dev)
+    mine = np.concatenate([torch.stack(us).flatten().cpu().numpy(), ctl.backend.action_sequence().numpy().ravel()]).astype(np.float32)
+    rows = [None] * rn.world
+    if dist.is_initialized():
+        dist.all_gather_object(rows, mine.tobytes())
+    else:
+        rows = [mine.tobytes()]
+    out = {"steps": steps, "exchange": ctl.exchange, "ranks_bit_identical": all(r_ == rows[0] for r_ in rows), "finite": bool(np.isfinite(mine).all())}
+    del ctl
+    if unsharded_ref and rn.rank == 0:
+        h = m.Handle(k=K * rn.world, device=rn.local_rank, **kw)
+        xh = x.cpu().numpy()
+        ref = [h.next(xh).copy() for _ in range(steps)]
+        ref = np.concatenate([np.asarray(ref).ravel(), h.get_action_sequence().ravel()]).astype(np.float32)
+        h.close()
+        out["sharded_vs_unsharded_max_abs"] = float(np.abs(ref - mine).max())
+    return out
+
+
 class Runner:
     def __init__(self, args, dev, world, rank, local_rank):
         self.args, self.dev, self.world, self.rank, self.local_rank = args, dev, world, rank, local_rank
@@ -550,8 +607,8 @@ def r4(v):
 def roofline_of(r):
     """The bound each kernel is actually on: `mfma` for the learned 2x256 / Dense(32) models (exact-fp32
     matrix cores; the split-bf16 variants against the bf16 peak), `valu_issue` for the lane-per-rollout kernels (the analytic
-    point mass — its noise never leaves the chip, so HBM is idle (`traffic`) — the Fossen AUVModel, NNAUVModelSpeed, the small
-    networks on the vector ALU). `frac` of a valu_issue kernel = floor / kernel time, floor = the launch's COUNTED vector
+    point mass — its noise never leaves the chip, so HBM is idle (`traffic`) — the Fossen AUVModel, the small networks on the
+    vector ALU; NNAUVModelSpeed's default kernel runs its layers on the matrix cores and is priced as `mfma`). `frac` of a valu_issue kernel = floor / kernel time, floor = the launch's COUNTED vector
     instructions by class (rocprofv3 SQ_INSTS_VALU_*) x the issue cycles per instruction of the class measured on this part
     (profiles/r02_valu_issue.json) / (1024 SIMDs x 2.4 GHz) — no hand-estimated FLOP count.
     `algorithmic_hbm_frac` keeps SURVEY §8d's materialised-noise figure for the BASELINE point-mass configurations."""
@@ -576,7 +633,7 @@ def roofline_of(r):
             base["algorithmic_TFLOP_per_s"] = r4(tf / 3)
         return base
     base.update({"bound": "valu_issue", "unit": "G SIMD-cycle/s", "traffic": traffic})
-    if r["mlp"] is None and "k_rollout_gen" not in r["kernel"]:  # the BASELINE point-mass configurations: SURVEY §8d's byte model beside it
+    if r["workload"] in ("pm1d", "pm2d", "pm3d"):  # the BASELINE point-mass configurations: SURVEY §8d's byte model beside it (keyed on the workload — ADVICE r04)
         alg = r["algorithmic_bytes_per_launch"]
         base.update({"algorithmic_bytes_per_launch": alg, "algorithmic_hbm_frac": r4(alg / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS) if kus > 0 else None})
     v = prof.get("valu")
@@ -645,6 +702,7 @@ def main():
     two_phase = world > 1 and not os.environ.get("MPPI_EXCHANGE") and os.environ.get("MPPI_BENCH_CHILD") != "1"
     if two_phase:
         os.environ["MPPI_EXCHANGE"] = "rccl"
+        os.environ.setdefault("MPPI_RCCL_CALL", "torch")  # in-process: the path with no native bring-up of its own (a hang here could not be recovered from)
     if rehearsal:
         local_rank = 0
         os.environ.setdefault("MPPI_EXCHANGE", "p2p")
@@ -693,13 +751,18 @@ def main():
             # (rehearsal on one GPU: the analytic model — two MLP shards cannot be co-resident on one device, k_rollout_mlp2 owns whole CUs)
             subs.append(rn.run("pm3d" if rehearsal else "mlp", 65536, 128, 10, 2, 0.0))
 
-    p2p_line, p2p_outcome = (None, None)
-    if two_phase:
+    parity = None
+    if world > 1 or dist.is_initialized():
         try:
-            p2p_line, p2p_outcome = direct_exchange_in_children(args, world, rank, dist)
-        except Exception as e:  # whatever happens there, the measured line is printed
-            p2p_line, p2p_outcome = None, "failed: %s" % e
+            parity = sharded_parity(rn, headline, K, H)
+            if not is_mlp and headline not in GEN:
+                parity["normalize_cost"] = sharded_parity(rn, headline, K, H, normalize=True)
+            if subs:  # configs[4]'s shape: the cross-rank check only (an unsharded 524288-sample MLP step is its own benchmark)
+                parity["sub_record"] = sharded_parity(rn, subs[0]["workload"], subs[0]["K_per_gpu"], subs[0]["H"], steps=2, unsharded_ref=False)
+        except Exception as e:  # the verdict is a field of the line: its failure is reported there, the measured line still goes out
+            parity = {"error": str(e)[:300]}
 
+    out = None
     if rank == 0:
         name = CONFIG_NAME.get((headline, K, H, world), CONFIG_NAME.get((headline, K, H, 1), "not a BASELINE configuration"))
         s_dim = r["s_dim"]
@@ -723,7 +786,10 @@ def main():
             out["rccl_ranks"] = dist.get_world_size() if dist.is_initialized() else 1
             if rehearsal:
                 out["rehearsal"] = "MPPI_BENCH_ONE_GPU=1: %d ranks share ONE GPU over gloo + hipIpc; not a scaling measurement" % world
-            out["exchange"] = {"used": r["exchange"], "direct_exchange_bring_up": r["p2p_note"], "rccl_call": r["rccl_note"]}
+            call = r["rccl_note"] if r["rccl_note"] != "not requested" else "torch.distributed all_gather (three C calls + one collective call per step)"
+            out["exchange"] = {"used": r["exchange"], "direct_exchange_bring_up": r["p2p_note"], "rccl_call": call if r["exchange"] == "rccl" else None}
+            if parity is not None:
+                out["parity"] = parity
             out["rank_ms_per_step"] = [r4(q) for q in r["rank_ms_per_step"]]
         if subs:
             out["sub_records"] = [sub_record(s) for s in subs]
@@ -743,6 +809,27 @@ def main():
                         sys.stderr.write("bench.py: pm2d synchronous figure skipped: %s\n" % e)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(headline, H, K, r["mlp"])
+        if two_phase:
+            # the measured all-gather line leaves this process BEFORE the direct exchange — never run between two real
+            # devices — is tried on the same GPUs: to stderr and to a file, so that a fault there costs a field of the line, not the line
+            keep = json.dumps(out)
+            sys.stderr.write("bench.py: all-gather line (kept): %s\n" % keep)
+            sys.stderr.flush()
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "bench_allgather_line.json"), "w") as fh:
+                    fh.write(keep + "\n")
+            except OSError:
+                pass
+
+    p2p_line, p2p_outcome = (None, None)
+    if two_phase:
+        try:
+            p2p_line, p2p_outcome = direct_exchange_in_children(args, world, rank, dist)
+        except Exception as e:  # whatever happens there, the measured line is printed
+            p2p_line, p2p_outcome = None, "failed: %s" % e
+
+    if rank == 0:
         if two_phase:  # both outcomes; the better headline is the line's
             ex = dict(out.get("exchange") or {})
             ex["rccl"] = {"value": r4(out["value"]), "ms_per_step": r4(out["ms_per_step"]), "used": r["exchange"]}

@@ -462,28 +462,39 @@ class Handle:
                                          fp(w), fp(wn), fp(Un)))
         return dict(beta=beta[0], arg=arg, exp=e, nabla=nabla[0], w=w, wn=wn, Unew=Un)
 
-    # ---- device-resident step (pointers are ints: tensor.data_ptr(), stream.cuda_stream) -----
-    def next_device(self, x_ptr, u_ptr, stream=0):
-        self._check(self.lib.mppi_next_device(self.h, x_ptr, u_ptr, stream))
+    # ---- device-resident step (pointers are ints: tensor.data_ptr()) -----
+    @staticmethod
+    def _stream(stream):
+        """The C-ABI's `void *stream` from what a Python caller holds. None = the handle's own stream (NULL in C). A torch stream object or its
+        `.cuda_stream` integer names that stream — and torch's DEFAULT stream, whose handle is 0, is passed as hipStreamLegacy (1): a raw 0 that
+        came out of torch must never select the handle's own non-blocking stream, which nothing of torch's is ordered against (the stale-record
+        race of r04; ADVICE r04: mapped once, here, for every caller)."""
+        if stream is None:
+            return 0
+        v = getattr(stream, "cuda_stream", stream)
+        return int(v) or 1
 
-    def shard_partial(self, x_ptr, record_ptr, stream=0):
-        self._check(self.lib.mppi_shard_partial(self.h, x_ptr, record_ptr, stream))
+    def next_device(self, x_ptr, u_ptr, stream=None):
+        self._check(self.lib.mppi_next_device(self.h, x_ptr, u_ptr, self._stream(stream)))
 
-    def shard_finish(self, records_ptr, n_records, u_ptr, stream=0):
-        self._check(self.lib.mppi_shard_finish(self.h, records_ptr, n_records, u_ptr, stream))
+    def shard_partial(self, x_ptr, record_ptr, stream=None):
+        self._check(self.lib.mppi_shard_partial(self.h, x_ptr, record_ptr, self._stream(stream)))
 
-    def shard_cost_range(self, x_ptr, range_ptr, stream=0):
+    def shard_finish(self, records_ptr, n_records, u_ptr, stream=None):
+        self._check(self.lib.mppi_shard_finish(self.h, records_ptr, n_records, u_ptr, self._stream(stream)))
+
+    def shard_cost_range(self, x_ptr, range_ptr, stream=None):
         """normalize_cost on a sharded handle, first half: {-min, max} of this shard's sample costs -> range_ptr[2]"""
-        self._check(self.lib.mppi_shard_cost_range(self.h, x_ptr, range_ptr, stream))
+        self._check(self.lib.mppi_shard_cost_range(self.h, x_ptr, range_ptr, self._stream(stream)))
 
-    def shard_partial_normalized(self, x_ptr, range_ptr, record_ptr, stream=0):
+    def shard_partial_normalized(self, x_ptr, range_ptr, record_ptr, stream=None):
         """... second half: range_ptr[2] = the {-min, max} all ranks agreed on (all-reduce MAX) -> this shard's record"""
-        self._check(self.lib.mppi_shard_partial_normalized(self.h, x_ptr, range_ptr, record_ptr, stream))
+        self._check(self.lib.mppi_shard_partial_normalized(self.h, x_ptr, range_ptr, record_ptr, self._stream(stream)))
 
     # ---- options of the Python reference's update ---------------------------------------------
-    def shard_step(self, x_ptr, u_ptr, coll=None, stream=0):
+    def shard_step(self, x_ptr, u_ptr, coll=None, stream=None):
         """mppi_shard_step: the whole sharded step in ONE call; coll = a Collectives (or None on an unsharded handle: record -> finish)"""
-        self._check(self.lib.mppi_shard_step(self.h, x_ptr, u_ptr, C.byref(coll) if coll is not None else None, stream))
+        self._check(self.lib.mppi_shard_step(self.h, x_ptr, u_ptr, C.byref(coll) if coll is not None else None, self._stream(stream)))
 
     def set_action_limits(self, a_min=None, a_max=None):
         """clip_act (controller_base.py:500-504): clamp U' rows to [a_min, a_max]; None, None = off"""
@@ -515,13 +526,13 @@ class Handle:
         arr = (C.c_void_p * len(inbox_ptrs))(*inbox_ptrs)
         self._check(self.lib.mppi_shard_p2p_attach(self.h, arr, len(inbox_ptrs), timeout_ms))
 
-    def p2p_probe(self, stream=0):
+    def p2p_probe(self, stream=None):
         ok = C.c_int(0)
-        self._check(self.lib.mppi_shard_p2p_probe(self.h, stream, C.byref(ok)))
+        self._check(self.lib.mppi_shard_p2p_probe(self.h, self._stream(stream), C.byref(ok)))
         return bool(ok.value)
 
-    def p2p_step(self, x_ptr, u_ptr, stream=0):
-        self._check(self.lib.mppi_shard_p2p_step(self.h, x_ptr, u_ptr, stream))
+    def p2p_step(self, x_ptr, u_ptr, stream=None):
+        self._check(self.lib.mppi_shard_p2p_step(self.h, x_ptr, u_ptr, self._stream(stream)))
 
     def p2p_timed_out(self):
         t = C.c_int(0)

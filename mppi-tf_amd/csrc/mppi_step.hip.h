@@ -15,6 +15,13 @@
 //   fine-grained device memory that the host stores into directly (large BAR) — {x_i, seq} granules again — and starts the recurrence
 //   the moment they arrive. What a synchronous step then pays is the granules' flight and the recurrence, not launch + dispatch + Philox
 //   (chain_probe: host round trip 2.8 us armed against 8.2 us launch-after-write).
+// STEP_SPLIT (with STEP_FUSE)  the consumer's work on two wavefronts. A lone wave issues one vector instruction every 4 to 8 cycles
+//   whatever its dependences (tools/timeline.py at configs[1]: 66 ns per step for ~20 instructions), and with one tile per CU the
+//   tile's whole duration is that wave's 64-step chain. The RECURRENCE wave keeps only x <- A x + (B/m) v (8 instructions per step at
+//   a = 2) and hands every post-step state, with the step's action cost, to the COST wave through an LDS ring of one chunk; the cost
+//   wave evaluates the state cost and keeps the running sum in the reference's order. Inside a chunk the two are coupled by a progress
+//   counter in LDS (written after the state, read before it: LDS operations of one wave execute in order), at chunk ends by the
+//   workgroup barrier everybody joins. Same operations on the same operands: bit-identical costs.
 //   Who decides: ONLY tile 0's consumer. It accepts (x complete before its soft deadline) or aborts (deadline passed, or the host
 //   stored the cancel tag) and says so in a decision granule (device) and in a pinned host word. Every other wave takes x from the host
 //   slot as soon as it is complete but gives up only on tile 0's abort (or a hard deadline, which raises a sticky error): a late x that
@@ -26,7 +33,7 @@
 namespace mppi {
 
 typedef unsigned long long u64;
-enum { STEP_FUSE = 1, STEP_ARM = 2 };
+enum { STEP_FUSE = 1, STEP_ARM = 2, STEP_SPLIT = 4 };
 constexpr unsigned kArmAccept = 1u, kArmAbort = 2u, kArmCancelBit = 0x80000000u; // tags are 31-bit launch sequence numbers; bit 31 = the host's cancel
 
 struct StepArgs {
@@ -185,16 +192,25 @@ __device__ __forceinline__ void step_column(const StepArgs &sa, int c, int lane)
 // The kernel. Grid: nb tile workgroups (+ ceil(HA / (NP + 1)) column workgroups under STEP_FUSE), 64 (NP + 1) threads, dynamic LDS
 // pc_lds_floats(A, NP) * 4 (+ H A floats under STEP_ARM: the nominal sequence, staged before x arrives).
 // Without STEP_FUSE the tile records go out as plain floats for k_finish_cols (partials, rsb, rsc: as k_rollout_pc).
+// floats of one (step, lane) state record of the split consumer: the S post-step states + the action cost, in whole 16-byte parts
+__host__ __device__ constexpr int step_rec_floats(int A) { return (2 * A + 1 + 3) / 4 * 4; }
+__host__ __device__ inline size_t step_lds_floats(int A, int NP, int HA, int mode)
+{
+    return pc_lds_floats(A, NP) + ((mode & STEP_ARM) ? (size_t)((HA + 3) & ~3) : 0) + ((mode & STEP_SPLIT) ? (size_t)4 * NP * 64 * step_rec_floats(A) : 0);
+}
+
 template <int A, int NP, int NSLOT, bool DIAG, int MODE>
-__global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : (NSLOT * 4 * A <= 80 ? NP + 1 : 2))) void k_step_pc( // (a fused grid has at most 128 tiles: one workgroup per CU)
+__global__ __launch_bounds__(64 * (NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0)), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 3 : (NSLOT * 4 * A <= 80 ? NP + 1 : 2))) void k_step_pc( // (a fused grid has at most 128 tiles: one workgroup per CU; the 6-wave workgroup serves at most 512: two per CU)
     const DevConsts *__restrict__ C, const float *__restrict__ x_dev, const float *__restrict__ U_dev,
     const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
     const int rsb, const int rsc, const int balance, const StepArgs sa)
 {
-    constexpr bool FUSE = (MODE & STEP_FUSE) != 0, ARM = (MODE & STEP_ARM) != 0;
+    constexpr bool FUSE = (MODE & STEP_FUSE) != 0, ARM = (MODE & STEP_ARM) != 0, SPLIT = (MODE & STEP_SPLIT) != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 2 * A;
-    constexpr int NW = NP + 1;
+    constexpr int NW = NP + 1 + (SPLIT ? 1 : 0); // roles: 0 consumer (SPLIT: the recurrence wave), 1..NP producers, NP + 1 the cost wave
+    constexpr int SR = step_rec_floats(A), NV = SR / 4;
+    typedef float f4_t __attribute__((ext_vector_type(4)));
     constexpr int CS = 4 * NP;
     constexpr int SLOT = pc_slot_floats(A);
     constexpr bool PACKED = SLOT != A + 1 || A == 3;
@@ -218,7 +234,10 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : (NSLOT * 4
     float *buf = smem;
     float *w_s = smem;
     float *U_s = smem + 2 * CH; // ARM: the nominal sequence [H A]
+    float *ring = smem + 2 * CH + (ARM ? ((H * A + 3) & ~3) : 0); // SPLIT: the chunk's state records [CS][NV][64 lanes][4]
     __shared__ int go_s;        // ARM: -1 no x yet, 1 x is here (set by the consumer the moment it sees it), 0 the step is off
+    __shared__ int r_done_s;    // SPLIT: horizon steps whose state record the recurrence wave has stored
+    if (SPLIT && tid == 0) r_done_s = 0; // (a workgroup barrier lies between this and the first use on either path)
 
     // role placement: as k_rollout_pc (SIMD-true consumer when the 4 waves sit on 4 SIMDs; speed only)
     const int gen = (int)(blockIdx.x >> 8);
@@ -245,7 +264,7 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : (NSLOT * 4
         __syncthreads();
     }
 
-    if (wave != 0) {
+    if (wave != 0 && wave <= NP) {
         // ------------------------------------------------------------------ producers
         const int p = wave - 1;
         const unsigned int gk = (unsigned int)C->k_offset + (unsigned int)(k0 + lane);
@@ -308,7 +327,7 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : (NSLOT * 4
             static_for<0, NSLOT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 const int g = NP * i + p;
-                if (balance) pc_set_prio(i, nch, gen);
+                if (balance && !FUSE) pc_set_prio(i, nch, gen);
                 float ug[4][A];
                 if (i < nch && g < NG) {
 #pragma unroll
@@ -382,8 +401,74 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : (NSLOT * 4
             const int t = 4 * (NP * i + p) + tl;
             if (n < NREG && t < H) put(2 + t * A + j, tot[m]);
         }
+    } else if (SPLIT && wave == NP + 1) {
+        // ------------------------------------------------------------------ cost wave (SPLIT): the consumer's cost half, a few steps behind
+        PcConsumerConsts<S> ccst;
+        ccst.load(C);
+        const PcConsumerConsts<S> *CC = &ccst;
+        if constexpr (ARM) {
+            __syncthreads(); // B_go
+            if (go_s <= 0) return;
+        } else {
+            __syncthreads(); // chunk 0 published
+        }
+        __builtin_amdgcn_s_setprio(2);
+        float c = 0.0f;
+        float xs[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) xs[i] = 0.0f;
+        for (int ch = 0; ch < nch; ++ch) {
+            const int tend = min(CS, H - ch * CS);
+            int tl = 0;
+            auto cost_of_record = [&](const float (&rec)[SR]) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) xs[i] = rec[i];
+                const float sc = state_cost<S, false>(CC, xs); // cost on the POST-step state
+                const float tmp = sc + rec[S];                 // Step_cost_result cost_base.cpp:49
+                c = c + tmp;                                   // path_cost        controller_base.cpp:268
+            };
+            auto load_record = [&](int t, float (&rec)[SR]) {
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const f4_t v4 = *static_cast<const f4_t *>(__builtin_assume_aligned(ring + ((t * NV + q) * 64 + lane) * 4, 16));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rec[4 * q + j] = v4[j];
+                }
+            };
+            while (tl < tend) {
+                // the recurrence wave announces its records four at a time (one at a time in a ragged tail): four records are requested
+                // together, so the LDS latency is paid once per four steps
+                const int avail = min(*static_cast<volatile int *>(&r_done_s) - ch * CS, tend);
+                asm volatile("" ::: "memory"); // the records are read after the counter that announces them
+                while (tl + 4 <= avail) {
+                    float r4[4][SR];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) load_record(tl + q, r4[q]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cost_of_record(r4[q]);
+                    tl += 4;
+                }
+                if (avail - tl > 0 && avail - tl < 4 && avail == tend) { // the ragged tail of the last chunk (H not a multiple of 4)
+                    for (; tl < tend; ++tl) {
+                        float rec[SR];
+                        load_record(tl, rec);
+                        cost_of_record(rec);
+                    }
+                }
+            }
+            if (ch + 1 < nch) __syncthreads(); // the recurrence wave reuses the ring
+        }
+        c = c + state_cost<S, false>(CC, xs); // terminal: x_H counted a second time, :271-272
+        if (valid) cost[k0 + lane] = c;
+        const float beta = wave_min(valid ? c : INFINITY);
+        const float arg = CC->neg_inv_lambda * (c - beta);
+        const float ek = valid ? expf(arg) : 0.0f;
+        const float eta = wave_sum(ek);
+        w_s[lane] = ek;
+        if (lane == 0) { put(0, beta); put(1, eta); }
+        __syncthreads(); // weights published
     } else {
-        // ------------------------------------------------------------------ consumer
+        // ------------------------------------------------------------------ consumer (SPLIT: its recurrence half)
         PcConsumerConsts<S> ccst;
         ccst.load(C);
         const PcConsumerConsts<S> *CC = &ccst;
@@ -398,9 +483,64 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : (NSLOT * 4
             for (int i = 0; i < S; ++i) x[i] = x_dev[i];
             __syncthreads(); // chunk 0 published
         }
+        if constexpr (FUSE) __builtin_amdgcn_s_setprio(3); // one workgroup per CU: the tile lasts as long as this wave's chain
+        if constexpr (SPLIT) {
+            for (int ch = 0; ch < nch; ++ch) {
+                const float *cb = buf + (ch & 1) * CH;
+                const int tend = min(CS, H - ch * CS);
+                auto load_slot = [&](int t, float (&v)[A], float &ac) {
+                    if constexpr (PACKED) {
+                        const slot_t sv = *static_cast<const slot_t *>(__builtin_assume_aligned(cb + (t * 64 + lane) * SLOT, SLOT * 4));
+#pragma unroll
+                        for (int j = 0; j < A; ++j) v[j] = sv[j];
+                        ac = sv[A];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < A; ++j) v[j] = cb[(t * (A + 1) + j) * 64 + lane];
+                        ac = cb[(t * (A + 1) + A) * 64 + lane];
+                    }
+                };
+                auto step_and_store = [&](int t, const float (&v)[A], float ac) {
+                    float rec[SR];
+                    pm_step<A>(CC, x, v);
+#pragma unroll
+                    for (int i = 0; i < S; ++i) rec[i] = x[i];
+                    rec[S] = ac;
+#pragma unroll
+                    for (int i = S + 1; i < SR; ++i) rec[i] = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) {
+                        f4_t v4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v4[j] = rec[4 * q + j];
+                        *static_cast<f4_t *>(__builtin_assume_aligned(ring + ((t * NV + q) * 64 + lane) * 4, 16)) = v4;
+                    }
+                };
+                int tl = 0;
+                for (; tl + 4 <= tend; tl += 4) { // four slots requested together, four records announced together
+                    float v4[4][A], ac4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) load_slot(tl + q, v4[q], ac4[q]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) step_and_store(tl + q, v4[q], ac4[q]);
+                    asm volatile("" ::: "memory"); // the counter is stored after the records it announces (LDS executes a wave's operations in order)
+                    if (lane == 0) *static_cast<volatile int *>(&r_done_s) = ch * CS + tl + 4;
+                }
+                for (; tl < tend; ++tl) { // ragged tail of the last chunk
+                    float v[A], ac;
+                    load_slot(tl, v, ac);
+                    step_and_store(tl, v, ac);
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) *static_cast<volatile int *>(&r_done_s) = ch * CS + tl + 1;
+                }
+                if (ch + 1 < nch) __syncthreads(); // chunk ch consumed by both halves / chunk ch+1 published
+            }
+            __syncthreads(); // weights published (by the cost wave)
+            return;
+        }
         float c = 0.0f;
         for (int ch = 0; ch < nch; ++ch) {
-            if (balance) pc_set_prio(ch, nch, gen, MPPI_PC_CONSUMER_BOOST);
+            if (balance && !FUSE) pc_set_prio(ch, nch, gen, MPPI_PC_CONSUMER_BOOST);
             const float *cb = buf + (ch & 1) * CH;
             const int tend = min(CS, H - ch * CS);
             for (int tl = 0; tl < tend; ++tl) {

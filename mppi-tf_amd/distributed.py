@@ -44,11 +44,10 @@ class HipShardBackend:
         self.normalize = bool(cfg.get("normalize_cost", False))
 
     def _stream(self):
-        """torch's CURRENT stream as the library's `void *stream`. torch's default stream is the legacy null stream, whose handle is 0 —
-        which the C-ABI reads as "the handle's own stream" (a non-blocking stream nothing of torch's is ordered against: the record would
-        race with the collective that reads it and x with the torch op that wrote it; found by the two-rank rehearsal of r04, where the
-        gathered records were one step stale). hipStreamLegacy ((hipStream_t)1) names the null stream explicitly."""
-        return torch.cuda.current_stream(self.device).cuda_stream or 1
+        """torch's CURRENT stream, for Handle's stream arguments (Handle._stream maps torch's default stream, whose handle is 0, to
+        hipStreamLegacy: the C-ABI reads 0 as "the handle's own stream", which nothing of torch's is ordered against — the record would race
+        with the collective that reads it; found by the two-rank rehearsal of r04, where the gathered records were one step stale)."""
+        return torch.cuda.current_stream(self.device)
 
     def partial(self, x, record):
         self.h.shard_partial(x.data_ptr(), record.data_ptr(), self._stream())
