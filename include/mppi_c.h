@@ -90,7 +90,8 @@ enum { MPPI_DBG_COSTS = 0,    /* c[K_local]         sample costs of the last ste
        MPPI_DBG_ETA = 2,      /* [1]                Σ exp(-(c-β)/λ)                          */
        MPPI_DBG_WEIGHTS = 3,  /* w[K_local]         exp(-(c-β)/λ)/η                          */
        MPPI_DBG_NOISE = 4,    /* eps[K_local,tau,a] the noise the last step used             */
-       MPPI_DBG_U_UPDATED = 5 /* U'[tau,a]          updated sequence before the shift        */ };
+       MPPI_DBG_U_UPDATED = 5,/* U'[tau,a]          updated sequence before the shift        */
+       MPPI_DBG_AUX = 6       /* [8]                beta, eta, and the words timing-study builds stamp (tools/timeline_step.py) */ };
 
 /* Learned model_base: Dense(relu) x (n_layers-1) + Dense(linear) -> s_dim outputs. */
 typedef struct {
@@ -369,8 +370,7 @@ enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instea
        MPPI_TUNE_GEN_ONE_WAVE = 9,
        /* r05 (ABI 5), the point-mass producer/consumer path with the diagonal quadratic cost (mppi_step.hip.h): */
        MPPI_TUNE_FUSED_STEP = 10,       /* default 1: a handle of <= 128 tiles (K <= 8192) runs its Philox step as ONE launch — tiles and the column waves that
-                                         * finish them in one grid, records handed over as {value, sequence} granules, the consumer's recurrence and its
-                                         * costs on two waves; 2: the same with the consumer on one wave; 0: rollout launch + finish launch */
+                                         * finish them in one grid, records handed over as {value, sequence} granules; 0: rollout launch + finish launch */
        MPPI_TUNE_ARMED_US = 11,         /* default 0 (off). N > 0: once two mppi_next calls have followed each other within N microseconds, a call leaves the NEXT
                                          * step's launch behind it, armed: resident on the GPU, its noise drawn, waiting up to N us for x. The next mppi_next then
                                          * only stores x into device memory (large BAR) and watches the pinned u slot — no launch, no dispatch between x and u.

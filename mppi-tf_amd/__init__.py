@@ -12,7 +12,7 @@ hand-written HIP for gfx950 in csrc/, reached through the C-ABI of include/mppi_
   distributed.py   K-sharding across GPUs (one process per GPU, one all-gather per step)
 """
 from . import build as _build  # noqa: F401
-from ._lib import (ACTION_COST_CPP, ACTION_COST_PY, CSV_REFERENCE, CSV_ROUNDTRIP, DBG_BETA, DBG_COSTS, DBG_ETA, DBG_NOISE,
+from ._lib import (ACTION_COST_CPP, ACTION_COST_PY, CSV_REFERENCE, CSV_ROUNDTRIP, DBG_AUX, DBG_BETA, DBG_COSTS, DBG_ETA, DBG_NOISE,
                    DBG_U_UPDATED, DBG_WEIGHTS, Handle, MppiError, load)
 from .controller import ControllerBase, ControllerBaseCpp, CostBase, ElipseCost, PointMassModel, StaticCost
 from .auv import AUVModel, ElipseCost3D, NNAUVModel, NNAUVModelSpeed, StaticQuatCost
@@ -21,4 +21,4 @@ from ._lib import Learner
 
 __all__ = ["Handle", "MppiError", "load", "ControllerBase", "ControllerBaseCpp", "CostBase", "PointMassModel",
            "StaticCost", "ElipseCost", "AUVModel", "NNAUVModel", "NNAUVModelSpeed", "StaticQuatCost", "ElipseCost3D", "LearnerBase", "Learner", "ACTION_COST_CPP", "ACTION_COST_PY", "DBG_COSTS", "DBG_BETA", "DBG_ETA", "DBG_WEIGHTS",
-           "DBG_NOISE", "DBG_U_UPDATED", "CSV_REFERENCE", "CSV_ROUNDTRIP"]
+           "DBG_NOISE", "DBG_U_UPDATED", "DBG_AUX", "CSV_REFERENCE", "CSV_ROUNDTRIP"]

@@ -18,7 +18,7 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_SINGULAR_SIGMA
 MODEL_POINT_MASS, MODEL_MLP, MODEL_AUV, MODEL_NN_AUV, MODEL_NN_AUV_SPEED = 0, 1, 2, 3, 4
 STATE_COST_QUADRATIC, STATE_COST_ELLIPSE, STATE_COST_QUAT, STATE_COST_ELLIPSE3D = 0, 1, 2, 3
 ACTION_COST_CPP, ACTION_COST_PY = 0, 1
-DBG_COSTS, DBG_BETA, DBG_ETA, DBG_WEIGHTS, DBG_NOISE, DBG_U_UPDATED = range(6)
+DBG_COSTS, DBG_BETA, DBG_ETA, DBG_WEIGHTS, DBG_NOISE, DBG_U_UPDATED, DBG_AUX = range(7)
 CSV_REFERENCE, CSV_ROUNDTRIP = 0, 1
 # mppi_set_tuning items (diagnostics; the library reads no environment variable)
 TUNING = {"force_tile_kernel": 0, "pc_producers": 1, "pc_balance": 2, "pc_lds_min": 3, "sync_spin": 4, "p2p_fault": 5, "mlp_v1": 6, "mlp32_valu": 7,
@@ -384,7 +384,7 @@ class Handle:
 
     def debug_get(self, what):
         n = {DBG_COSTS: self.k_local, DBG_BETA: 1, DBG_ETA: 1, DBG_WEIGHTS: self.k_local,
-             DBG_NOISE: self.k_local * self.tau * self.a, DBG_U_UPDATED: self.tau * self.a}[what]
+             DBG_NOISE: self.k_local * self.tau * self.a, DBG_U_UPDATED: self.tau * self.a, DBG_AUX: 8}[what]
         out = np.zeros(n, np.float32)
         self._check(self.lib.mppi_debug_get(self.h, what, fp(out), n))
         if what == DBG_NOISE:

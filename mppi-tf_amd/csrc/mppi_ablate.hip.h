@@ -70,7 +70,10 @@ __device__ __forceinline__ unsigned long long pc_stamp()
 #define MPPI_STORE_COST(valid, ptr, c) do { } while (0)
 // let the producers finish and stamp (a few hundred cycles), then dump the stamps in place of the costs
 #define MPPI_TL_DUMP(valid, ptr) do { for (int q_ = 0; q_ < 8; ++q_) __builtin_amdgcn_s_sleep(127); if (valid) *(ptr) = tl_s[lane]; } while (0)
+// (k_step_pc's column wave 0: 100 MHz stamps of its start, its sentinel, its sweep and its store into the handle's debug words 2..5)
+#define MPPI_COL_STAMP(sa, c, lane, i) do { if ((c) == 0 && (lane) == 0 && (sa).dbg != nullptr) (sa).dbg[2 + (i)] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull); } while (0)
 #else
+#define MPPI_COL_STAMP(sa, c, lane, i) do { } while (0)
 #define MPPI_TL_DECL() do { } while (0)
 #define MPPI_STAMP_RT(slot) do { } while (0)
 #define MPPI_STAMP(slot) do { } while (0)

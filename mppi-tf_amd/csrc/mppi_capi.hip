@@ -816,7 +816,7 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
         else if (h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp_bx3<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
         else std::snprintf(buf, n, "mppi::k_rollout_mlp<%d, %s>", h->a, h->sigma_diag ? "true" : "false");
     else if (fuse_ok(h)) // the whole step in one launch (mppi_step.hip.h)
-        std::snprintf(buf, n, "mppi::k_step_pc<%d, 5, %d, %s, %d>", h->a, NG <= 20 ? 4 : 8, h->sigma_diag ? "true" : "false", h->fuse_step == 1 ? 5 : 1);
+        std::snprintf(buf, n, "mppi::k_step_pc<%d, 5, %d, %s, 1>", h->a, NG <= 20 ? 4 : 8, h->sigma_diag ? "true" : "false");
     else if (pc_eligible(h)) // (normalizeCost: two passes of it on the fused path; injected noise runs the tile kernel)
     {
         const int ck = h->hc.state_cost_kind == MPPI_STATE_COST_ELLIPSE ? 1 : (h->hc.q_full ? 2 : 0); // PC_COST_* (spelled out as the profiler spells it)
@@ -901,7 +901,7 @@ static mppi_status fused_step(mppi_handle *h, hipStream_t st, const float *x_dev
     const bool prof = h->prof_n < h->prof_cap;
     h->kev0 = prof ? h->ev[4 * h->prof_n + 0] : nullptr; // the launch's own begin / end
     h->kev1 = prof ? h->ev[4 * h->prof_n + 1] : nullptr;
-    const mppi_step_launch L{STEP_FUSE | (h->fuse_step == 1 ? STEP_SPLIT : 0), x_dev, h->U_cur(), h->U_other(), u_dev, h->next_seq()};
+    const mppi_step_launch L{STEP_FUSE, x_dev, h->U_cur(), h->U_other(), u_dev, h->next_seq()};
     const hipError_t e = launch_step(h, st, &L);
     h->kev0 = h->kev1 = nullptr;
     HIP_TRY(h, e);
@@ -919,7 +919,7 @@ static mppi_status fused_step(mppi_handle *h, hipStream_t st, const float *x_dev
 // enqueued before this one has been applied (the caller's bookkeeping may still be one step behind).
 static mppi_status arm_launch(mppi_handle *h, const float *U_in, float *U_out, unsigned seq)
 {
-    const int mode = STEP_ARM | (fuse_ok(h) ? (STEP_FUSE | (h->fuse_step == 1 ? STEP_SPLIT : 0)) : 0);
+    const int mode = STEP_ARM | (fuse_ok(h) ? STEP_FUSE : 0);
     float *u_arg = h->d_pin + 2 * kMaxS;
     if (!(mode & STEP_FUSE)) HIP_TRY(h, ensure_record_layout(h, h->stream, h->nb));
     const mppi_step_launch L{mode, nullptr, U_in, U_out, u_arg, seq};
@@ -1400,9 +1400,7 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
     if (!h) return MPPI_ERR_INVALID_ARG;
     MPPI_ENTER(h); // (an armed launch was built for the handle as it was)
     switch (what) {
-    case MPPI_TUNE_FUSED_STEP:
-        if (value < 0 || value > 2) return fail(h, MPPI_ERR_INVALID_ARG, "fused step: 0 off, 1 on (consumer on two waves), 2 on (consumer on one wave)");
-        h->fuse_step = value; break;
+    case MPPI_TUNE_FUSED_STEP: h->fuse_step = value != 0; break;
     case MPPI_TUNE_ARMED_US:
         if (value < 0 || value > 1000000) return fail(h, MPPI_ERR_INVALID_ARG, "armed launch: soft deadline 0 (off) .. 1000000 us");
         if (value > 0 && !h->d_xslot)
@@ -1499,6 +1497,7 @@ extern "C" mppi_status mppi_debug_get(mppi_handle *h, int what, float *out, size
     case MPPI_DBG_COSTS: src = h->d_cost; need = K; break;
     case MPPI_DBG_BETA: src = h->d_dbg; need = 1; break;
     case MPPI_DBG_ETA: src = h->d_dbg + 1; need = 1; break;
+    case MPPI_DBG_AUX: src = h->d_dbg; need = 8; break; // beta, eta, and what a timing-study build left in the other words
     case MPPI_DBG_U_UPDATED: // U' of the last step = the current buffer from offset 0 (the warm start reads it from offset a)
         if (!h->d_Uupd) return fail(h, MPPI_ERR_INVALID_ARG, "no step has run since the action sequence was set");
         src = h->d_Uupd; need = (size_t)h->HA; break;

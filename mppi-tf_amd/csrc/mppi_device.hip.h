@@ -396,6 +396,88 @@ __device__ __forceinline__ void pm_step(const CT *__restrict__ C, float (&x)[2 *
     for (int i = 0; i < 2 * A; ++i) x[i] = fr[i] + ac[i];
 }
 
+// ----------------------------------------------------------------------------------------
+// The point-mass step and the diagonal quadratic cost in PACKED form (two fp32 per v_pk_* instruction), written out instead of left
+// to the SLP vectoriser (which finds some pairs, builds them with v_mov, and changes its mind with the shape of the loop around them).
+// Axes go in pairs: P = (p_2i, p_2i+1), Q = (q_2i, q_2i+1); an odd last axis travels as L = (p, q). Per element these are exactly
+// pm_step's and state_cost<S, false>'s operations in their order (IEEE add and multiply per lane, no contraction), and the cost's sum runs
+// over the state index 0, 1, 2, ... as the reference's diffT·(Q·diff) does: bit-identical to the scalar forms above and below.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int A>
+struct PmPack {
+    static constexpr int NPR = A / 2;
+    static constexpr bool ODD = (A & 1) != 0;
+    static constexpr int NA = NPR ? NPR : 1;
+    float dt;
+    v2f dt2, bp2, bq2, bpq;
+    v2f gP[NA], gQ[NA], qP[NA], qQ[NA], gL, qL;
+    template <class CT>
+    __device__ __forceinline__ void load(const CT *__restrict__ C)
+    {
+        dt = C->dt;
+        dt2 = v2f{C->dt, C->dt}; bp2 = v2f{C->bp, C->bp}; bq2 = v2f{C->bq, C->bq}; bpq = v2f{C->bp, C->bq};
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) {
+            gP[i] = v2f{C->goal[4 * i], C->goal[4 * i + 2]}; gQ[i] = v2f{C->goal[4 * i + 1], C->goal[4 * i + 3]};
+            qP[i] = v2f{C->qdiag[4 * i], C->qdiag[4 * i + 2]}; qQ[i] = v2f{C->qdiag[4 * i + 1], C->qdiag[4 * i + 3]};
+        }
+        if constexpr (ODD) { gL = v2f{C->goal[2 * A - 2], C->goal[2 * A - 1]}; qL = v2f{C->qdiag[2 * A - 2], C->qdiag[2 * A - 1]}; }
+    }
+};
+template <int A>
+struct PmState {
+    static constexpr int NA = (A / 2) ? (A / 2) : 1;
+    v2f P[NA], Q[NA], L;
+    __device__ __forceinline__ void from(const float (&x)[2 * A])
+    {
+#pragma unroll
+        for (int i = 0; i < A / 2; ++i) { P[i] = v2f{x[4 * i], x[4 * i + 2]}; Q[i] = v2f{x[4 * i + 1], x[4 * i + 3]}; }
+        if constexpr (A & 1) L = v2f{x[2 * A - 2], x[2 * A - 1]};
+    }
+};
+// x <- A x + (B/m) v  (pm_step): fr_p = p + dt q ; x_p = fr_p + bp v ; x_q = q + bq v
+template <int A>
+__device__ __forceinline__ void pm_step_packed(const PmPack<A> &K, PmState<A> &s, const float (&v)[A])
+{
+#pragma unroll
+    for (int i = 0; i < A / 2; ++i) {
+        const v2f V = v2f{v[2 * i], v[2 * i + 1]};
+        const v2f acp = K.bp2 * V, acq = K.bq2 * V;
+        const v2f m = K.dt2 * s.Q[i];
+        const v2f f = s.P[i] + m;
+        s.P[i] = f + acp;
+        s.Q[i] = s.Q[i] + acq;
+    }
+    if constexpr (A & 1) {
+        const v2f ac = K.bpq * v2f{v[A - 1], v[A - 1]};
+        const float m = K.dt * s.L.y;
+        const v2f fr = v2f{s.L.x + m, s.L.y};
+        s.L = fr + ac;
+    }
+}
+// diffT (Q diff), Q diagonal, summed over the state index in order (state_cost<S, false>)
+template <int A>
+__device__ __forceinline__ float state_cost_packed(const PmPack<A> &K, const PmState<A> &s)
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < A / 2; ++i) {
+        const v2f dP = s.P[i] - K.gP[i], dQ = s.Q[i] - K.gQ[i];
+        const v2f tP = dP * (K.qP[i] * dP), tQ = dQ * (K.qQ[i] * dQ);
+        acc = i == 0 ? tP.x : acc + tP.x; // (the scalar form starts from diff[0]*left[0], not from 0 + it)
+        acc = acc + tQ.x;
+        acc = acc + tP.y;
+        acc = acc + tQ.y;
+    }
+    if constexpr (A & 1) {
+        const v2f dL = s.L - K.gL;
+        const v2f tL = dL * (K.qL * dL);
+        acc = A == 1 ? tL.x : acc + tL.x;
+        acc = acc + tL.y;
+    }
+    return acc;
+}
+
 // cost_base.cpp:56-61 mStateCost: diff = x-g ; left = Q·diff ; cost = diffᵀ·left.
 template <int S, bool QFULL, class CT = DevConsts>
 __device__ __forceinline__ float state_cost(const CT *__restrict__ C, const float (&x)[S])

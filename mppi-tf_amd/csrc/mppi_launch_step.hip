@@ -10,8 +10,8 @@ template <int A, int NP, int NSLOT, int MODE>
 static hipError_t launch_step_inst(mppi_handle *h, hipStream_t st, const mppi_step_launch *L)
 {
     constexpr bool FUSE = (MODE & STEP_FUSE) != 0, ARM = (MODE & STEP_ARM) != 0;
-    constexpr int NW = NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0);
-    const size_t lds = std::max(step_lds_floats(A, NP, h->HA, MODE) * 4, (size_t)h->pc_lds_min);
+    constexpr int NW = NP + 1;
+    const size_t lds = std::max(pc_lds_floats(A, NP) * 4 + (ARM ? sizeof(float) * (size_t)h->HA : 0), (size_t)h->pc_lds_min);
     const int nb = (h->K_local + 63) / 64;
     const int ncw = FUSE ? (h->HA + NW - 1) / NW : 0;
     const dim3 g(nb + ncw), b(64 * NW);
@@ -37,13 +37,9 @@ hipError_t MPPI_CAT(mppi_launch_step_a, MPPI_UNIT_A)(MPPI_STEP_PARAMS)
 {
     constexpr int AA = MPPI_UNIT_A;
     const int NG = (h->H + 3) / 4;
-    if (L->mode & STEP_FUSE) { // <= 128 tiles: 5 producers, and the consumer on two waves unless MPPI_TUNE_FUSED_STEP = 2 asks for one
+    if (L->mode & STEP_FUSE) { // <= 128 tiles: always the 6-wave workgroup
         if (h->pc_np != 5) return hipErrorInvalidValue;
         const bool small = NG <= 20;
-        if (L->mode & STEP_SPLIT) {
-            if (L->mode & STEP_ARM) return small ? launch_step_inst<AA, 5, 4, STEP_FUSE | STEP_ARM | STEP_SPLIT>(h, st, L) : launch_step_inst<AA, 5, 8, STEP_FUSE | STEP_ARM | STEP_SPLIT>(h, st, L);
-            return small ? launch_step_inst<AA, 5, 4, STEP_FUSE | STEP_SPLIT>(h, st, L) : launch_step_inst<AA, 5, 8, STEP_FUSE | STEP_SPLIT>(h, st, L);
-        }
         if (L->mode & STEP_ARM) return small ? launch_step_inst<AA, 5, 4, STEP_FUSE | STEP_ARM>(h, st, L) : launch_step_inst<AA, 5, 8, STEP_FUSE | STEP_ARM>(h, st, L);
         return small ? launch_step_inst<AA, 5, 4, STEP_FUSE>(h, st, L) : launch_step_inst<AA, 5, 8, STEP_FUSE>(h, st, L);
     }

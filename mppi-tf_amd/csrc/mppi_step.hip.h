@@ -15,13 +15,6 @@
 //   fine-grained device memory that the host stores into directly (large BAR) — {x_i, seq} granules again — and starts the recurrence
 //   the moment they arrive. What a synchronous step then pays is the granules' flight and the recurrence, not launch + dispatch + Philox
 //   (chain_probe: host round trip 2.8 us armed against 8.2 us launch-after-write).
-// STEP_SPLIT (with STEP_FUSE)  the consumer's work on two wavefronts. A lone wave issues one vector instruction every 4 to 8 cycles
-//   whatever its dependences (tools/timeline.py at configs[1]: 66 ns per step for ~20 instructions), and with one tile per CU the
-//   tile's whole duration is that wave's 64-step chain. The RECURRENCE wave keeps only x <- A x + (B/m) v (8 instructions per step at
-//   a = 2) and hands every post-step state, with the step's action cost, to the COST wave through an LDS ring of one chunk; the cost
-//   wave evaluates the state cost and keeps the running sum in the reference's order. Inside a chunk the two are coupled by a progress
-//   counter in LDS (written after the state, read before it: LDS operations of one wave execute in order), at chunk ends by the
-//   workgroup barrier everybody joins. Same operations on the same operands: bit-identical costs.
 //   Who decides: ONLY tile 0's consumer. It accepts (x complete before its soft deadline) or aborts (deadline passed, or the host
 //   stored the cancel tag) and says so in a decision granule (device) and in a pinned host word. Every other wave takes x from the host
 //   slot as soon as it is complete but gives up only on tile 0's abort (or a hard deadline, which raises a sticky error): a late x that
@@ -33,7 +26,7 @@
 namespace mppi {
 
 typedef unsigned long long u64;
-enum { STEP_FUSE = 1, STEP_ARM = 2, STEP_SPLIT = 4 };
+enum { STEP_FUSE = 1, STEP_ARM = 2 };
 constexpr unsigned kArmAccept = 1u, kArmAbort = 2u, kArmCancelBit = 0x80000000u; // tags are 31-bit launch sequence numbers; bit 31 = the host's cancel
 
 struct StepArgs {
@@ -112,6 +105,7 @@ __device__ __forceinline__ void step_column(const StepArgs &sa, int c, int lane)
     if (sa.clip != nullptr) { lo = sa.clip[c % sa.a]; hi = sa.clip[sa.a + c % sa.a]; }
     const u64 *pb = sa.recs, *pe = sa.recs + nbp, *pv = sa.recs + (size_t)(2 + c) * nbp;
     const long long t0 = wall_clock64();
+    MPPI_COL_STAMP(sa, c, lane, 0);
     // sentinel: lane 0 polls ONE granule and the verdict — the beta of tile c mod nb, which its consumer stores at the tile's soft-min,
     // a butterfly ahead of the V columns: the sweeps below then poll for well under a microsecond, and only once their tile is nearly done
     const int sent = record_slot(c % nb, nbp);
@@ -131,6 +125,7 @@ __device__ __forceinline__ void step_column(const StepArgs &sa, int c, int lane)
         __builtin_amdgcn_s_sleep(4);
     }
     if (off) return;
+    MPPI_COL_STAMP(sa, c, lane, 1);
     // sweep: the lane's two slots x (beta, eta, V), repeated until every tag of a real slot matches
     const int q = nbp >> 3;
     float bb[2], ee[2], vv[2];
@@ -165,6 +160,7 @@ __device__ __forceinline__ void step_column(const StepArgs &sa, int c, int lane)
         }
         __builtin_amdgcn_s_sleep(2);
     }
+    MPPI_COL_STAMP(sa, c, lane, 2);
     const float beta = wave_min(fminf(bb[0], bb[1]));
     double se[2], sv[2];
 #pragma unroll
@@ -187,30 +183,22 @@ __device__ __forceinline__ void step_column(const StepArgs &sa, int c, int lane)
         if (c < sa.a) sa.u_out[c] = un;  // mGetNew
         if (c == 0) sa.step_ctr[0] = step_old + 1ull;
     }
+    MPPI_COL_STAMP(sa, c, lane, 3);
 }
 
 // The kernel. Grid: nb tile workgroups (+ ceil(HA / (NP + 1)) column workgroups under STEP_FUSE), 64 (NP + 1) threads, dynamic LDS
 // pc_lds_floats(A, NP) * 4 (+ H A floats under STEP_ARM: the nominal sequence, staged before x arrives).
 // Without STEP_FUSE the tile records go out as plain floats for k_finish_cols (partials, rsb, rsc: as k_rollout_pc).
-// floats of one (step, lane) state record of the split consumer: the S post-step states + the action cost, in whole 16-byte parts
-__host__ __device__ constexpr int step_rec_floats(int A) { return (2 * A + 1 + 3) / 4 * 4; }
-__host__ __device__ inline size_t step_lds_floats(int A, int NP, int HA, int mode)
-{
-    return pc_lds_floats(A, NP) + ((mode & STEP_ARM) ? (size_t)((HA + 3) & ~3) : 0) + ((mode & STEP_SPLIT) ? (size_t)4 * NP * 64 * step_rec_floats(A) : 0);
-}
-
 template <int A, int NP, int NSLOT, bool DIAG, int MODE>
-__global__ __launch_bounds__(64 * (NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0)), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 3 : (NSLOT * 4 * A <= 80 ? NP + 1 : 2))) void k_step_pc( // (a fused grid has at most 128 tiles: one workgroup per CU; the 6-wave workgroup serves at most 512: two per CU)
+__global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 3 : (NSLOT * 4 * A <= 80 ? NP + 1 : 2))) void k_step_pc( // (a fused grid has at most 128 tiles: one workgroup per CU; the 6-wave workgroup serves at most 512: two per CU)
     const DevConsts *__restrict__ C, const float *__restrict__ x_dev, const float *__restrict__ U_dev,
     const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
     const int rsb, const int rsc, const int balance, const StepArgs sa)
 {
-    constexpr bool FUSE = (MODE & STEP_FUSE) != 0, ARM = (MODE & STEP_ARM) != 0, SPLIT = (MODE & STEP_SPLIT) != 0;
+    constexpr bool FUSE = (MODE & STEP_FUSE) != 0, ARM = (MODE & STEP_ARM) != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 2 * A;
-    constexpr int NW = NP + 1 + (SPLIT ? 1 : 0); // roles: 0 consumer (SPLIT: the recurrence wave), 1..NP producers, NP + 1 the cost wave
-    constexpr int SR = step_rec_floats(A), NV = SR / 4;
-    typedef float f4_t __attribute__((ext_vector_type(4)));
+    constexpr int NW = NP + 1;
     constexpr int CS = 4 * NP;
     constexpr int SLOT = pc_slot_floats(A);
     constexpr bool PACKED = SLOT != A + 1 || A == 3;
@@ -233,11 +221,9 @@ __global__ __launch_bounds__(64 * (NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0)), ((MO
     const int nch = (NG + NP - 1) / NP;
     float *buf = smem;
     float *w_s = smem;
+    MPPI_TL_DECL(); // (timing-study builds only, mppi_ablate.hip.h: slots 0..9 the consumer, 10 + 8 p + {0 start, 1..4 chunk published, 5 weights, 6 stored} producer p; 100 MHz stamps)
     float *U_s = smem + 2 * CH; // ARM: the nominal sequence [H A]
-    float *ring = smem + 2 * CH + (ARM ? ((H * A + 3) & ~3) : 0); // SPLIT: the chunk's state records [CS][NV][64 lanes][4]
     __shared__ int go_s;        // ARM: -1 no x yet, 1 x is here (set by the consumer the moment it sees it), 0 the step is off
-    __shared__ int r_done_s;    // SPLIT: horizon steps whose state record the recurrence wave has stored
-    if (SPLIT && tid == 0) r_done_s = 0; // (a workgroup barrier lies between this and the first use on either path)
 
     // role placement: as k_rollout_pc (SIMD-true consumer when the 4 waves sit on 4 SIMDs; speed only)
     const int gen = (int)(blockIdx.x >> 8);
@@ -264,7 +250,7 @@ __global__ __launch_bounds__(64 * (NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0)), ((MO
         __syncthreads();
     }
 
-    if (wave != 0 && wave <= NP) {
+    if (wave != 0) {
         // ------------------------------------------------------------------ producers
         const int p = wave - 1;
         const unsigned int gk = (unsigned int)C->k_offset + (unsigned int)(k0 + lane);
@@ -274,6 +260,7 @@ __global__ __launch_bounds__(64 * (NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0)), ((MO
         PcProducerConsts<A> pcst;
         pcst.template load<DIAG>(C);
         const PcProducerConsts<A> *PC = &pcst;
+        MPPI_STAMP_RT(10 + 8 * p);
         // the noise of horizon group g = NP i + p -> eps_r (zeros where the group does not exist)
         auto draw = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -340,6 +327,7 @@ __global__ __launch_bounds__(64 * (NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0)), ((MO
                 draw(ic);
                 if (i < nch) {
                     if (g < NG) publish(ic, ug);
+                    MPPI_STAMP_RT(10 + 8 * p + 1 + (i < 4 ? i : 3));
                     __syncthreads(); // chunk i published
                 }
             });
@@ -386,6 +374,7 @@ __global__ __launch_bounds__(64 * (NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0)), ((MO
             if (nch >= 2) __syncthreads(); // chunk nch - 2 consumed (the last chunk was published before it)
         }
         __syncthreads(); // weights published by the consumer
+        MPPI_STAMP_RT(10 + 8 * p + 5);
         // phase C from registers: V_b[t,j] = sum_k e_k eps[k,t,j]  (mWeightedNoise, controller_base.cpp:188-192)
         const float w = w_s[lane];
 #pragma unroll
@@ -401,74 +390,9 @@ __global__ __launch_bounds__(64 * (NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0)), ((MO
             const int t = 4 * (NP * i + p) + tl;
             if (n < NREG && t < H) put(2 + t * A + j, tot[m]);
         }
-    } else if (SPLIT && wave == NP + 1) {
-        // ------------------------------------------------------------------ cost wave (SPLIT): the consumer's cost half, a few steps behind
-        PcConsumerConsts<S> ccst;
-        ccst.load(C);
-        const PcConsumerConsts<S> *CC = &ccst;
-        if constexpr (ARM) {
-            __syncthreads(); // B_go
-            if (go_s <= 0) return;
-        } else {
-            __syncthreads(); // chunk 0 published
-        }
-        __builtin_amdgcn_s_setprio(2);
-        float c = 0.0f;
-        float xs[S];
-#pragma unroll
-        for (int i = 0; i < S; ++i) xs[i] = 0.0f;
-        for (int ch = 0; ch < nch; ++ch) {
-            const int tend = min(CS, H - ch * CS);
-            int tl = 0;
-            auto cost_of_record = [&](const float (&rec)[SR]) {
-#pragma unroll
-                for (int i = 0; i < S; ++i) xs[i] = rec[i];
-                const float sc = state_cost<S, false>(CC, xs); // cost on the POST-step state
-                const float tmp = sc + rec[S];                 // Step_cost_result cost_base.cpp:49
-                c = c + tmp;                                   // path_cost        controller_base.cpp:268
-            };
-            auto load_record = [&](int t, float (&rec)[SR]) {
-#pragma unroll
-                for (int q = 0; q < NV; ++q) {
-                    const f4_t v4 = *static_cast<const f4_t *>(__builtin_assume_aligned(ring + ((t * NV + q) * 64 + lane) * 4, 16));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) rec[4 * q + j] = v4[j];
-                }
-            };
-            while (tl < tend) {
-                // the recurrence wave announces its records four at a time (one at a time in a ragged tail): four records are requested
-                // together, so the LDS latency is paid once per four steps
-                const int avail = min(*static_cast<volatile int *>(&r_done_s) - ch * CS, tend);
-                asm volatile("" ::: "memory"); // the records are read after the counter that announces them
-                while (tl + 4 <= avail) {
-                    float r4[4][SR];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) load_record(tl + q, r4[q]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cost_of_record(r4[q]);
-                    tl += 4;
-                }
-                if (avail - tl > 0 && avail - tl < 4 && avail == tend) { // the ragged tail of the last chunk (H not a multiple of 4)
-                    for (; tl < tend; ++tl) {
-                        float rec[SR];
-                        load_record(tl, rec);
-                        cost_of_record(rec);
-                    }
-                }
-            }
-            if (ch + 1 < nch) __syncthreads(); // the recurrence wave reuses the ring
-        }
-        c = c + state_cost<S, false>(CC, xs); // terminal: x_H counted a second time, :271-272
-        if (valid) cost[k0 + lane] = c;
-        const float beta = wave_min(valid ? c : INFINITY);
-        const float arg = CC->neg_inv_lambda * (c - beta);
-        const float ek = valid ? expf(arg) : 0.0f;
-        const float eta = wave_sum(ek);
-        w_s[lane] = ek;
-        if (lane == 0) { put(0, beta); put(1, eta); }
-        __syncthreads(); // weights published
+        MPPI_STAMP_RT(10 + 8 * p + 6);
     } else {
-        // ------------------------------------------------------------------ consumer (SPLIT: its recurrence half)
+        // ------------------------------------------------------------------ consumer
         PcConsumerConsts<S> ccst;
         ccst.load(C);
         const PcConsumerConsts<S> *CC = &ccst;
@@ -479,71 +403,73 @@ __global__ __launch_bounds__(64 * (NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0)), ((MO
             __syncthreads(); // B_go
             if (!go) return;
         } else {
+            MPPI_STAMP_RT(0);
+            MPPI_STAMP(60); // (shader-clock stamps 60 / 61 against the 100 MHz stamps 0 / 9: the clock the tile really ran at)
 #pragma unroll
             for (int i = 0; i < S; ++i) x[i] = x_dev[i];
             __syncthreads(); // chunk 0 published
         }
-        if constexpr (FUSE) __builtin_amdgcn_s_setprio(3); // one workgroup per CU: the tile lasts as long as this wave's chain
-        if constexpr (SPLIT) {
-            for (int ch = 0; ch < nch; ++ch) {
-                const float *cb = buf + (ch & 1) * CH;
-                const int tend = min(CS, H - ch * CS);
-                auto load_slot = [&](int t, float (&v)[A], float &ac) {
-                    if constexpr (PACKED) {
-                        const slot_t sv = *static_cast<const slot_t *>(__builtin_assume_aligned(cb + (t * 64 + lane) * SLOT, SLOT * 4));
-#pragma unroll
-                        for (int j = 0; j < A; ++j) v[j] = sv[j];
-                        ac = sv[A];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < A; ++j) v[j] = cb[(t * (A + 1) + j) * 64 + lane];
-                        ac = cb[(t * (A + 1) + A) * 64 + lane];
-                    }
-                };
-                auto step_and_store = [&](int t, const float (&v)[A], float ac) {
-                    float rec[SR];
-                    pm_step<A>(CC, x, v);
-#pragma unroll
-                    for (int i = 0; i < S; ++i) rec[i] = x[i];
-                    rec[S] = ac;
-#pragma unroll
-                    for (int i = S + 1; i < SR; ++i) rec[i] = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < NV; ++q) {
-                        f4_t v4;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v4[j] = rec[4 * q + j];
-                        *static_cast<f4_t *>(__builtin_assume_aligned(ring + ((t * NV + q) * 64 + lane) * 4, 16)) = v4;
-                    }
-                };
-                int tl = 0;
-                for (; tl + 4 <= tend; tl += 4) { // four slots requested together, four records announced together
-                    float v4[4][A], ac4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) load_slot(tl + q, v4[q], ac4[q]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) step_and_store(tl + q, v4[q], ac4[q]);
-                    asm volatile("" ::: "memory"); // the counter is stored after the records it announces (LDS executes a wave's operations in order)
-                    if (lane == 0) *static_cast<volatile int *>(&r_done_s) = ch * CS + tl + 4;
-                }
-                for (; tl < tend; ++tl) { // ragged tail of the last chunk
-                    float v[A], ac;
-                    load_slot(tl, v, ac);
-                    step_and_store(tl, v, ac);
-                    asm volatile("" ::: "memory");
-                    if (lane == 0) *static_cast<volatile int *>(&r_done_s) = ch * CS + tl + 1;
-                }
-                if (ch + 1 < nch) __syncthreads(); // chunk ch consumed by both halves / chunk ch+1 published
-            }
-            __syncthreads(); // weights published (by the cost wave)
-            return;
-        }
+        // With one workgroup per CU (a fused grid) the tile lasts as long as this wave's H-step chain, and a lone wave is bound by the
+        // latency between dependent instructions (~8 cycles; tools/timeline.py: 158 cycles per step at a = 2 for ~20 instructions), not by
+        // their number. So: the top priority for good; the steps in groups of four — the NEXT group's slots requested before this group
+        // is computed (the LDS round trip leaves the chain), the four recurrence steps first, then their four state costs, which do not
+        // depend on each other, then the running sum in the reference's order. The same operations on the same operands: the same bits.
+        if constexpr (FUSE) __builtin_amdgcn_s_setprio(3);
         float c = 0.0f;
+        MPPI_STAMP_RT(1);
+        auto load_group = [&](const float *cb, int t0, float (&v)[4][A], float (&ac)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (PACKED) {
+                    const slot_t sv = *static_cast<const slot_t *>(__builtin_assume_aligned(cb + ((t0 + q) * 64 + lane) * SLOT, SLOT * 4));
+#pragma unroll
+                    for (int j = 0; j < A; ++j) v[q][j] = sv[j];
+                    ac[q] = sv[A];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < A; ++j) v[q][j] = cb[((t0 + q) * (A + 1) + j) * 64 + lane];
+                    ac[q] = cb[((t0 + q) * (A + 1) + A) * 64 + lane];
+                }
+            }
+        };
+        PmPack<A> pk;
+        pk.load(CC);
+        PmState<A> st;
+        st.from(x);
+        auto run_group = [&](const float (&v)[4][A], const float (&ac)[4]) {
+            PmState<A> xs[4];
+            float sc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pm_step_packed<A>(pk, st, v[q]);
+                xs[q] = st;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sc[q] = state_cost_packed<A>(pk, xs[q]); // cost on the POST-step state
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float tmp = sc[q] + ac[q]; // Step_cost_result cost_base.cpp:49
+                c = c + tmp;                     // path_cost        controller_base.cpp:268
+            }
+        };
         for (int ch = 0; ch < nch; ++ch) {
             if (balance && !FUSE) pc_set_prio(ch, nch, gen, MPPI_PC_CONSUMER_BOOST);
             const float *cb = buf + (ch & 1) * CH;
             const int tend = min(CS, H - ch * CS);
-            for (int tl = 0; tl < tend; ++tl) {
+            const int ng = tend >> 2;
+            float va[4][A], aca[4], vb[4][A], acb[4];
+            // (the prefetch is unconditional — past the last group it re-reads that group: a load under a runtime predicate would be
+            // waited for on the spot)
+            if (ng > 0) load_group(cb, 0, va, aca);
+            for (int g = 0; g < ng;) {
+                load_group(cb, 4 * min(g + 1, ng - 1), vb, acb);
+                run_group(va, aca);
+                if (++g >= ng) break;
+                load_group(cb, 4 * min(g + 1, ng - 1), va, aca);
+                run_group(vb, acb);
+                ++g;
+            }
+            for (int tl = 4 * ng; tl < tend; ++tl) { // ragged tail of the last chunk (H not a multiple of 4)
                 float v[A], ac;
                 if constexpr (PACKED) {
                     const slot_t sv = *static_cast<const slot_t *>(__builtin_assume_aligned(cb + (tl * 64 + lane) * SLOT, SLOT * 4));
@@ -555,15 +481,16 @@ __global__ __launch_bounds__(64 * (NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0)), ((MO
                     for (int j = 0; j < A; ++j) v[j] = cb[(tl * (A + 1) + j) * 64 + lane];
                     ac = cb[(tl * (A + 1) + A) * 64 + lane];
                 }
-                pm_step<A>(CC, x, v);
-                const float sc = state_cost<S, false>(CC, x); // cost on the POST-step state
-                const float tmp = sc + ac;                    // Step_cost_result cost_base.cpp:49
-                c = c + tmp;                                  // path_cost        controller_base.cpp:268
+                pm_step_packed<A>(pk, st, v);
+                const float sc = state_cost_packed<A>(pk, st);
+                const float tmp = sc + ac;
+                c = c + tmp;
             }
+            MPPI_STAMP_RT(2 + (ch < 4 ? ch : 3));
             if (ch + 1 < nch) __syncthreads(); // chunk ch consumed / chunk ch+1 published
         }
-        c = c + state_cost<S, false>(CC, x); // terminal: x_H counted a second time, :271-272
-        if (valid) cost[k0 + lane] = c;
+        c = c + state_cost_packed<A>(pk, st); // terminal: x_H counted a second time, :271-272
+        MPPI_STORE_COST(valid, cost + k0 + lane, c);
         // tile-local mBeta / mExpArg / mExp / mNabla (controller_base.cpp:166-182)
         const float beta = wave_min(valid ? c : INFINITY);
         const float arg = CC->neg_inv_lambda * (c - beta);
@@ -571,7 +498,10 @@ __global__ __launch_bounds__(64 * (NP + 1 + ((MODE & STEP_SPLIT) ? 1 : 0)), ((MO
         const float eta = wave_sum(ek);
         w_s[lane] = ek;
         if (lane == 0) { put(0, beta); put(1, eta); }
+        MPPI_STAMP_RT(9);
+        MPPI_STAMP(61);
         __syncthreads(); // weights published
+        MPPI_TL_DUMP(valid, cost + k0 + lane);
     }
 }
 

@@ -53,13 +53,11 @@ def closed_loop(h, a, steps, x0=None):
 SHAPES = [(128, 32, 1), (4096, 64, 2), (3000, 50, 3), (8192, 64, 3), (200, 7, 4), (1000, 100, 2), (64, 4, 2), (65, 64, 3), (5000, 160, 1)]
 
 
-@pytest.mark.parametrize("fused", [1, 2])
 @pytest.mark.parametrize("K,H,a", SHAPES)
-def test_fused_step_equals_two_launch_step(m, K, H, a, fused):
-    """Same x sequence through a fused handle (1: the consumer's recurrence and costs on two waves, the default; 2: on one) and a
-    two-launch handle: controls, U', costs, step counter — the same bits."""
+def test_fused_step_equals_two_launch_step(m, K, H, a):
+    """Same x sequence through a fused handle and a two-launch handle: controls, U', costs, step counter — the same bits."""
     c = cfg_of(K, H, a)
-    hf, h2 = m.Handle(tuning={"fused_step": fused}, **c), m.Handle(tuning={"fused_step": 0}, **c)
+    hf, h2 = m.Handle(**c), m.Handle(tuning={"fused_step": 0}, **c)
     assert "k_step_pc" in hf.rollout_kernel_name() and "k_rollout_pc" in h2.rollout_kernel_name()
     x = np.zeros(2 * a, F32)
     for i in range(6):

@@ -68,7 +68,7 @@ def sync(tuning, n=600):
 nb = (K + 63) // 64
 out = {"K": K, "H": H, "a": a, "tiles": nb}
 print(json.dumps(out))
-modes = [("two_launches", {"fused_step": 0})] + ([("fused_one_consumer_wave", {"fused_step": 2}), ("fused", {"fused_step": 1})] if nb <= 128 else [])
+modes = [("two_launches", {"fused_step": 0})] + ([("fused", {"fused_step": 1})] if nb <= 128 else [])
 for name, t in modes:
     print(json.dumps({"pipelined": name, **pipelined(t)}), flush=True)
 for name, t in modes:
