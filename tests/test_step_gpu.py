@@ -50,7 +50,7 @@ def closed_loop(h, a, steps, x0=None):
     return np.asarray(us), x
 
 
-SHAPES = [(128, 32, 1), (4096, 64, 2), (3000, 50, 3), (8192, 64, 3), (200, 7, 4), (1000, 100, 2), (64, 4, 2), (65, 64, 3), (5000, 160, 1)]
+SHAPES = [(128, 32, 1), (4096, 64, 2), (3000, 50, 3), (8192, 64, 3), (200, 7, 4), (1000, 100, 2), (64, 4, 2), (65, 64, 3), (5000, 160, 1), (777, 80, 4), (2048, 79, 2), (100, 1, 3)]
 
 
 @pytest.mark.parametrize("K,H,a", SHAPES)
