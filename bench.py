@@ -659,6 +659,8 @@ def sub_record(s):
         {"mlp32": "ref Dense(32)x3", "nnauv": "ref NNAUVModel s13 a6", "auv": "ref Fossen AUVModel rk2", "nnspeed": "ref NNAUVModelSpeed Dense(16)x3"}.get(s["workload"], "")
     if "bx3" in s["kernel"]:
         name += " +BF16X3"
+    if s["kernel"].endswith("3, 0>") and "k_rollout_pc" in s["kernel"]:
+        name += " +FP_CONTRACT"
     rf = roofline_of(s)
     # (the line has to stay below 4 KB: a sub-record keeps the kernel, its bound, frac = achieved / peak and the time; peaks and units are
     # DESIGN.md §4's — 157.3 TFLOP/s exact-fp32 MFMA, 2500 bf16, 2458 G SIMD-cycle/s for valu_issue; K = 65536, H = 64 unless given)
@@ -736,6 +738,7 @@ def main():
     if args.workload is None and not args.no_subrecords:
         if world == 1:  # the other single-GPU BASELINE configs, so that one driver run measures them all
             subs.append(rn.run("pm2d", 4096, 64, steps, args.warmup, args.min_time))
+            subs.append(rn.run("pm3d", 65536, 64, steps, args.warmup, 0.3, fp_contract=True))  # MPPI_FLAG_FP_CONTRACT: the opt-in contracted instance
             subs.append(rn.run("mlp", 65536, 64, 20, 3, 0.0))
             subs.append(rn.run("mlp", 65536, 64, 20, 3, 0.0, mlp_bf16x3=True))
             # (sub-second steps: batches repeated for 0.15 s and the median taken, as for the headline — a single 20-step batch of a 0.2 ms step

@@ -78,11 +78,16 @@ enum { MPPI_STATE_COST_QUADRATIC = 0, /* (x-g)ᵀQ(x-g)   src/cost_base.cpp:56-6
 /* mppi_config.flags */
 enum { MPPI_FLAG_UPSILON_SCALES_NOISE = 1, /* Py build_noise: eps = (υΣ)·z while the cost keeps Σ⁻¹ of the
                                               un-augmented Σ (controller_base.py:362-368, cost_base.py:35-41) */
-       MPPI_FLAG_MLP_BF16X3 = 2 /* learned models (point mass: 256- or 32-wide hidden layers; NNAUVModel: 32-wide): the layers run on the BF16
+       MPPI_FLAG_MLP_BF16X3 = 2, /* learned models (point mass: 256- or 32-wide hidden layers; NNAUVModel: 32-wide): the layers run on the BF16
                                    matrix cores with every fp32 operand split into two bf16 values and three products per
                                    term (fp32 accumulate): ~2x the rounding error of the exact-fp32 path (sample costs
                                    within 1e-6 relative of fp64 on the synthetic network), 1.7-3.3x its speed. Off by
-                                   default: the default MLP path is exact fp32 (v_mfma_f32_32x32x2_f32). */ };
+                                   default: the default MLP path is exact fp32 (v_mfma_f32_32x32x2_f32). */
+       MPPI_FLAG_FP_CONTRACT = 4 /* point mass, diagonal quadratic cost, Philox noise: the rollout kernel evaluates the model step, the state cost
+                                   and the action cost with FUSED multiply-adds (one rounding per pair instead of two) — ~15 % fewer vector
+                                   instructions in an issue-bound kernel. Sample costs are then NOT bit-identical to the reference's op-by-op
+                                   fp32 evaluation: they agree with an fp64 evaluation to 2e-6 relative (as the unfused evaluation does), the update to 1e-5 (tests). Off by
+                                   default; the fused one-launch step and the armed launches are not taken by such a handle. */ };
 
 /* what mppi_debug_get returns (observer_base.py:101-187 logs the same intermediates) */
 enum { MPPI_DBG_COSTS = 0,    /* c[K_local]         sample costs of the last step            */

@@ -194,7 +194,7 @@ class Handle:
     def __init__(self, k, tau, s_dim, a_dim, dt=0.1, mass=1.0, lam=1.0, gamma=1.0, upsilon=1.0,
                  sigma=None, goal=None, Q=None, q_is_full=None, action_cost=ACTION_COST_CPP,
                  normalize_cost=False, seed=1, device=0, shard_rank=0, shard_count=1, mlp=None,
-                 upsilon_scales_noise=False, mlp_bf16x3=False, tuning=None, log_rows=0, ellipse=None,
+                 upsilon_scales_noise=False, mlp_bf16x3=False, fp_contract=False, tuning=None, log_rows=0, ellipse=None,
                  auv=None, nnauv=None, quat_cost=False, ellipse3d=None, nnauv_speed=None):
         """mlp: dict(W=[W1,W2,W3], b=[b1,b2,b3], xmean=, xstd=, ymean=, ystd=) selects the learned
         model_base (Dense(256,relu) x2 + Dense(s_dim); Keras [in x out] kernels).
@@ -212,7 +212,7 @@ class Handle:
         cfg.lam, cfg.gamma, cfg.upsilon = lam, gamma, upsilon
         cfg.action_cost_kind, cfg.normalize_cost = action_cost, int(bool(normalize_cost))
         cfg.seed, cfg.device, cfg.shard_rank, cfg.shard_count = seed, device, shard_rank, shard_count
-        cfg.flags = (1 if upsilon_scales_noise else 0) | (2 if mlp_bf16x3 else 0)  # MPPI_FLAG_UPSILON_SCALES_NOISE | MPPI_FLAG_MLP_BF16X3
+        cfg.flags = (1 if upsilon_scales_noise else 0) | (2 if mlp_bf16x3 else 0) | (4 if fp_contract else 0)  # MPPI_FLAG_UPSILON_SCALES_NOISE | _MLP_BF16X3 | _FP_CONTRACT
         keep = []
         if ellipse is not None:  # ElipseCost (elipse_cost.py:9-85): dict or the 7 numbers a, b, cx, cy, speed, m_state, m_vel
             e = [ellipse[k] for k in ("a", "b", "cx", "cy", "speed", "m_state", "m_vel")] if isinstance(ellipse, dict) else ellipse

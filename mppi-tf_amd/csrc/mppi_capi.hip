@@ -412,6 +412,7 @@ extern "C" mppi_status mppi_create(const mppi_config *cfg, mppi_handle **out)
     else if (tile_lds_floats(h->HA, R) * 4 > lds_cap) h->no_rollout = "tau*a_dim too large: the 16-rollout LDS tile exceeds 160 KiB";
     h->R = R; h->nb = (h->K_local + R - 1) / R; h->tile_lds = tile_lds_floats(h->HA, R) * 4;
     h->mlp_bx3 = ((cfg->model_kind == MPPI_MODEL_MLP || cfg->model_kind == MPPI_MODEL_NN_AUV) && (cfg->flags & MPPI_FLAG_MLP_BF16X3)) ? 1 : 0;
+    h->fp_contract = (cfg->model_kind == MPPI_MODEL_POINT_MASS && (cfg->flags & MPPI_FLAG_FP_CONTRACT)) ? 1 : 0;
     h->mlp_small = ((cfg->model_kind == MPPI_MODEL_MLP && cfg->mlp->widths[0] != kHid) || cfg->model_kind == MPPI_MODEL_NN_AUV ||
                     cfg->model_kind == MPPI_MODEL_NN_AUV_SPEED) ? cfg->mlp->widths[0] : 0;
     h->is_gen = gen ? 1 : 0;
@@ -537,7 +538,7 @@ static hipError_t launch_step(mppi_handle *h, hipStream_t st, const mppi_step_la
 static bool step_shape_ok(const mppi_handle *h)
 {
     return pc_eligible(h) && h->hc.state_cost_kind == MPPI_STATE_COST_QUADRATIC && !h->hc.q_full && !h->normalize && h->shard_count == 1 &&
-           h->sg_window == 0 && h->d_decision != nullptr;
+           h->sg_window == 0 && h->d_decision != nullptr && !h->fp_contract;
 }
 // the whole step in ONE launch: at most 128 tiles (K <= 8192), the 6-wave workgroup
 static bool fuse_ok(const mppi_handle *h) { return h->fuse_step && step_shape_ok(h) && h->nb <= 128 && h->pc_np == 5 && h->d_step_recs != nullptr; }
@@ -819,7 +820,7 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
         std::snprintf(buf, n, "mppi::k_step_pc<%d, 5, %d, %s, 1>", h->a, NG <= 20 ? 4 : 8, h->sigma_diag ? "true" : "false");
     else if (pc_eligible(h)) // (normalizeCost: two passes of it on the fused path; injected noise runs the tile kernel)
     {
-        const int ck = h->hc.state_cost_kind == MPPI_STATE_COST_ELLIPSE ? 1 : (h->hc.q_full ? 2 : 0); // PC_COST_* (spelled out as the profiler spells it)
+        const int ck = h->hc.state_cost_kind == MPPI_STATE_COST_ELLIPSE ? 1 : (h->hc.q_full ? 2 : (h->fp_contract ? 3 : 0)); // PC_COST_* (spelled out as the profiler spells it)
         // (normalizeCost: the records come from the weights-only second pass, PC_PASS_WEIGHTS = 2, whose one instance is the diagonal-Q one)
         std::snprintf(buf, n, "mppi::k_rollout_pc<%d, %d, %d, %s, %d, %d>", h->a, h->pc_np,
                       h->pc_np == 3 ? (NG <= 18 ? 6 : 11) : (NG <= 20 ? 4 : 8), h->sigma_diag ? "true" : "false", h->normalize ? 0 : ck, h->normalize ? 2 : 0);

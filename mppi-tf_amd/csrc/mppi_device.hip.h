@@ -386,14 +386,26 @@ __device__ __forceinline__ void pm_action_step(const CT *__restrict__ C, const f
     }
 }
 
-template <int A, class CT = DevConsts>
+// FMA: the opt-in contracted form (MPPI_FLAG_FP_CONTRACT): every multiply that feeds an add becomes one fused multiply-add — fewer
+// instructions in an issue-bound kernel, one rounding less per pair; NOT the reference's op-by-op rounding (sample costs then agree
+// with an fp64 evaluation to ~1e-6 relative instead of bit for bit with the unfused fp32 one).
+template <int A, class CT = DevConsts, bool FMA = false>
 __device__ __forceinline__ void pm_step(const CT *__restrict__ C, float (&x)[2 * A], const float (&v)[A])
 {
-    float fr[2 * A], ac[2 * A];
-    pm_free_step<A>(C, x, fr);
-    pm_action_step<A>(C, v, ac);
+    if constexpr (FMA) {
 #pragma unroll
-    for (int i = 0; i < 2 * A; ++i) x[i] = fr[i] + ac[i];
+        for (int j = 0; j < A; ++j) {
+            const float fr = __builtin_fmaf(C->dt, x[2 * j + 1], x[2 * j]);
+            x[2 * j] = __builtin_fmaf(C->bp, v[j], fr);
+            x[2 * j + 1] = __builtin_fmaf(C->bq, v[j], x[2 * j + 1]);
+        }
+    } else {
+        float fr[2 * A], ac[2 * A];
+        pm_free_step<A>(C, x, fr);
+        pm_action_step<A>(C, v, ac);
+#pragma unroll
+        for (int i = 0; i < 2 * A; ++i) x[i] = fr[i] + ac[i];
+    }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -479,9 +491,19 @@ __device__ __forceinline__ float state_cost_packed(const PmPack<A> &K, const PmS
 }
 
 // cost_base.cpp:56-61 mStateCost: diff = x-g ; left = Q·diff ; cost = diffᵀ·left.
-template <int S, bool QFULL, class CT = DevConsts>
+template <int S, bool QFULL, class CT = DevConsts, bool FMA = false>
 __device__ __forceinline__ float state_cost(const CT *__restrict__ C, const float (&x)[S])
 {
+    if constexpr (FMA && !QFULL) { // contracted diagonal form (see pm_step)
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const float d = x[i] - C->goal[i];
+            const float l = C->qdiag[i] * d;
+            acc = i == 0 ? d * l : __builtin_fmaf(d, l, acc);
+        }
+        return acc;
+    }
     float diff[S], left[S];
 #pragma unroll
     for (int i = 0; i < S; ++i) diff[i] = x[i] - C->goal[i];
@@ -577,9 +599,23 @@ __device__ __forceinline__ float state_cost_of(const DevConsts *__restrict__ C, 
 }
 
 // cost_base.cpp:63-68 (C++: λ·uᵀ(Σ⁻¹ε), u = NOMINAL action) or cost_base.py:114-170 (γ/υ form).
-template <int A, bool DIAG = false, class CT = DevConsts>
+template <int A, bool DIAG = false, class CT = DevConsts, bool FMA = false>
 __device__ __forceinline__ float action_cost(const CT *__restrict__ C, const float (&u)[A], const float (&e)[A])
 {
+    if constexpr (FMA && DIAG) { // contracted form of the diagonal-Sigma case (see pm_step); both cost kinds
+        float mix = u[0] * (C->sigma_inv[0] * e[0]);
+#pragma unroll
+        for (int i = 1; i < A; ++i) mix = __builtin_fmaf(u[i], C->sigma_inv[i * kMaxA + i] * e[i], mix);
+        if (C->action_cost_kind == MPPI_ACTION_COST_CPP) return C->lambda * mix;
+        float n = e[0] * (C->sigma_inv[0] * e[0]), ac = u[0] * (C->sigma_inv[0] * u[0]);
+#pragma unroll
+        for (int i = 1; i < A; ++i) {
+            n = __builtin_fmaf(e[i], C->sigma_inv[i * kMaxA + i] * e[i], n);
+            ac = __builtin_fmaf(u[i], C->sigma_inv[i * kMaxA + i] * u[i], ac);
+        }
+        const float control = __builtin_fmaf(C->gamma, ac, C->gamma * (2.0f * mix));
+        return 0.5f * __builtin_fmaf(C->py_ncoef, n, control);
+    }
     float rhsN[A];
 #pragma unroll
     for (int i = 0; i < A; ++i) {

@@ -25,6 +25,7 @@ struct mppi_handle {
     int nb_mlp = 0;       // record count of the MLP rollout kernel (64 rollouts per workgroup)
     int nbp = 0;          // record slots in d_part: record_pad(max(nb, nb_mlp)), the column stride of every rollout launch
     int part_nb = 0;      // tile count whose slots currently hold records (0: all slots neutral)
+    int fp_contract = 0;  // MPPI_FLAG_FP_CONTRACT: the point-mass producer/consumer rollout with fused multiply-adds (PC_COST_DIAG_FMA)
     int mlp_bx3 = 0;      // MPPI_FLAG_MLP_BF16X3: split-bf16 matrix-core variant of the MLP rollout
     int mlp_small = 0;    // hidden width (16 or 32) of a small learned model served by k_rollout_mlp_small, else 0
     MlpSmallArgs small_args{};

@@ -209,7 +209,9 @@ __host__ __device__ inline size_t pc_lds_floats(int A, int NP) { return (size_t)
 
 // COST: the cost_base form of the consumer — 0 quadratic with a diagonal Q (the BASELINE configurations), 1 ElipseCost (s >= 4),
 // 2 quadratic with a dense Q. A template parameter, so the instances of the hot configuration are what they were.
-enum { PC_COST_DIAG = 0, PC_COST_ELLIPSE = 1, PC_COST_DENSE = 2 };
+// 3: the diagonal quadratic cost with CONTRACTED arithmetic (MPPI_FLAG_FP_CONTRACT: fused multiply-adds in the model step, the state cost and the
+// action cost — not bit-identical to the reference's op-by-op rounding; tests/test_parity_gpu.py holds it to an fp64 evaluation instead).
+enum { PC_COST_DIAG = 0, PC_COST_ELLIPSE = 1, PC_COST_DENSE = 2, PC_COST_DIAG_FMA = 3 };
 // PASS (r04): the two passes of the Python reference's normalizeCost=True (controller_base.py:468-474: c' = (c - min c)/(max c - min c) before the
 // soft-min) on this kernel. The normalised update is the plain one at the temperature lambda (max - min) (exp(-(c' - min c')/lambda) =
 // exp(-(c - min c)/(lambda (max - min)))), which needs every cost before any weight:
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
     constexpr int CH = CS * SLOT * 64;        // floats per chunk buffer
     typedef float slot_t __attribute__((ext_vector_type(SLOT == 2 ? 2 : 4)));
     constexpr int NREG = NSLOT * 4 * A;       // noise values a producer lane keeps
+    constexpr bool FMA = COST == PC_COST_DIAG_FMA;
     const int H = C->H;
     const int K = C->K_local;
     const int NG = (H + 3) / 4;               // horizon groups
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
                             eps_r[(i * 4 + tl) * A + j] = e[j];
                             slot[j] = u[j] + e[j]; // to_apply, :258
                         }
-                        slot[A] = action_cost<A, DIAG>(PC, u, e);
+                        slot[A] = action_cost<A, DIAG, PcProducerConsts<A>, FMA>(PC, u, e);
                         if constexpr (PACKED) {
                             slot_t sv;
 #pragma unroll
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
         auto cost_of = [&](const float (&xs)[S]) {
             if constexpr (COST == PC_COST_ELLIPSE) return state_cost_ellipse<S>(&ecst, xs);
             else if constexpr (COST == PC_COST_DENSE) return state_cost_dense<S>(&qcst, xs);
-            else return state_cost<S, false>(CC, xs);
+            else return state_cost<S, false, PcConsumerConsts<S>, FMA>(CC, xs);
         };
         float c = 0.0f;
         MPPI_STAMP(0);
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
                     for (int j = 0; j < A; ++j) v[j] = cb[(tl * (A + 1) + j) * 64 + lane];
                     ac = cb[(tl * (A + 1) + A) * 64 + lane];
                 }
-                pm_step<A>(CC, x, v);
+                pm_step<A, PcConsumerConsts<S>, FMA>(CC, x, v);
                 const float sc = cost_of(x);                  // cost on the POST-step state
                 const float tmp = sc + ac;                    // Step_cost_result cost_base.cpp:49
                 c = c + tmp;                                  // path_cost        controller_base.cpp:268

@@ -42,6 +42,8 @@ static hipError_t launch_pc_inst(mppi_handle *h, hipStream_t st, const float *x_
         if (h->hc.state_cost_kind == MPPI_STATE_COST_ELLIPSE) return launch_pc_cost<A, NP, NSLOT, PC_COST_ELLIPSE>(h, st, x_dev);
     }
     if (h->hc.q_full) return launch_pc_cost<A, NP, NSLOT, PC_COST_DENSE>(h, st, x_dev);
+    // MPPI_FLAG_FP_CONTRACT: the step's one pass with fused multiply-adds (the two passes of normalizeCost keep the plain instances)
+    if (h->fp_contract && h->pc_pass == PC_PASS_PLAIN) return launch_pc_pass<A, NP, NSLOT, PC_COST_DIAG_FMA, PC_PASS_PLAIN>(h, st, x_dev);
     return launch_pc_cost<A, NP, NSLOT, PC_COST_DIAG>(h, st, x_dev);
 }
 

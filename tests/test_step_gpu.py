@@ -217,3 +217,34 @@ def test_armed_adaptive_rule(m):
             time.sleep(0.001)
     np.testing.assert_array_equal(ha.get_action_sequence(), hu.get_action_sequence())
     ha.close(); hu.close()
+
+
+@pytest.mark.parametrize("K,H,a", [(65536, 64, 3), (4096, 64, 2), (1000, 100, 1), (20000, 64, 4)])
+def test_contracted_instance_against_fp64(m, K, H, a):
+    """MPPI_FLAG_FP_CONTRACT (k_rollout_pc<.., PC_COST_DIAG_FMA>): fused multiply-adds in the model step and the costs. Not the reference's
+    op-by-op rounding, so not bit-identical to the fp32 oracle — held to the oracle's fp64 evaluation on the noise the step drew instead:
+    sample costs within 2e-6 relative, or 1.25x the unfused fp32 evaluation's own distance where that is larger (long horizons), U' and u within 1e-5 (north_star's tolerance)."""
+    c = cfg_of(K, H, a)
+    h = m.Handle(fp_contract=True, **c)
+    assert h.rollout_kernel_name().endswith("3, 0>"), h.rollout_kernel_name()
+    kw = dict(tau=H, s=2 * a, a=a, dt=0.1, mass=1.0, lam=1.0, sigma=c["sigma"], goal=c["goal"], Q=c["Q"], threads=0)
+    p64, p32 = orc.Problem(dtype=np.float64, **kw), orc.Problem(**kw)
+    x, U = np.array([0.1, 0, -0.2, 0, 0.3, 0, 0.05, 0][:2 * a], F32), np.zeros((H, a), F32)
+    for step in range(3):
+        u = h.next(x)
+        eps = h.debug_get(m.DBG_NOISE)
+        c_dev = h.debug_get(m.DBG_COSTS).astype(np.float64)
+        c64 = np.asarray(p64.rollout_cost(x.astype(np.float64), U.astype(np.float64), eps.astype(np.float64)), np.float64)
+        rel = np.abs(c_dev - c64) / np.maximum(np.abs(c64), 1e-30)
+        u_ref, U_ref, c32 = p32.next_with_noise(x, U, eps)
+        rel32 = np.abs(c32.astype(np.float64) - c64) / np.maximum(np.abs(c64), 1e-30)  # what the reference's own unfused fp32 evaluation is off by
+        # 2e-6 relative: a 64..100-step fp32 recurrence and ~200 fp32 additions per sample; the unfused fp32 evaluation itself sits at ~1e-6
+        # over 65536 samples (measured 1.2e-6 for the contracted one) — the contracted instance must not be worse than that by more than a rounding or two
+        # (H = 100, a = 1: both evaluations sit at 2.5e-6 — the bar that means something is the unfused evaluation's own distance)
+        assert rel.max() <= max(2e-6, 1.25 * rel32.max()), "contracted costs off the fp64 evaluation by %.3g relative (unfused fp32: %.3g)" % (rel.max(), rel32.max())
+        assert not np.array_equal(c_dev.astype(F32), c32) or K < 100, "the contracted instance should differ from the unfused fp32 costs somewhere"
+        np.testing.assert_allclose(u, u_ref, rtol=0, atol=U_TOL)
+        np.testing.assert_allclose(h.get_action_sequence(), U_ref, rtol=0, atol=U_TOL)
+        U = h.get_action_sequence()
+        x = plant(x, u, a)
+    h.close()
