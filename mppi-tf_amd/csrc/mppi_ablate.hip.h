@@ -162,6 +162,15 @@ __device__ __forceinline__ unsigned long long pct_stamp()
 #define MPPI_PCT_DUMP(valid, ptr, c) do { if (valid) *(ptr) = (c); } while (0)
 #endif
 
+// ---- k_rollout_pc: the action-cost form resolved once around the producers' horizon loop (r05) or per step as before (A/B: tools/ablate.py kind_per_step) ----
+#if defined(MPPI_PC_KIND_PER_STEP)
+#define MPPI_PC_KIND_ONCE(cond) true
+#define MPPI_PC_KIND_OF(k) (-1)
+#else
+#define MPPI_PC_KIND_ONCE(cond) (cond)
+#define MPPI_PC_KIND_OF(k) (k)
+#endif
+
 // ---- k_rollout_pc: priority levels added to the consumer wave's progress level (A/B: tools/ablate.py consumer_boost) ----
 #ifndef MPPI_PC_CONSUMER_BOOST
 #define MPPI_PC_CONSUMER_BOOST 0

@@ -599,14 +599,18 @@ __device__ __forceinline__ float state_cost_of(const DevConsts *__restrict__ C, 
 }
 
 // cost_base.cpp:63-68 (C++: λ·uᵀ(Σ⁻¹ε), u = NOMINAL action) or cost_base.py:114-170 (γ/υ form).
-template <int A, bool DIAG = false, class CT = DevConsts, bool FMA = false>
+// KIND: the action-cost form when the caller has already branched on it (MPPI_ACTION_COST_CPP / _PY), -1 = read C->action_cost_kind here.
+// k_rollout_pc's producers branch ONCE around their whole horizon loop: the per-step test it replaces split every horizon group of the
+// unrolled loop into basic blocks (two scalar branches per step) that the scheduler could not move the Philox rounds across.
+template <int A, bool DIAG = false, class CT = DevConsts, bool FMA = false, int KIND = -1>
 __device__ __forceinline__ float action_cost(const CT *__restrict__ C, const float (&u)[A], const float (&e)[A])
 {
+    const bool cpp_form = KIND >= 0 ? KIND == MPPI_ACTION_COST_CPP : C->action_cost_kind == MPPI_ACTION_COST_CPP;
     if constexpr (FMA && DIAG) { // contracted form of the diagonal-Sigma case (see pm_step); both cost kinds
         float mix = u[0] * (C->sigma_inv[0] * e[0]);
 #pragma unroll
         for (int i = 1; i < A; ++i) mix = __builtin_fmaf(u[i], C->sigma_inv[i * kMaxA + i] * e[i], mix);
-        if (C->action_cost_kind == MPPI_ACTION_COST_CPP) return C->lambda * mix;
+        if (cpp_form) return C->lambda * mix;
         float n = e[0] * (C->sigma_inv[0] * e[0]), ac = u[0] * (C->sigma_inv[0] * u[0]);
 #pragma unroll
         for (int i = 1; i < A; ++i) {
@@ -631,7 +635,7 @@ __device__ __forceinline__ float action_cost(const CT *__restrict__ C, const flo
     float mix = u[0] * rhsN[0];
 #pragma unroll
     for (int i = 1; i < A; ++i) mix = mix + u[i] * rhsN[i];
-    if (C->action_cost_kind == MPPI_ACTION_COST_CPP) return C->lambda * mix;
+    if (cpp_form) return C->lambda * mix;
 
     float rhsA[A];
 #pragma unroll

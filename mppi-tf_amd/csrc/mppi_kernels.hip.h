@@ -303,8 +303,9 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
         pcst.template load<DIAG>(C);
         const PcProducerConsts<A> *PC = &pcst;
         MPPI_STAMP(16 + 10 * p + 9);
-        static_for<0, NSLOT>([&](auto ic) {
+        auto produce = [&](auto ic, auto kindc) { // kindc: the action-cost form, resolved once below
             constexpr int i = decltype(ic)::value;
+            constexpr int KIND = decltype(kindc)::value;
             const int g = NP * i + p;
             if (balance) pc_set_prio(i, nch, gen);
             if (PASS == PC_PASS_WEIGHTS && i < nch && g < NG) { // the noise alone: nothing is published, no chunk barrier
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
                             eps_r[(i * 4 + tl) * A + j] = e[j];
                             slot[j] = u[j] + e[j]; // to_apply, :258
                         }
-                        slot[A] = action_cost<A, DIAG, PcProducerConsts<A>, FMA>(PC, u, e);
+                        slot[A] = action_cost<A, DIAG, PcProducerConsts<A>, FMA, KIND>(PC, u, e);
                         if constexpr (PACKED) {
                             slot_t sv;
 #pragma unroll
@@ -371,7 +372,15 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
 #pragma unroll
                 for (int r = 0; r < 4 * A; ++r) eps_r[i * 4 * A + r] = 0.0f;
             }
-        });
+        };
+        // the action-cost form (C++ reference / Python gamma-upsilon form) is decided once, around the whole horizon loop — in the instances of
+        // the step's one pass with the diagonal cost (the BASELINE configurations); the others keep the per-step test (half the code to compile)
+        if constexpr (PASS == PC_PASS_PLAIN && (COST == PC_COST_DIAG || COST == PC_COST_DIAG_FMA)) {
+            if (MPPI_PC_KIND_ONCE(pcst.action_cost_kind == MPPI_ACTION_COST_CPP)) static_for<0, NSLOT>([&](auto ic) { produce(ic, std::integral_constant<int, MPPI_PC_KIND_OF(MPPI_ACTION_COST_CPP)>{}); });
+            else static_for<0, NSLOT>([&](auto ic) { produce(ic, std::integral_constant<int, MPPI_PC_KIND_OF(MPPI_ACTION_COST_PY)>{}); });
+        } else {
+            static_for<0, NSLOT>([&](auto ic) { produce(ic, std::integral_constant<int, -1>{}); });
+        }
         __syncthreads(); // weights published by the consumer
         MPPI_STAMP(16 + 10 * p + 7);
         // phase C from registers: V_b[t,j] = Σ_k e_k·eps[k,t,j]  (mWeightedNoise, controller_base.cpp:188-192)

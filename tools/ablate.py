@@ -22,6 +22,7 @@ VARIANTS = {
     "pc_no_network": ["MPPI_PC_ABL=1"],
     "pc_no_pose": ["MPPI_PC_ABL=2"],
     "pc_neither": ["MPPI_PC_ABL=3"],
+    "kind_per_step": ["MPPI_PC_KIND_PER_STEP"],  # k_rollout_pc: the action-cost form tested in every step (r04) instead of once around the producers' loop (r05; tools/ab_kind.py)
     "consumer_boost": ["MPPI_PC_CONSUMER_BOOST=1"],  # k_rollout_pc: the consumer wave one priority level above its progress level
     "finish_s0": ["MPPI_FINISH_STAGE=0"],
     "finish_s1": ["MPPI_FINISH_STAGE=1"],
