@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--samples", type=int, default=None, help="rollouts PER GPU (default 65536; 4096 for pm2d, 128 for pm1d)")
     ap.add_argument("--min-time", type=float, default=1.0, help="repeat the K-step batch until this many seconds are timed (headline only)")
     ap.add_argument("--bf16x3", action="store_true", help="the split-bf16 matrix-core variant of a learned-model workload (MPPI_FLAG_MLP_BF16X3)")
+    ap.add_argument("--fp-contract", action="store_true", help="the contracted instance of the point-mass rollout (MPPI_FLAG_FP_CONTRACT: fused multiply-adds; not bit-identical to the reference's rounding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true")
     return ap.parse_args()
@@ -732,7 +733,8 @@ def main():
     K = args.samples or {"pm1d": 128, "pm2d": 4096}.get(headline, 65536)
     steps = args.steps if args.steps is not None else (20 if is_mlp else 200)
     rn = Runner(args, dev, world, rank, local_rank)
-    r = rn.run(headline, K, H, steps, args.warmup if not is_mlp else min(args.warmup, 3), args.min_time, **(dict(mlp_bf16x3=True) if args.bf16x3 else {}))
+    head_kw = dict(mlp_bf16x3=True) if args.bf16x3 else (dict(fp_contract=True) if args.fp_contract else {})
+    r = rn.run(headline, K, H, steps, args.warmup if not is_mlp else min(args.warmup, 3), args.min_time, **head_kw)
 
     subs = []
     if args.workload is None and not args.no_subrecords:
@@ -801,7 +803,7 @@ def main():
                 out["sub_records"][0]["exchange"] = subs[0]["exchange"]
                 out["sub_records"][0]["rank_ms_per_step"] = [r4(q) for q in subs[0]["rank_ms_per_step"]]
         if world == 1:
-            out["ms_per_control_step_sync"] = sync_record(m, headline, H, K, r["mlp"], **(dict(mlp_bf16x3=True) if args.bf16x3 else {}))
+            out["ms_per_control_step_sync"] = sync_record(m, headline, H, K, r["mlp"], **head_kw)
             for sr, s_ in zip(out.get("sub_records", []), subs):  # configs[1]: the synchronous figure too
                 if s_["workload"] == "pm2d":
                     try:

@@ -2,7 +2,9 @@
 // The reference's loop is: get_x -> ctrl.next(x) -> env.simulate(u) -> get_x -> ctrl.saveNext(x);
 // then ctrl.toCSV(...), then a (commented-out) chrono loop around ctrl.next. MuJoCo is replaced by the
 // same point-mass plant stepped on the host (x' = A x + B u, envs/point_mass*.xml dimensions).
-//   usage: host_loop [k=65536] [tau=64] [a_dim=3] [steps=100] [csv | -] [trace]
+//   usage: host_loop [k=65536] [tau=64] [a_dim=3] [steps=100] [csv | -] [trace | armed=N]
+// "armed=N" as the 6th argument: armed launches with a soft deadline of N microseconds (MPPI_TUNE_ARMED_US) — the next step's launch
+// sits on the GPU, its noise drawn, while this loop steps the plant; next(x) then only stores x and waits for u (include/mppi_c.h).
 // "trace" as the 6th argument switches on the library's roctx ranges (mppi:step > mppi:rollout / mppi:finish; the reference brackets its
 // step with tf.profiler, controller_base.py:241-248): `rocprofv3 --marker-trace --kernel-trace -- examples/host_loop 65536 64 3 20 - trace`.
 #include <chrono>
@@ -28,6 +30,11 @@ int main(int argc, char const *argv[])
         for (int i = 0; i < aDim; i++) { goal.push_back(pos[i % 3]); goal.push_back(0.f); }
         if (!ctrl.setGoal(goal)) return 2;
         if (argc > 6 && std::string(argv[6]) == "trace" && mppi_set_tuning(ctrl.handle(), MPPI_TUNE_TRACE, 1) != MPPI_OK) {
+            fprintf(stderr, "host_loop: %s\n", mppi_last_error(ctrl.handle()));
+            return 4;
+        }
+        if (argc > 6 && std::string(argv[6]).rfind("armed=", 0) == 0 &&
+            mppi_set_tuning(ctrl.handle(), MPPI_TUNE_ARMED_US, atoi(argv[6] + 6)) != MPPI_OK) {
             fprintf(stderr, "host_loop: %s\n", mppi_last_error(ctrl.handle()));
             return 4;
         }

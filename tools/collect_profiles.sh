@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun) from the repo root: collects the rocprofv3 evidence behind bench.py's roofline fields, for every
 # kernel the bench line quotes —
-#   tools/collect_profiles.sh TAG WORKLOAD[:bx3] [WORKLOAD[:bx3] ...]        e.g.  r04 pm3d mlp mlp:bx3 mlp32 mlp32:bx3 nnauv nnauv:bx3 auv nnspeed
+#   tools/collect_profiles.sh TAG WORKLOAD[:bx3|:fma] [...]        e.g.  r05 pm3d pm3d:fma pm2d mlp mlp:bx3 mlp32 mlp32:bx3 nnauv nnauv:bx3 auv nnspeed
 # per workload: --kernel-trace --stats, then PMC counters in SEPARATE passes (never combined with sys/hip/marker traces): the VALU
 # instruction classes, the busy cycles of the issue ports, the matrix pipe, GRBM_GUI_ACTIVE, and (point mass / 2x256 MLP) FETCH_SIZE and
 # WRITE_SIZE. Results land in gpurun_out/profiles_<tag>/<workload>/; tools/summarize_profiles.py turns them into the files under profiles/.
@@ -10,13 +10,15 @@ TAG=${1:-r04}
 shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
-rm -rf $OUT   # never mix passes of different runs (gpurun merges gpurun_out/ back over what is already there: clear the local copy too)
+[ -z "${MPPI_PROFILES_APPEND:-}" ] && rm -rf $OUT   # never mix passes of different runs (gpurun merges gpurun_out/ back over what is already there: clear the local copy too); MPPI_PROFILES_APPEND=1: a second call of the same collection
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for SPEC in "$@"; do
   WL=${SPEC%%:*}
   EXTRA=""; [ "$SPEC" != "$WL" ] && EXTRA="--bf16x3"
+  [ "$SPEC" = "$WL:fma" ] && EXTRA="--fp-contract"   # the contracted instance of the point-mass rollout (MPPI_FLAG_FP_CONTRACT)
+  [ "$SPEC" = "$WL:k4096" ] && EXTRA="--samples 4096"
   NAME=${SPEC/:/_}
   D=$OUT/$NAME
   mkdir -p $D

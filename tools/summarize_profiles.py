@@ -94,7 +94,7 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
     json.dump(out, open(os.path.join(dst, "%s_%s_pmc_summary.json" % (tag, wl)), "w"), indent=1, sort_keys=True)
 
     for kname, k in summary.items():
-        if "k_rollout" not in kname:
+        if "k_rollout" not in kname and "k_step" not in kname:
             continue
         rec = {"code_sha": code_sha, "tag": "%s_%s" % (tag, wl), "stats": stats.get(kname)}
         if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
@@ -113,17 +113,30 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
                        "cvt": k["SQ_INSTS_VALU_CVT"]}
             classes["other"] = k["SQ_INSTS_VALU"] - sum(classes.values()) - n_mfma  # (SQ_INSTS_VALU counts the MFMAs too)
             mixfile = os.path.join(dst, "%s_valu_static_mix_%s.json" % (tag, wl))
-            mix = {}
+            mix, static_all = {}, {}
             try:
                 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "valu_static_mix.py"), kname.replace("mppi::", ""), mixfile],
                                       stdout=subprocess.DEVNULL)
-                mix = {c: n for c, n in json.load(open(mixfile))["classes"].items() if c.startswith("other:")}
+                static_all = json.load(open(mixfile))["classes"]
+                mix = {c: n for c, n in static_all.items() if c.startswith("other:") and c != "other:dpp_f32"}  # (DPP adds are counted, and priced, in add_f32)
             except Exception as e:  # the static mix only refines the price of `other`
                 print("static mix of %s unavailable: %s" % (kname, e))
             other_price = (sum(n * KIND_PRICE.get(c, cyc["v_bitop3_b32"]) for c, n in mix.items()) / max(1, sum(mix.values()))) if mix else cyc["v_bitop3_b32"]
             price = {"add_f32": cyc["v_add_f32"], "mul_f32": cyc["v_mul_f32"], "fma_f32": cyc["v_fma_f32"],
                      "trans_f32": (cyc["v_log_f32"] + cyc["v_sqrt_f32"] + cyc["v_sin_f32"]) / 3, "int32": cyc["v_xor_b32"],
                      "int64": cyc["v_mad_u64_u32 (+0)"], "cvt": cyc["v_cvt_f32_u32"], "other": other_price}
+            # packed fp32 (r05): the add / mul / fma counters tally a v_pk_* like a plain instruction (profiles/r05_valu_counter_classes.txt),
+            # so each of the three classes is priced at the static plain : packed share of the kernel's code object (DPP adds sit in add_f32 too)
+            pk_share = {}
+            for c_, pk_op in (("add_f32", "v_pk_add_f32"), ("mul_f32", "v_pk_mul_f32"), ("fma_f32", "v_pk_fma_f32")):
+                n_pk = static_all.get("pk_" + c_, 0)
+                n_dpp = static_all.get("other:dpp_f32", 0) if c_ == "add_f32" else 0
+                n_plain = static_all.get(c_, 0)
+                tot = n_pk + n_dpp + n_plain
+                if tot and pk_op in cyc:
+                    price[c_] = (n_plain * price[c_] + n_pk * cyc[pk_op] + n_dpp * cyc["v_add_f32_dpp quad_perm"]) / tot
+                    pk_share[c_] = {"plain": n_plain, "packed": n_pk, "dpp": n_dpp}
+            rec["valu_static_plain_packed"] = pk_share
             rec["valu"] = {"simds": 1024, "clock_mhz": 2400.0, "insts_per_launch": classes, "cycles_per_inst": price,
                            "other_static_mix": mix, "active_quad_cycles_per_launch": k.get("SQ_ACTIVE_INST_VALU"),
                            "waves_per_launch": k.get("SQ_WAVES"),

@@ -44,8 +44,16 @@ def classify(op):
     base = op.replace("_e32", "").replace("_e64", "").replace("_sdwa", "")
     dpp = base.endswith("_dpp")
     base = base.replace("_dpp", "")
+    # packed fp32: the hardware counts one v_pk_add / _mul / _fma in SQ_INSTS_VALU_ADD / _MUL / _FMA_F32 like a plain one
+    # (profiles/r05_valu_counter_classes.txt: tools/micro/valu_issue.hip under rocprofv3 --pmc) but issues it at 4.26 cycles, not 2.46:
+    # tools/summarize_profiles.py prices each of the three classes by the static plain : packed share of the kernel's code object
+    m = re.match(r"v_pk_(add|mul|fma)_f32$", base)
+    if m:
+        return "pk_%s_f32" % m.group(1)
+    if base.startswith("v_pk_mov"):
+        return "other:mov"
     if base.startswith("v_pk_"):
-        return "pk_f32"
+        return "other:misc"
     if re.match(r"v_(add|sub|subrev|min|max)_f32$", base):
         return "other:dpp_f32" if dpp else ("add_f32" if not base.startswith(("v_min", "v_max")) else "other:minmax")
     if re.match(r"v_mul(_legacy)?_f32$", base):
