@@ -264,6 +264,10 @@ class ControllerBase:
             self._h.set_action_limits(np.asarray(lo, np.float32).reshape(-1), np.asarray(hi, np.float32).reshape(-1))
         self._timingDict = {"total": 0., "calls": 0}
         self._steps = 0
+        # log=True: save() runs predict() on every transition (controller_base.py:158-160). The reference hands the numbers to its
+        # TensorBoard observer (out of scope here); they are kept in `predictions` instead, one dict per transition.
+        self._log = bool(log)
+        self.predictions = []
 
     @staticmethod
     def _state_cost_args(cost):
@@ -289,6 +293,32 @@ class ControllerBase:
 
     def save(self, x, u, xNext):
         self._h.save_next(np.asarray(xNext, np.float32).reshape(-1))
+        if self._log:  # controller_base.py:158-160
+            self.predict(x, u, None, xNext)
+
+    def state_error(self, stateGt, statePred):
+        """controller_base.py:162-170, for the 13-state layout it assumes (position [:3], quaternion [3:7], velocities [-6:]):
+        -> (|position error|, 1 - <q_gt, q_pred>, |velocity error|, velocity error [6])"""
+        gt, pr = np.asarray(stateGt, np.float64).reshape(-1), np.asarray(statePred, np.float64).reshape(-1)
+        return (float(np.linalg.norm(gt[:3] - pr[:3])), float(1.0 - np.dot(gt[3:7], pr[3:7])), float(np.linalg.norm(gt[-6:] - pr[-6:])),
+                gt[-6:] - pr[-6:])
+
+    def predict(self, x, u, actionSeq, xNext):
+        """controller_base.py:172-210: the model's one-step prediction from (x, u) against the observed next state, the cost's distance
+        metric and the step's state cost (the reference's rollout over actionSeq is commented out there; so it is here). The prediction
+        and the state cost run on the device through the C-ABI helpers (mppi_model_step / mppi_state_cost). -> the predicted next state
+        [1, sDim, 1]; the numbers go to `self.predictions`."""
+        x, u = np.asarray(x, np.float32).reshape(1, self._sDim, 1), np.asarray(u, np.float32).reshape(1, self._aDim, 1)
+        nextState = self._model.predict(x, u)
+        rec = {"error": self.state_error(xNext, nextState)}
+        try:
+            d = self._cost.dist(x)  # (the reference: tf.squeeze(self._cost.dist(tf.expand_dims(x, axis=0)), axis=0))
+            rec["dist"] = d[0] if isinstance(d, np.ndarray) and d.ndim == 3 else d
+        except NotImplementedError:  # CostBase.dist is abstract in the reference too (cost_base.py:193-205)
+            rec["dist"] = None
+        rec["step_cost"] = float(np.asarray(self._cost.state_cost("step_cost", x)).reshape(-1)[0])
+        self.predictions.append(rec)
+        return nextState
 
     def update_model(self):
         """Push the model object's current weights and normalisation into the controller (mppi_set_mlp): what happens implicitly in

@@ -551,6 +551,36 @@ def test_python_controller_with_the_auv_model_and_quaternion_cost(m, G):
     assert np.isfinite(x).all()
 
 
+def test_controller_predict_and_state_error(m, G):
+    """ControllerBase.predict / state_error (controller_base.py:162-210) with log=True: save(x, u, xNext) compares the model's one-step
+    prediction (on the device) with the observed next state; the observed state here comes from a plant with 3 % more mass, so the errors
+    are the model mismatch — checked against the fp64 oracle stepping both parameter sets."""
+    K, H = 256, 4
+    model = m.AUVModel(actionDim=6, dt=0.1, parameters=G["params"])
+    sigma = 200.0 * np.eye(6)
+    cost = m.StaticQuatCost(1.0, 1.0, 1.0, sigma, np.array(GOAL13)[:, None], Q10)
+    ctl = m.ControllerBase(model=model, cost=cost, k=K, tau=H, sDim=13, aDim=6, lam=1.0, sigma=sigma, seed=3, log=True)
+    kw = dict(tau=H, s=13, a=6, lam=1.0, sigma=sigma, goal=GOAL13, Q=Q10, quat_cost=True, action_cost=orc.ACTION_COST_PY, threads=0, dtype=np.float64)
+    p_model = orc.Problem(auv=G["params"], **kw)
+    p_plant = orc.Problem(auv=dict(G["params"], mass=1.03 * G["params"]["mass"]), **kw)
+    x = np.array([0.1, -0.2, 0.3, 0.0, 0.0, 0.0, 1.0, 0.2, 0.0, -0.1, 0.0, 0.05, 0.0])
+    for step in range(3):
+        u = ctl.next(x[:, None])
+        xn = p_plant.model_next([x], [u])[0]
+        ctl.save(x[:, None], u[:, None], xn[:, None])
+        rec = ctl.predictions[-1]
+        pred64 = p_model.model_next([x], [u])[0]
+        e_pos, e_rot, e_vel, e_vel_dec = rec["error"]
+        assert abs(e_pos - np.linalg.norm(xn[:3] - pred64[:3])) < 1e-5
+        assert abs(e_rot - (1.0 - xn[3:7] @ pred64[3:7])) < 1e-5
+        np.testing.assert_allclose(e_vel_dec, xn[-6:] - pred64[-6:], rtol=0, atol=2e-5)
+        assert abs(e_vel - np.linalg.norm(xn[-6:] - pred64[-6:])) < 5e-5 and e_vel > 0
+        np.testing.assert_allclose(rec["step_cost"], p_model.state_cost([x])[0], rtol=3e-6)
+        assert rec["dist"] is not None
+        x = xn
+    assert len(ctl.predictions) == 3
+
+
 def test_auv_family_argument_errors(m, G):
     with pytest.raises(m.MppiError) as e:
         m.Handle(k=64, tau=4, s_dim=12, a_dim=6, sigma=np.eye(6), goal=np.zeros(12), auv=G["params"])
