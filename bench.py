@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — rollouts/s of the MPPI control step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload pm3d|pm2d|pm1d|mlp|mlp32|auv|nnauv] [--horizon H] [--samples K_PER_GPU]
+    python bench.py --gpus N --steps K --warmup W [--workload pm3d|pm2d|pm1d|mlp|mlp32|auv|nnauv|nnspeed] [--horizon H] [--samples K_PER_GPU] [--bf16x3 | --fp-contract]
 
 `--gpus N` with N > 1 works as typed: the parent process — before anything touches a GPU — starts
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` as a CHILD
@@ -12,7 +12,7 @@ A "step" is ONE control step of the hot path: K rollouts x H model steps + costs
 state x and the nominal sequence U already resident in HBM and the noise drawn on the device (Philox).
 Headline workload at N=1: BASELINE configs[2], point_mass3d analytic, K=65536, H=64 — the configuration the metric is
 quoted on. Every BASELINE config is launchable:
-    configs[1]  --workload pm2d --samples 4096                 (also a sub-record of the default run)
+    configs[1]  --workload pm2d --samples 4096                 (also a sub-record of the default run; its step is ONE launch, k_step_pc)
     configs[2]  (default)
     configs[3]  --workload mlp                                 (also a sub-record of the default run, with the split-bf16 variant)
     configs[4]  --workload mlp --horizon 128 --gpus 8          (K = 65536 per rank = 524288 in all; a sub-record of every N>1 run)
@@ -22,9 +22,11 @@ N>1 is WEAK scaling: every rank keeps --samples rollouts of a (samples x N)-samp
 (beta, eta, V) record per step. Rank 0 prints ONE JSON line (value = whole-job rollouts/s, max-over-ranks time).
 
 Timing: W warm-up steps, then batches of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and
-reduced with MAX over ranks; batches repeat until --min-time seconds have been timed (a 200-step batch of the analytic
-workload is 4 ms: one batch is a noisy sample), `value` is the MEDIAN batch. The line stays below 4 KB: what each field
-means is written in DESIGN.md §4, not in the line.
+reduced with MAX over ranks; batches repeat until --min-time seconds have been TIMED (default 1 s, whatever K is: a 200-step
+batch of the analytic workload is 4 ms, one batch is a noisy sample), `value` is the MEDIAN batch; the kernel durations come
+from >= 200 launches bracketed by the dispatches' own timestamps. `ms_per_control_step_sync` is the host-synchronous
+mppi_next figure, with armed launches (MPPI_TUNE_ARMED_US) where the handle supports them and launch-per-call beside it.
+N > 1 lines carry `parity` (sharded_parity below). The line stays below 4 KB: what each field means is written in DESIGN.md §6.
 """
 import argparse
 import json

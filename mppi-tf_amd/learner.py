@@ -208,21 +208,18 @@ class LearnerBase:
             transErrNorm = float(np.mean(transErrSplitNorm))
             transErrSplit = np.mean(((predNorm - yN) * np.asarray(model.Ystd)) ** 2, axis=0)  # denormalizeY: Ymean cancels in the difference
             transErr = float(np.mean(transErrSplit))
-        if transition and split and norm:
-            return err, errNorm, errSplit, errSplitNorm, transErr, transErrNorm, transErrSplit, transErrSplitNorm
-        if transition and split:
-            return err, errSplit, transErr, transErrSplit
-        if transition and norm:
-            return err, errNorm, transErr, transErrNorm
-        if split and norm:
-            return err, errNorm, errSplit, errSplitNorm
+        # What the caller unpacks (learner_base.py:301-322), built instead of enumerated: the trajectory error, then with `norm` its normalised
+        # twin, then with `split` the per-dimension pair; with `transition` the same pattern again for the one-step error.
+        def pattern(e, eNorm, eSplit, eSplitNorm):
+            out = [e] + ([eNorm] if norm else [])
+            if split:
+                out += [eSplit] + ([eSplitNorm] if norm else [])
+            return out
+
+        out = pattern(err, errNorm, errSplit, errSplitNorm)
         if transition:
-            return err, transErr
-        if split:
-            return err, errSplit
-        if norm:
-            return err, errNorm
-        return err
+            out += pattern(transErr, transErrNorm, transErrSplit, transErrSplitNorm)
+        return out[0] if len(out) == 1 else tuple(out)
 
     def _train_step(self, model, optimizer, Xnorm, Ynorm, split=False, norm=False):
         """ONE Adam step on (Xnorm, Ynorm) (learner_base.py:469-496) -> (loss, grads): the loss of the forward pass before the update in
