@@ -680,6 +680,15 @@ def test_cpp_facade_reference_vectors_and_host_loop(m):
     r = subprocess.run([loop, "4096", "32", "2", "80"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Execution time" in r.stdout
+    # the same loop with armed launches (r05): same closed-loop result line — the controls are bit-identical — on the fused (<= 128 tiles) and the
+    # two-kernel (rollout + finish) armed form; a device without a large BAR answers MPPI_ERR_UNSUPPORTED (exit code 4), which is not a failure of the loop
+    for shape in (["4096", "32", "2", "80"], ["16384", "32", "3", "60"]):
+        plain = subprocess.run([loop] + shape, capture_output=True, text=True, timeout=120)
+        armed = subprocess.run([loop] + shape + ["-", "armed=2000"], capture_output=True, text=True, timeout=120)
+        if armed.returncode == 4 and "large-BAR" in armed.stderr:
+            continue
+        assert plain.returncode == 0 and armed.returncode == 0, armed.stdout + armed.stderr
+        assert plain.stdout.splitlines()[0] == armed.stdout.splitlines()[0], (plain.stdout, armed.stdout)
 
 
 # =============================================================== §8f row 4 (first slice): the elliptic cost in the cost_base slot

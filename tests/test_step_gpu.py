@@ -174,6 +174,32 @@ def test_armed_launch_deadline_path(m, K, H, a):
     ha.close(); hu.close()
 
 
+def test_armed_soak_with_a_host_that_dithers_around_the_deadline(m):
+    """3000 closed-loop steps with host delays drawn between 0 and 2.5 deadlines (so that every interleaving of "x arrives" and "tile 0
+    gives up" occurs many times), the transition log on, an action clip set: the same controls as a handle that never arms, step for step."""
+    if not armable(m):
+        pytest.skip("no large-BAR device: MPPI_TUNE_ARMED_US is unsupported here")
+    c = cfg_of(3000, 50, 3)
+    ha, hu = m.Handle(tuning={"armed_us": 60, "armed_always": 1}, log_rows=64, **c), m.Handle(**c)
+    for h in (ha, hu):
+        h.set_action_limits([-0.3] * 3, [0.3] * 3)
+    rng = np.random.default_rng(5)
+    x = np.zeros(6, F32)
+    for i in range(3000):
+        ua, uu = ha.next(x), hu.next(x)
+        assert np.array_equal(ua, uu), "step %d: %s vs %s" % (i, ua, uu)
+        x = plant(x, ua, 3)
+        if i % 500 == 499:
+            x = rng.standard_normal(6).astype(F32)  # (keep the loop away from its fixed point)
+        d = rng.uniform(0.0, 150e-6)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < d:
+            pass
+    np.testing.assert_array_equal(ha.get_action_sequence(), hu.get_action_sequence())
+    assert ha.get_step_counter() == hu.get_step_counter() == 3000
+    ha.close(); hu.close()
+
+
 def test_armed_launch_is_retired_by_every_other_entry_point(m):
     """set_goal, debug getters, next_with_noise, next_device, destroy — with a launch armed behind the last mppi_next."""
     if not armable(m):
