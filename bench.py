@@ -382,12 +382,16 @@ def sync_record(m, workload, H, K, mlp, **handle_kw):
         try:
             am, ap = sync_latency(m, workload, H, K, mlp, tuning={"armed_us": ARMED_US}, **handle_kw)
             rec = {"median": r4(am), "p95": r4(ap), "mode": "armed (MPPI_TUNE_ARMED_US=%d)" % ARMED_US, "launch_per_call": {"median": r4(med), "p95": r4(p95)}}
+            # the loop above spends ~3 us between two calls (a numpy point mass): an armed launch is then still drawing its noise when x arrives.
+            # With a plant of 10 us (any simulator's step) it is ready: the same figure, measured (tools/sync_think_time.py has the curve)
+            tm, _ = sync_latency(m, workload, H, K, mlp, tuning={"armed_us": ARMED_US}, think_us=10.0, **handle_kw)
+            rec["plant_10us"] = r4(tm)
         except Exception as e:  # no large BAR: MPPI_ERR_UNSUPPORTED
             rec["armed"] = "unavailable: %s" % str(e)[:80]
     return rec
 
 
-def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20, **handle_kw):
+def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20, think_us=0.0, **handle_kw):
     """Host-synchronous closed loop: mppi_next(x)->u with the plant stepped on the host (the shape of the reference's
     loop, main.cpp:37-43). Median / p95 ms per control step."""
     import numpy as np
@@ -408,6 +412,8 @@ def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20, **handle_kw):
         for j in range(0 if gen else a):  # point-mass plant, fp32, same model
             x[2 * j] = x[2 * j] + dt * x[2 * j + 1] + (dt * dt / 2) * u[j]
             x[2 * j + 1] = x[2 * j + 1] + dt * u[j]
+        while think_us and time.perf_counter() - t1 < think_us * 1e-6:  # a plant that takes think_us (the reference's is a MuJoCo step)
+            pass
     ts = np.sort(np.asarray(ts)) * 1e3
     h.close()
     return float(np.median(ts)), float(ts[int(0.95 * (len(ts) - 1))])
