@@ -1412,7 +1412,10 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
     case MPPI_TUNE_PC_PRODUCERS:
         if (value != 3 && value != 5) return fail(h, MPPI_ERR_INVALID_ARG, "producer waves per workgroup: 3 or 5");
         h->pc_np = value; break;
-    case MPPI_TUNE_PC_BALANCE: h->pc_no_balance = value == 0; break;
+    case MPPI_TUNE_PC_BALANCE: // 0 off, 1 on, 0x10000 | b3 b2 b1 b0 (hex nibbles): on with these head starts of the generations
+        h->pc_no_balance = value == 0;
+        if (value & 0x10000) h->pc_bias = value & 0xffff;
+        break;
     case MPPI_TUNE_PC_LDS_MIN:
         if (value < 0 || value > 64 * 1024) return fail(h, MPPI_ERR_INVALID_ARG, "LDS bytes out of range (0..65536)");
         h->pc_lds_min = value; break;

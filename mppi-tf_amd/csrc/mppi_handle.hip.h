@@ -45,6 +45,7 @@ struct mppi_handle {
     // diagnostic switches, set only through mppi_set_tuning (the library reads no environment variable)
     int force_tile = 0;   // MPPI_TUNE_FORCE_TILE_KERNEL: the LDS-tile kernel instead of the producer/consumer one (A/B timing)
     int pc_no_balance = 0; // MPPI_TUNE_PC_BALANCE = 0: no SIMD-true roles / progress priorities
+    int pc_bias = -1;      // head start (quarter chunks) of the four generations of workgroups on a CU, gen 0 in the low nibble (pc_set_prio); -1: the launcher's choice; MPPI_TUNE_PC_BALANCE = 0x10000 | biases
     int pc_lds_min = 0;   // MPPI_TUNE_PC_LDS_MIN: pad the dynamic LDS (caps workgroups per CU)
     int sync_spin = 1;    // MPPI_TUNE_SYNC_SPIN: the synchronous step watches the pinned u slot (0: waits for the stream)
     int p2p_fault = 0;    // MPPI_TUNE_P2P_FAULT: 1 = inbox export refused, 2 = probe reports failure (fallback tests)

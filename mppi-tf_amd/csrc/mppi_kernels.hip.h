@@ -184,12 +184,11 @@ __device__ __forceinline__ void static_for(F &&f)
 // by age inside one level): level = 3 - floor(4*(i + 3(3-gen)/4)/n), gen = blockIdx/256 = arrival order on the CU.
 // Measured at K=65536, H=64 (tools/timeline.py): workgroup end times 10.5 .. 19.4 us after the first start without,
 // 13.2 .. 15.3 us with; kernel 21.9 -> 19.2 us together with the SIMD-true role placement below.
-#if !defined(MPPI_PC_PRIO_BIAS)
-#define MPPI_PC_PRIO_BIAS 3
-#endif
-__device__ __forceinline__ void pc_set_prio(int i, int n, int gen, int boost = 0)
+// r05: the head start of a generation (quarter chunks) arrives with the launch — `balance` = 1 | bias(gen 0) << 8 | bias(gen 1) << 12 | bias(gen 2) << 16 |
+// bias(gen 3) << 20, default 9, 6, 3, 0 = r04's 3 (3 - gen) — so that it can be tuned per handle (MPPI_TUNE_PC_BALANCE) without a rebuild.
+__device__ __forceinline__ void pc_set_prio(int i, int n, int gen, int balance, int boost = 0)
 {
-    const int bias = MPPI_PC_PRIO_BIAS * (3 - min(gen, 3)); // quarter chunks
+    const int bias = (balance >> (8 + 4 * min(gen, 3))) & 15; // quarter chunks
     const int lvl = min(3, boost + 3 - min(3, (16 * i + 4 * bias) / (4 * n)));
     switch (lvl) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
             constexpr int i = decltype(ic)::value;
             constexpr int KIND = decltype(kindc)::value;
             const int g = NP * i + p;
-            if (balance) pc_set_prio(i, nch, gen);
+            if (balance) pc_set_prio(i, nch, gen, balance);
             if (PASS == PC_PASS_WEIGHTS && i < nch && g < NG) { // the noise alone: nothing is published, no chunk barrier
                 float z[4 * A];
                 MPPI_NORMALS_GROUP_UB(A, seed, gk, base + (unsigned long long)g, z);
@@ -424,7 +423,7 @@ __global__ __launch_bounds__(64 * (NP + 1), (NSLOT * 4 * A <= 80 ? NP + 1 : 2)) 
         __syncthreads(); // chunk 0 published
         MPPI_STAMP(1);
         for (int ch = 0; ch < nch; ++ch) {
-            if (balance) pc_set_prio(ch, nch, gen, MPPI_PC_CONSUMER_BOOST);
+            if (balance) pc_set_prio(ch, nch, gen, balance, MPPI_PC_CONSUMER_BOOST);
             const float *cb = buf + (ch & 1) * CH;
             const int tend = min(CS, H - ch * CS);
             for (int tl = 0; tl < MPPI_ABL_CHUNK_STEPS(tend, ch); ++tl) {

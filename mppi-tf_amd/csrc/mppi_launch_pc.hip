@@ -13,7 +13,11 @@ static hipError_t launch_pc_pass(mppi_handle *h, hipStream_t st, const float *x_
     const dim3 g(nb), b(64 * (NP + 1));
     // tile records go out column-major ([2+HA][nb]): the finish kernel reads one column per workgroup
     // one round of workgroups (<= 4 per CU, all resident from the start): SIMD-true roles + progress priorities
-    const int balance = (nb <= 4 * 256 && !h->pc_no_balance) ? 1 : 0;
+    // bit 0: on; bits 8..23: the generations' head starts (pc_set_prio). Four workgroups per CU (the small-NSLOT instances): 10, 3, 3, 0 quarter chunks —
+    // r05's sweep on three boxes (tools/tune_prio.py, profiles/r05_tune_prio.txt): kernel 15.05 -> 14.68 us at configs[2], 14.1 -> 13.4 at K = 49152, against
+    // r04's 9, 6, 3, 0; two per CU (H > 80 at a = 3) keep r04's: the new ones cost 10 % there
+    const int bias = h->pc_bias >= 0 ? h->pc_bias : ((NSLOT * 4 * A <= 80) ? 0x033a : 0x0369);
+    const int balance = (nb <= 4 * 256 && !h->pc_no_balance) ? (1 | (bias << 8)) : 0;
     const DevConsts *dC = h->dC;
     const float *U = h->U_cur();
     const unsigned long long *stp = h->d_step;

@@ -15,7 +15,8 @@ static hipError_t launch_step_inst(mppi_handle *h, hipStream_t st, const mppi_st
     const int nb = (h->K_local + 63) / 64;
     const int ncw = FUSE ? (h->HA + NW - 1) / NW : 0;
     const dim3 g(nb + ncw), b(64 * NW);
-    const int balance = (nb <= 4 * 256 && !h->pc_no_balance) ? 1 : 0;
+    const int bias = h->pc_bias >= 0 ? h->pc_bias : ((NSLOT * 4 * A <= 80) ? 0x033a : 0x0369); // as mppi_launch_pc.hip
+    const int balance = (nb <= 4 * 256 && !h->pc_no_balance) ? (1 | (bias << 8)) : 0;
     StepArgs sa{};
     sa.recs = h->d_step_recs; sa.nb = nb; sa.nbp = 128; sa.seq = L->seq;
     sa.xslot = h->d_xslot; sa.decision = ARM ? h->d_decision : nullptr;

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 
             static_for<0, NSLOT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 const int g = NP * i + p;
-                if (balance && !FUSE) pc_set_prio(i, nch, gen);
+                if (balance && !FUSE) pc_set_prio(i, nch, gen, balance);
                 float ug[4][A];
                 if (i < nch && g < NG) {
 #pragma unroll
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 
             }
         };
         for (int ch = 0; ch < nch; ++ch) {
-            if (balance && !FUSE) pc_set_prio(ch, nch, gen, MPPI_PC_CONSUMER_BOOST);
+            if (balance && !FUSE) pc_set_prio(ch, nch, gen, balance, MPPI_PC_CONSUMER_BOOST);
             const float *cb = buf + (ch & 1) * CH;
             const int tend = min(CS, H - ch * CS);
             const int ng = tend >> 2;
