@@ -320,6 +320,20 @@ class ControllerBase:
         self.predictions.append(rec)
         return nextState
 
+    def predict_trajectory(self, x, actionSeq=None):
+        """The part of predict() the reference left commented out (controller_base.py:186-201): the model rolled along the nominal action
+        sequence from x — no noise — with the state cost of every state it passes and the terminal cost added once more. One device call
+        per step through the model / cost helpers (a diagnostic, not the hot path). -> (trajectory [tau, sDim], cost)"""
+        U = self._h.get_action_sequence() if actionSeq is None else np.asarray(actionSeq, np.float32).reshape(self._tau, self._aDim)
+        state = np.asarray(x, np.float32).reshape(1, self._sDim, 1)
+        traj, cost = [], 0.0
+        for t in range(self._tau):
+            state = self._model.build_step_graph("predict", state, U[t].reshape(1, self._aDim, 1))
+            traj.append(np.asarray(state, np.float32).reshape(-1))
+            cost += float(np.asarray(self._cost.state_cost("predict", state)).reshape(-1)[0])
+        cost += float(np.asarray(self._cost.state_cost("predict", state)).reshape(-1)[0])  # build_final_step_cost_graph
+        return np.asarray(traj), cost
+
     def update_model(self):
         """Push the model object's current weights and normalisation into the controller (mppi_set_mlp): what happens implicitly in
         the reference, where learner and controller share the model's tf.Variables (learner_base.py:469-496). Learned models only."""

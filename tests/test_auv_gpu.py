@@ -579,6 +579,15 @@ def test_controller_predict_and_state_error(m, G):
         assert rec["dist"] is not None
         x = xn
     assert len(ctl.predictions) == 3
+    # the nominal rollout the reference left commented out in predict(): the updated sequence rolled from x on the device, against the
+    # oracle's trajectory export on zero noise (its state costs + the terminal cost; the action cost of zero noise is the gamma u'S^-1 u term
+    # of the Python form, which the reference's commented-out loop does not add either)
+    traj, cost = ctl.predict_trajectory(x[:, None])
+    U = ctl._h.get_action_sequence()
+    c_o, tr_o = p_model.rollout_cost(x, U, np.zeros((1, H, 6)), traj=True)
+    np.testing.assert_allclose(traj, tr_o[0], rtol=2e-5, atol=2e-5)
+    sc = sum(p_model.state_cost([tr_o[0][t]])[0] for t in range(H)) + p_model.state_cost([tr_o[0][-1]])[0]
+    np.testing.assert_allclose(cost, sc, rtol=1e-5)
 
 
 def test_auv_family_argument_errors(m, G):
