@@ -804,7 +804,7 @@ def main():
                        "K_global": K * world, "K_per_gpu": K, "H": H, "s_dim": s_dim, "a_dim": a,
                        "lambda": float(cfg_of(headline, H).get("lam", 1.0)), "sigma": "1500*I (6 thrusts, N)" if a == 6 else "0.25*I", "dt": 0.1,
                        "parallelism": "K-shard x%d" % world, "exchange": r["exchange"], "record_floats": r["record_size"]},
-            "roofline": roofline_of(r),
+            "roofline": dict(roofline_of(r), code_sha=__import__("mppi_tf_amd").build.source_sha()),  # the kernel sources this run executed: tools/summarize_profiles.py tags the profile with it
         }
         if world > 1 or dist.is_initialized():
             out["rccl_ranks"] = dist.get_world_size() if dist.is_initialized() else 1

@@ -1106,11 +1106,15 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
         // input 4 s + g, a hidden layer unit 4 g + s — where register s of the previous layer's accumulators holds its units (D register i of
         // lane (n, g) = unit 4 g + i of rollout n): the accumulators ARE the next layer's B operands, as on the 32-wide tiles
         const int m16 = lane & 15, g16 = lane >> 4;
-        float a1q[4], ahq[2][4], w3q[4][NOUT];
+        float a1q[4], ahq[2][4];
+        f32x2 w3q[4][NOUT / 2]; // output-layer weights of the lane's four units, outputs in pairs (packed fp32: a lone wave issues a v_pk_fma in the time of a v_fma)
         f32x4 b1q, bhq[2];
         if constexpr (MF16) {
 #pragma unroll
-            for (int s1 = 0; s1 < 4; ++s1) a1q[s1] = 4 * s1 + g16 < NIN ? M->Wl[0][(4 * s1 + g16) * HID + m16] : 0.0f;
+            for (int s1 = 0; s1 < 4; ++s1) { // k slot 4 s1 + g16 of layer 1: the inputs in PAIRS that exist as pairs (slots 0-2 Euler angles, 3 empty, 4-9 velocities, 10-15 forces)
+                const int slot = 4 * s1 + g16, inp = slot < 3 ? slot : slot - 1;
+                a1q[s1] = slot != 3 ? M->Wl[0][inp * HID + m16] : 0.0f;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) b1q[i] = M->bl[0][4 * g16 + i];
 #pragma unroll
@@ -1125,7 +1129,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int o = 0; o < NOUT; ++o) w3q[i][o] = W3g[(4 * g16 + i) * ld3 + o];
+                for (int o = 0; o < NOUT; ++o) w3q[i][o >> 1][o & 1] = W3g[(4 * g16 + i) * ld3 + o];
         } else {
 #pragma unroll
         for (int s1 = 0; s1 < K1H; ++s1) a1[s1] = (row_live && 2 * s1 + hh < NIN) ? M->Wl[0][(2 * s1 + hh) * HID + j] : 0.0f;
@@ -1148,11 +1152,25 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
         xm[NIN] = 0.0f; xr[NIN] = 0.0f;
 #pragma unroll
         for (int i = 0; i < NOUT; ++i) { b3v[i] = b3g[i]; ysd[i] = M->ystd[i]; ymn[i] = M->ymean[i]; }
+        f32x2 b3p[NOUT / 2], ysdp[NOUT / 2], ymnp[NOUT / 2]; // the same in pairs (the 16-wide path's packed output stage)
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) { b3p[i >> 1][i & 1] = b3v[i]; ysdp[i >> 1][i & 1] = ysd[i]; ymnp[i >> 1][i & 1] = ymn[i]; }
         PcProducerConsts<A> pcst; // Sigma, Sigma^-1, lambda: a kernel-local copy (no re-fetch behind the barriers)
         pcst.template load<DIAG>(C);
-        float vel[6];
+        f32x2 xm2[8], xr2[8]; // input mean / 1/std in the slot order of the 16-wide path
 #pragma unroll
-        for (int i = 0; i < 6; ++i) vel[i] = x_dev[7 + i];
+        for (int k = 0; k < 16; ++k) {
+            const int inp = k < 3 ? k : k - 1;
+            xm2[k >> 1][k & 1] = k != 3 ? xm[inp] : 0.0f;
+            xr2[k >> 1][k & 1] = k != 3 ? xr[inp] : 0.0f;
+        }
+        f32x2 sg2[A / 2], si2[A / 2]; // diagonal of Sigma and of its inverse, in pairs
+#pragma unroll
+        for (int i = 0; i < A; ++i) { sg2[i >> 1][i & 1] = pcst.sigma[i * kMaxA + i]; si2[i >> 1][i & 1] = pcst.sigma_inv[i * kMaxA + i]; }
+        const bool ac_packed = DIAG && pcst.action_cost_kind == MPPI_ACTION_COST_CPP; // (wave-uniform) lambda u' Sigma^-1 eps of a diagonal Sigma: products in pairs, the sum in index order as action_cost has it
+        f32x2 velp[3]; // the six velocities, in pairs
+#pragma unroll
+        for (int i = 0; i < 6; ++i) velp[i >> 1][i & 1] = x_dev[7 + i];
         __syncthreads(); // w3_s
         __syncthreads(); // the Euler angles of x0
 
@@ -1178,7 +1196,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                 float lo = (n & 1) ? pA[n / 2].y : pA[n / 2].x, up = (n & 1) ? pB[n / 2].y : pB[n / 2].x;
                 permlane32_swap(lo, up); // lane l: lo = the lower half's partial of ITS rollout, up = the upper half's
                 const float y = (lo + up) + b3v[n];
-                vel[n] = vel[n] + (y * ysd[n] + ymn[n]);
+                velp[n >> 1][n & 1] = velp[n >> 1][n & 1] + (y * ysd[n] + ymn[n]);
             }
         };
 
@@ -1190,27 +1208,54 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                 const int t = 4 * g + tl;
                 if (t < H) { // (wave-uniform)
                     MPPI_PCT(t, 0, 0); // step start
-                    float u[A], e[A], v[A];
+                    // noise, v = u + eps, action cost — on pairs (v_pk_*_f32: the wave a step waits for is alone on its SIMD's vector pipe for
+                    // most of it, and a lone wave issues a packed instruction in the time of a plain one). Same operations per element, same order of the sums.
+                    f32x2 u2[A / 2], e2[A / 2], v2[A / 2];
                     if (SRC == SRC_PHILOX) {
-                        float z1[A];
+                        if constexpr (DIAG) {
 #pragma unroll
-                        for (int i = 0; i < A; ++i) z1[i] = z[tl * A + i];
-                        scale_noise<A, DIAG>(&pcst, z1, e);
+                            for (int q = 0; q < A / 2; ++q) e2[q] = sg2[q] * f32x2{z[tl * A + 2 * q], z[tl * A + 2 * q + 1]};
+                        } else {
+                            float z1[A], e1[A];
+#pragma unroll
+                            for (int i = 0; i < A; ++i) z1[i] = z[tl * A + i];
+                            scale_noise<A, DIAG>(&pcst, z1, e1);
+#pragma unroll
+                            for (int i = 0; i < A; ++i) e2[i >> 1][i & 1] = e1[i];
+                        }
                     } else {
 #pragma unroll
-                        for (int i = 0; i < A; ++i) e[i] = eps_hbm[(size_t)kk * HA + t * A + i];
+                        for (int i = 0; i < A; ++i) e2[i >> 1][i & 1] = eps_hbm[(size_t)kk * HA + t * A + i];
                     }
 #pragma unroll
-                    for (int i = 0; i < A; ++i) { u[i] = U_dev[t * A + i]; v[i] = u[i] + e[i]; }
-                    const float ac = action_cost<A, DIAG>(&pcst, u, e);
+                    for (int i = 0; i < A; ++i) u2[i >> 1][i & 1] = U_dev[t * A + i];
+#pragma unroll
+                    for (int q = 0; q < A / 2; ++q) v2[q] = u2[q] + e2[q];
+                    float ac;
+                    if (ac_packed) {
+                        f32x2 pr[A / 2];
+#pragma unroll
+                        for (int q = 0; q < A / 2; ++q) pr[q] = u2[q] * (si2[q] * e2[q]);
+                        float mix = pr[0][0];
+#pragma unroll
+                        for (int i = 1; i < A; ++i) mix = mix + pr[i >> 1][i & 1];
+                        ac = pcst.lambda * mix;
+                    } else {
+                        float u[A], e[A];
+#pragma unroll
+                        for (int i = 0; i < A; ++i) { u[i] = u2[i >> 1][i & 1]; e[i] = e2[i >> 1][i & 1]; }
+                        ac = action_cost<A, DIAG>(&pcst, u, e);
+                    }
                     MPPI_PCT(t, 0, 1); // noise, action cost done
                     // inputs (prepare_data, nn_model.py:438-461): Euler angles (from P), body velocities, forces; input 15 = zero padding
                     float in[NIN + 1];
+                    if constexpr (!MF16) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) in[i] = eu_s[pair][t & 1][i][lane];
+                        for (int i = 0; i < 3; ++i) in[i] = eu_s[pair][t & 1][i][lane];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) { in[3 + i] = vel[i]; in[9 + i] = v[i]; }
-                    in[NIN] = 0.0f;
+                        for (int i = 0; i < 6; ++i) { in[3 + i] = velp[i >> 1][i & 1]; in[9 + i] = v2[i >> 1][i & 1]; }
+                        in[NIN] = 0.0f;
+                    }
                     if constexpr ((MPPI_PC_ABL & 1) != 0) { // (timing study, tools/ablate.py pc_*: no network)
                     } else if constexpr (MF16) {
                         // B operands of the four 16-rollout column blocks: per k step a 4 x 4 transpose of 16-lane rows across four registers
@@ -1218,11 +1263,15 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                         auto relu16 = [](float v) { return __int_as_float(max(__float_as_int(v), 0)); }; // ONE v_max_i32: a float below zero (and -0) is a negative int; fmaxf costs a canonicalising v_max_f32 first, and so does a v_med3_f32 hipcc recognises
                         f32x4 acc[4];
                         MPPI_PCT(t, 0, 2); // inputs read
+                        f32x2 in2[8]; // the 16 input slots in pairs
+                        in2[0] = f32x2{eu_s[pair][t & 1][0][lane], eu_s[pair][t & 1][1][lane]};
+                        in2[1] = f32x2{eu_s[pair][t & 1][2][lane], 0.0f};
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) { in2[2 + q] = velp[q]; in2[5 + q] = v2[q]; }
 #pragma unroll
                         for (int s1 = 0; s1 < 4; ++s1) {
-                            float xq[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) xq[q] = (in[4 * s1 + q] - xm[4 * s1 + q]) * xr[4 * s1 + q];
+                            const f32x2 x01 = (in2[2 * s1] - xm2[2 * s1]) * xr2[2 * s1], x23 = (in2[2 * s1 + 1] - xm2[2 * s1 + 1]) * xr2[2 * s1 + 1];
+                            float xq[4] = {x01[0], x01[1], x23[0], x23[1]};
                             permlane32_swap(xq[0], xq[2]);
                             permlane32_swap(xq[1], xq[3]);
                             permlane16_swap(xq[0], xq[1]);
@@ -1247,24 +1296,31 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                         // output layer: the lane's four units of each column block, then the sum over the four lane groups, transposed back to
                         // lane = rollout (two swap levels: the butterfly of the input transpose run backwards)
                         MPPI_PCT(t, 0, 3); // the three layers issued
-                        float part[4][NOUT];
+                        f32x2 part[4][NOUT / 2];
 #pragma unroll
                         for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const float hv = relu16(acc[c4][i]);
+                                const f32x2 h2 = {hv, hv};
 #pragma unroll
-                                for (int o = 0; o < NOUT; ++o) part[c4][o] = i == 0 ? hv * w3q[i][o] : fmaf(hv, w3q[i][o], part[c4][o]);
+                                for (int o = 0; o < NOUT / 2; ++o) part[c4][o] = i == 0 ? h2 * w3q[i][o] : __builtin_elementwise_fma(h2, w3q[i][o], part[c4][o]);
                             }
 #pragma unroll
-                        for (int o = 0; o < NOUT; ++o) {
-                            float p0 = part[0][o], p1 = part[1][o], p2 = part[2][o], p3 = part[3][o];
-                            permlane32_swap(p0, p2); // p0 = [c0 g0, c0 g1, c2 g0, c2 g1], p2 = [c0 g2, c0 g3, c2 g2, c2 g3]
-                            permlane32_swap(p1, p3);
-                            float s02 = p0 + p2, s13 = p1 + p3; // rows: (c0: g0+g2, c0: g1+g3, c2: .., c2: ..) and the same of c1 / c3
-                            permlane16_swap(s02, s13);           // s02 = [c0, c1, c2, c3] (g0+g2), s13 = [c0, c1, c2, c3] (g1+g3)
-                            const float y = (s02 + s13) + b3v[o];
-                            vel[o] = vel[o] + (y * ysd[o] + ymn[o]);
+                        for (int o2 = 0; o2 < NOUT / 2; ++o2) {
+                            f32x2 ys;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                float p0 = part[0][o2][e], p1 = part[1][o2][e], p2 = part[2][o2][e], p3 = part[3][o2][e];
+                                permlane32_swap(p0, p2); // p0 = [c0 g0, c0 g1, c2 g0, c2 g1], p2 = [c0 g2, c0 g3, c2 g2, c2 g3]
+                                permlane32_swap(p1, p3);
+                                float s02 = p0 + p2, s13 = p1 + p3; // rows: (c0: g0+g2, c0: g1+g3, c2: .., c2: ..) and the same of c1 / c3
+                                permlane16_swap(s02, s13);           // s02 = [c0, c1, c2, c3] (g0+g2), s13 = [c0, c1, c2, c3] (g1+g3)
+                                ys[e] = s02 + s13;
+                            }
+                            const f32x2 y = ys + b3p[o2];
+                            const f32x2 dl = y * ysdp[o2]; // (two roundings: the compile is -ffp-contract=off, and so was the unpacked form)
+                            velp[o2] = velp[o2] + (dl + ymnp[o2]);
                         }
                     } else {
                     float ba[K1H], bb[K1H];
@@ -1293,7 +1349,7 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                     }
                     MPPI_PCT(t, 0, 4); // network, output layer, velocities done
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) vel_s[pair][t & 1][i][lane] = vel[i];
+                    for (int i = 0; i < 6; ++i) vel_s[pair][t & 1][i][lane] = velp[i >> 1][i & 1];
                     vel_s[pair][t & 1][6][lane] = ac;
                     MPPI_PCT(t, 0, 5); // at the barrier
                     __syncthreads(); // step t handed over

@@ -68,12 +68,17 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
         continue
     wl = os.path.basename(wdir)
     stats = {}
-    sfiles = glob.glob(os.path.join(wdir, "stats", "*", "*kernel_stats.csv"))
+    # a re-collection merges its files beside an earlier one's (one <pid>_ prefix per run): the newest of a directory is the one that counts
+    sfiles = sorted(glob.glob(os.path.join(wdir, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if sfiles:
-        shutil.copy(sfiles[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, wl)))
-        stats = stats_of(sfiles[0])
+        shutil.copy(sfiles[-1], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, wl)))
+        stats = stats_of(sfiles[-1])
     summary = collections.defaultdict(dict)
-    for f in glob.glob(os.path.join(wdir, "pmc_*", "*", "*counter_collection.csv")):
+    for pdir in sorted(glob.glob(os.path.join(wdir, "pmc_*"))):
+        pfiles = sorted(glob.glob(os.path.join(pdir, "*", "*counter_collection.csv")), key=os.path.getmtime)
+        if not pfiles:
+            continue
+        f = pfiles[-1]
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -84,19 +89,23 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
             for c, v in cs.items():
                 summary[name][c] = sum(v) / len(v)
                 summary[name]["launches_" + c] = len(v)
-    out = {"tag": tag, "workload": wl, "code_sha": code_sha, "kernels": summary, "kernel_stats": stats}
+    out = {"tag": tag, "workload": wl, "kernels": summary, "kernel_stats": stats}
     b = os.path.join(wdir, "bench_under_profiler.json")
+    wl_sha = code_sha
     if os.path.exists(b) and os.path.getsize(b):
         try:
             out["bench_line_under_profiler"] = json.loads(open(b).read())
+            # the kernel sources the profiled run itself executed (bench.py's roofline.code_sha), not the ones in the tree now
+            wl_sha = out["bench_line_under_profiler"].get("roofline", {}).get("code_sha", code_sha)
         except ValueError:
             pass
+    out["code_sha"] = wl_sha
     json.dump(out, open(os.path.join(dst, "%s_%s_pmc_summary.json" % (tag, wl)), "w"), indent=1, sort_keys=True)
 
     for kname, k in summary.items():
         if "k_rollout" not in kname and "k_step" not in kname:
             continue
-        rec = {"code_sha": code_sha, "tag": "%s_%s" % (tag, wl), "stats": stats.get(kname)}
+        rec = {"code_sha": wl_sha, "tag": "%s_%s" % (tag, wl), "stats": stats.get(kname)}
         if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
             rec["traffic"] = {"FETCH_SIZE_KiB_raw": k["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": k["WRITE_SIZE"],
                               "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
