@@ -1016,6 +1016,39 @@ __global__ __launch_bounds__(kNnauv32Threads) void k_rollout_nnspeed32(
                                 base, partials + (size_t)record_slot(blockIdx.x, rsc) * rsb, rsc);
 }
 
+// ---- hand-off between the two waves of a tile WITHOUT a workgroup barrier (r05). A slot is [N values + 1 tag][64 lanes]; lane l of the writer
+// serves lane l of the reader (lane = rollout in both waves). Writer: the values, then the tag (the step the values belong to) — the LDS
+// instructions of one wave execute in order, so a reader that sees the tag sees the values. Reader: the tag, then the values, in one batch
+// (in order again: values read behind a fresh tag are fresh); the whole wave repeats the batch until every lane's tag is the expected one.
+// Against s_barrier: the writer does not wait for its stores to land (no s_waitcnt before a barrier), the two tiles of a workgroup no longer
+// wait for each other, and the wave that is ahead sleeps in 64-cycle naps instead of holding a barrier slot. Every spin is bounded
+// (a wave that never sees its tag returns false; the caller poisons its cost with a NaN, which no test lets pass).
+constexpr int kHandoffSpins = 1 << 18;
+template <int N>
+__device__ __forceinline__ void handoff_put(float *slot, const float (&v)[N], const int tag)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) slot[i * 64] = v[i];
+    asm volatile("" ::: "memory"); // the tag's store stays behind the values' in the instruction stream
+    slot[N * 64] = __int_as_float(tag);
+    asm volatile("" ::: "memory");
+}
+template <int N>
+__device__ __forceinline__ bool handoff_get(const float *slot, float (&v)[N], const int tag)
+{
+#pragma nounroll
+    for (int spin = 0; spin < kHandoffSpins; ++spin) {
+        asm volatile("" ::: "memory");
+        const int got = __float_as_int(slot[N * 64]);
+        asm volatile("" ::: "memory"); // the values' loads stay behind the tag's
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = slot[i * 64];
+        if (__builtin_amdgcn_ballot_w64(got != tag) == 0ull) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
 // k_rollout_nnspeed_pc<HID>: NNAUVModelSpeed as a two-wave pipeline per 64-rollout tile (r04). In k_rollout_nnspeed32 a wave is 32
 // rollouts whose per-rollout vector work — Euler angles, quaternion kinematics, the 13-term cost, the noise: ~650 instructions a step —
 // runs on 64 lanes for 32 results, and the f32 MFMA does not overlap with it. The model itself offers the split: next_state integrates
@@ -1053,8 +1086,8 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float w3_s[HID * W3LD]; // output-layer rows [unit][6 outputs + 2 zeros]
-    __shared__ float eu_s[2][2][3][64];   // [tile of the workgroup][step parity][angle][rollout]            P -> N
-    __shared__ float vel_s[2][2][7][64];  // [tile][step parity][6 velocities of the NEXT state, action cost][rollout]   N -> P
+    __shared__ float eu_s[2][2][4][64];   // [tile of the workgroup][step parity][3 angles, tag][rollout]            P -> N   (handoff_put / _get)
+    __shared__ float vel_s[2][2][8][64];  // [tile][step parity][6 velocities of the NEXT state, action cost, tag][rollout]   N -> P
     __shared__ float cost_s[2][64];
     __shared__ int simd_s[4];
     MPPI_PCT_DECL(); // (timing study: mppi_ablate.hip.h)
@@ -1171,8 +1204,9 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
         f32x2 velp[3]; // the six velocities, in pairs
 #pragma unroll
         for (int i = 0; i < 6; ++i) velp[i >> 1][i & 1] = x_dev[7 + i];
-        __syncthreads(); // w3_s
-        __syncthreads(); // the Euler angles of x0
+        vel_s[pair][0][7][lane] = 0.0f; vel_s[pair][1][7][lane] = 0.0f; // no step handed over yet (tags)
+        __syncthreads(); // w3_s, tags
+        bool fresh = true; // every hand-off arrived
 
         // output layer of both column blocks + vel' = vel + delta
         auto finish = [&](const f32x16 &hA, const f32x16 &hB) {
@@ -1248,10 +1282,11 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                     }
                     MPPI_PCT(t, 0, 1); // noise, action cost done
                     // inputs (prepare_data, nn_model.py:438-461): Euler angles (from P), body velocities, forces; input 15 = zero padding
-                    float in[NIN + 1];
+                    float in[NIN + 1], eu3[3];
+                    fresh = handoff_get<3>(&eu_s[pair][t & 1][0][lane], eu3, t + 1) && fresh; // Euler angles of pose t (P's step t-1; x0's before the loop)
                     if constexpr (!MF16) {
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) in[i] = eu_s[pair][t & 1][i][lane];
+                        for (int i = 0; i < 3; ++i) in[i] = eu3[i];
 #pragma unroll
                         for (int i = 0; i < 6; ++i) { in[3 + i] = velp[i >> 1][i & 1]; in[9 + i] = v2[i >> 1][i & 1]; }
                         in[NIN] = 0.0f;
@@ -1264,8 +1299,8 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                         f32x4 acc[4];
                         MPPI_PCT(t, 0, 2); // inputs read
                         f32x2 in2[8]; // the 16 input slots in pairs
-                        in2[0] = f32x2{eu_s[pair][t & 1][0][lane], eu_s[pair][t & 1][1][lane]};
-                        in2[1] = f32x2{eu_s[pair][t & 1][2][lane], 0.0f};
+                        in2[0] = f32x2{eu3[0], eu3[1]};
+                        in2[1] = f32x2{eu3[2], 0.0f};
 #pragma unroll
                         for (int q = 0; q < 3; ++q) { in2[2 + q] = velp[q]; in2[5 + q] = v2[q]; }
 #pragma unroll
@@ -1348,12 +1383,12 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                     }
                     }
                     MPPI_PCT(t, 0, 4); // network, output layer, velocities done
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) vel_s[pair][t & 1][i][lane] = velp[i >> 1][i & 1];
-                    vel_s[pair][t & 1][6][lane] = ac;
-                    MPPI_PCT(t, 0, 5); // at the barrier
-                    __syncthreads(); // step t handed over
-                    MPPI_PCT(t, 0, 6); // through the barrier
+                    {
+                        const float out7[7] = {velp[0][0], velp[0][1], velp[1][0], velp[1][1], velp[2][0], velp[2][1], fresh ? ac : __builtin_nanf("")};
+                        handoff_put<7>(&vel_s[pair][t & 1][0][lane], out7, t + 1); // step t handed over
+                    }
+                    MPPI_PCT(t, 0, 5); // handed over
+                    MPPI_PCT(t, 0, 6);
                 }
             }
         }
@@ -1372,18 +1407,20 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
             const float q4[4] = {x[3], x[4], x[5], x[6]};
             float eu[3];
             euler_from_quat(q4, eu);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) eu_s[pair][0][i][lane] = eu[i];
+            eu_s[pair][1][3][lane] = 0.0f; // (tag: nothing there yet)
+            handoff_put<3>(&eu_s[pair][0][0][lane], eu, 1);
         }
-        __syncthreads(); // w3_s
-        __syncthreads(); // the Euler angles of x0
+        __syncthreads(); // w3_s, tags
+        bool fresh = true;
         const float zero6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         for (int t = 0; t < H; ++t) {
             MPPI_PCT(t, 1, 0); // step start
             if (t >= 1) { // the state step t-1 produced: its pose is here, its velocities and the step's action cost come from N
+                float in7[7];
+                fresh = handoff_get<7>(&vel_s[pair][(t - 1) & 1][0][lane], in7, t) && fresh; // N's step t-1
 #pragma unroll
-                for (int i = 0; i < 6; ++i) x[7 + i] = vel_s[pair][(t - 1) & 1][i][lane];
-                const float ac = vel_s[pair][(t - 1) & 1][6][lane];
+                for (int i = 0; i < 6; ++i) x[7 + i] = in7[i];
+                const float ac = in7[6];
                 const float sc = (MPPI_PC_ABL & 2) ? x[0] : cost_of(x); // cost on the POST-step state
                 const float tmp = sc + ac;   // Step_cost_result cost_base.cpp:49
                 c = c + tmp;                 // path_cost        controller_base.cpp:268
@@ -1396,18 +1433,19 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
                 const float q4[4] = {x[3], x[4], x[5], x[6]};
                 float eu[3];
                 euler_from_quat(q4, eu);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) eu_s[pair][(t + 1) & 1][i][lane] = eu[i];
+                handoff_put<3>(&eu_s[pair][(t + 1) & 1][0][lane], eu, t + 2);
             }
-            MPPI_PCT(t, 1, 5); // Euler angles done: at the barrier
-            __syncthreads(); // step t handed over
-            MPPI_PCT(t, 1, 6); // through the barrier
+            MPPI_PCT(t, 1, 5); // Euler angles done, handed over
+            MPPI_PCT(t, 1, 6);
         }
+        float in7[7];
+        fresh = handoff_get<7>(&vel_s[pair][(H - 1) & 1][0][lane], in7, H) && fresh;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) x[7 + i] = vel_s[pair][(H - 1) & 1][i][lane];
+        for (int i = 0; i < 6; ++i) x[7 + i] = in7[i];
         const float sc = cost_of(x);
-        c = c + (sc + vel_s[pair][(H - 1) & 1][6][lane]);
+        c = c + (sc + in7[6]);
         c = c + sc; // terminal cost: x_H counted a second time, controller_base.cpp:271-272
+        if (!fresh) c = __builtin_nanf(""); // a hand-off that never arrived: visible
         cost_s[pair][lane] = c;
         MPPI_PCT_DUMP(valid, cost + k0 + lane, c);
     }
