@@ -375,7 +375,8 @@ enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instea
        MPPI_TUNE_GEN_ONE_WAVE = 9,
        /* r05 (ABI 5), the point-mass producer/consumer path with the diagonal quadratic cost (mppi_step.hip.h): */
        MPPI_TUNE_FUSED_STEP = 10,       /* default 1: a handle of <= 128 tiles (K <= 8192) runs its Philox step as ONE launch — tiles and the column waves that
-                                         * finish them in one grid, records handed over as {value, sequence} granules; 0: rollout launch + finish launch */
+                                         * finish them in one grid, records handed over as {value, sequence} granules (seven producer waves per tile where H <= 84);
+                                         * 0: rollout launch + finish launch; 2: one launch with the six-wave workgroup (five producers) at every horizon */
        MPPI_TUNE_ARMED_US = 11,         /* default 0 (off). N > 0: once two mppi_next calls have followed each other within N microseconds, a call leaves the NEXT
                                          * step's launch behind it, armed: resident on the GPU, its noise drawn, waiting up to N us for x. The next mppi_next then
                                          * only stores x into device memory (large BAR) and watches the pinned u slot — no launch, no dispatch between x and u.

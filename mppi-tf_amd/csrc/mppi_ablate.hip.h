@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned long long pc_stamp()
     return t;
 }
 #define MPPI_TL_DECL() __shared__ float tl_s[64]; if (threadIdx.x < 64) tl_s[threadIdx.x] = 0.0f; __syncthreads()
-#define MPPI_STAMP_RT(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); if (lane == 0) tl_s[(slot)] = (float)(t_ & 0xFFFFFFull); } while (0)
+#define MPPI_STAMP_RT(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); if (lane == 0 && (slot) < 64) tl_s[(slot)] = (float)(t_ & 0xFFFFFFull); } while (0)
 #define MPPI_STAMP(slot) do { const unsigned long long t_ = pc_stamp(); if (lane == 0) tl_s[(slot)] = (float)(t_ & 0xFFFFFFull); } while (0)
 // where this wave runs: HW_ID[15:0] (wave, simd, pipe, cu, sh, se) and XCC_ID[3:0]; role in slot
 #define MPPI_TL_WHERE(wave) do { if (lane == 0) tl_s[48 + (wave)] = (float)(__builtin_amdgcn_s_getreg((15 << 11) | 4) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16)); } while (0)

@@ -817,7 +817,8 @@ extern "C" mppi_status mppi_rollout_kernel_name(const mppi_handle *h, char *buf,
         else if (h->mlp_bx3) std::snprintf(buf, n, "mppi::k_rollout_mlp_bx3<%d, %s, 0>", h->a, h->sigma_diag ? "true" : "false");
         else std::snprintf(buf, n, "mppi::k_rollout_mlp<%d, %s>", h->a, h->sigma_diag ? "true" : "false");
     else if (fuse_ok(h)) // the whole step in one launch (mppi_step.hip.h)
-        std::snprintf(buf, n, "mppi::k_step_pc<%d, 5, %d, %s, 1>", h->a, NG <= 20 ? 4 : 8, h->sigma_diag ? "true" : "false");
+        if (h->fuse_step != 2 && NG <= 21) std::snprintf(buf, n, "mppi::k_step_pc<%d, 7, 3, %s, 1>", h->a, h->sigma_diag ? "true" : "false");
+        else std::snprintf(buf, n, "mppi::k_step_pc<%d, 5, %d, %s, 1>", h->a, NG <= 20 ? 4 : 8, h->sigma_diag ? "true" : "false");
     else if (pc_eligible(h)) // (normalizeCost: two passes of it on the fused path; injected noise runs the tile kernel)
     {
         const int ck = h->hc.state_cost_kind == MPPI_STATE_COST_ELLIPSE ? 1 : (h->hc.q_full ? 2 : (h->fp_contract ? 3 : 0)); // PC_COST_* (spelled out as the profiler spells it)
@@ -1401,7 +1402,9 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
     if (!h) return MPPI_ERR_INVALID_ARG;
     MPPI_ENTER(h); // (an armed launch was built for the handle as it was)
     switch (what) {
-    case MPPI_TUNE_FUSED_STEP: h->fuse_step = value != 0; break;
+    case MPPI_TUNE_FUSED_STEP:
+        if (value < 0 || value > 2) return fail(h, MPPI_ERR_INVALID_ARG, "fused step: 0 (two launches), 1 (one launch), 2 (one launch, the six-wave workgroup at every horizon)");
+        h->fuse_step = value; break;
     case MPPI_TUNE_ARMED_US:
         if (value < 0 || value > 1000000) return fail(h, MPPI_ERR_INVALID_ARG, "armed launch: soft deadline 0 (off) .. 1000000 us");
         if (value > 0 && !h->d_xslot)

@@ -102,7 +102,7 @@ struct mppi_handle {
     unsigned *d_xchg_dead = nullptr;                             // the same flag in device memory, read by every launch
     float *d_probe_got = nullptr;
     // r05: the whole step in one launch / the armed launch (mppi_step.hip.h, mppi_launch_step.hip)
-    int fuse_step = 1;          // MPPI_TUNE_FUSED_STEP: 1 = a handle of <= 128 tiles runs its device-resident step as ONE launch (0: rollout + finish)
+    int fuse_step = 1;          // MPPI_TUNE_FUSED_STEP: 1 = a handle of <= 128 tiles runs its device-resident step as ONE launch (0: rollout + finish; 2: ONE launch, five producer waves at every horizon)
     int arm_us = 0;             // MPPI_TUNE_ARMED_US: soft deadline of an armed launch in microseconds, 0 = mppi_next never arms
     int arm_always = 0;         // MPPI_TUNE_ARMED_ALWAYS: arm after every mppi_next, whatever the gap between the last two calls was
     unsigned long long *d_step_recs = nullptr; // record granules of the fused step [(2 + HA)][128]

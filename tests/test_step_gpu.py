@@ -71,6 +71,23 @@ def test_fused_step_equals_two_launch_step(m, K, H, a):
     hf.close(); h2.close()
 
 
+@pytest.mark.parametrize("K,H,a", [(4096, 64, 2), (3000, 50, 3), (128, 84, 1), (777, 80, 4), (2048, 33, 2)])
+def test_fused_step_seven_and_five_producers_agree(m, K, H, a):
+    """H <= 84 runs the one-launch step with seven producer waves per tile (k_step_pc<a, 7, 3, ..>), fused_step = 2 keeps five: the
+    same tiles, the same record algebra — the same bits."""
+    c = cfg_of(K, H, a)
+    h7, h5 = m.Handle(**c), m.Handle(tuning={"fused_step": 2}, **c)
+    assert "k_step_pc<%d, 7, 3" % a in h7.rollout_kernel_name() and "k_step_pc<%d, 5," % a in h5.rollout_kernel_name()
+    x = np.zeros(2 * a, F32)
+    for i in range(5):
+        u7, u5 = h7.next(x), h5.next(x)
+        np.testing.assert_array_equal(u7, u5, err_msg="step %d" % i)
+        np.testing.assert_array_equal(h7.debug_get(m.DBG_COSTS), h5.debug_get(m.DBG_COSTS))
+        np.testing.assert_array_equal(h7.get_action_sequence(), h5.get_action_sequence())
+        x = plant(x, u7, a)
+    h7.close(); h5.close()
+
+
 @pytest.mark.parametrize("K,H,a", [(4096, 64, 2), (3000, 50, 3), (128, 32, 1)])
 def test_fused_step_against_oracle(m, K, H, a):
     """BASELINE configs[1], the reference's default K = 3000 / H = 50, configs[0]: the fused step's costs bit-identical to the oracle's on
