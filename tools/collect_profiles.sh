@@ -43,6 +43,7 @@ for SPEC in "$@"; do
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/pmc_write -- $BENCH > $D/pmc_write.log 2>&1;;
   esac
   grep -h '"metric"' $D/*.log | head -1 > $D/bench_under_profiler.json
+  python3 $R/tools/slim_counters.py $D   # only what summarize_profiles.py reads travels back (gpurun merges <= 64 MiB)
 done
 cd $R
 ls $OUT

@@ -26,8 +26,8 @@ for _ in range(5):
     h.next_device(x.data_ptr(), u.data_ptr())
 h.synchronize()
 c = h.debug_get(m.DBG_COSTS).reshape(-1, 64).astype(np.float64)
-NAMES = {0: "N step start", 1: "N noise + action cost done", 2: "N inputs read", 3: "N three layers issued", 4: "N output layer, velocities done", 5: "N at the barrier",
-         6: "N through the barrier", 8: "P step start", 9: "P cost done", 10: "P pose done", 13: "P Euler angles done: at the barrier", 14: "P through the barrier"}
+NAMES = {0: "N step start", 1: "N noise + action cost done", 2: "N inputs read", 3: "N three layers issued", 4: "N output layer, velocities done", 5: "N step handed over (r04: at the barrier)",
+         6: "N after the hand-over (r04: through the barrier)", 8: "P step start", 9: "P cost done", 10: "P pose done", 13: "P Euler angles done, handed over (r04: at the barrier)", 14: "P after the hand-over"}
 for tile in (0, 1, 512, 1023):
     row = c[tile][:32]
     t0 = min(v for v in row if v > 0)
