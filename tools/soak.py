@@ -14,6 +14,7 @@ def mlp(dims, seed=0):
     return dict(W=[(r.uniform(-1, 1, (dims[i], dims[i+1])) / np.sqrt(dims[i]) * (0.1 if i == n-1 else 1)).astype(np.float32) for i in range(n)],
                 b=[(r.uniform(-1, 1, dims[i+1]) / np.sqrt(dims[i]) * (0.1 if i == n-1 else 1)).astype(np.float32) for i in range(n)])
 pm = dict(tau=64, s_dim=6, a_dim=3, dt=0.1, lam=1.0, sigma=0.25*np.eye(3), goal=[1,0,.5,0,.75,0])
+pm2 = dict(tau=64, s_dim=4, a_dim=2, dt=0.1, lam=1.0, sigma=0.25*np.eye(2), goal=[1,0,.5,0])
 at = auv_task(64, learned=True); x13 = np.asarray(at.pop("x0"), np.float32)
 cases = [
  ("pm3d", dict(k=65536, **pm), np.zeros(6, np.float32), 4000),
@@ -38,6 +39,13 @@ cases = [
  ("auv pc ragged", dict(k=200001, **auv_task(64)), x13, 600),
  ("auv pc rk4", dict(k=65536, **dict(auv_task(64), auv=dict(auv_task(64)["auv"], rk=4))), x13, 1000),
  ("auv one wave", dict(k=65536, tuning={"gen_one_wave": 1}, **auv_task(64)), x13, 1000),
+ # r05: the one-launch step (k_step_pc: seven / five producer waves per tile, a long horizon) and the armed host-synchronous loop
+ ("pm2d fused", dict(k=4096, **pm2), np.zeros(4, np.float32), 8000),
+ ("pm2d fused 5 prod", dict(k=4096, tuning={"fused_step": 2}, **pm2), np.zeros(4, np.float32), 4000),
+ ("pm3d fused K3000", dict(k=3000, **dict(pm, tau=50)), np.zeros(6, np.float32), 4000),
+ ("pm3d fused H=120", dict(k=2048, **dict(pm, tau=120)), np.zeros(6, np.float32), 2000),
+ ("pm3d armed sync", dict(k=65536, tuning={"armed_us": 500}, **pm), np.zeros(6, np.float32), 3000),
+ ("pm2d armed sync", dict(k=4096, tuning={"armed_us": 500}, **pm2), np.zeros(4, np.float32), 4000),
 ]
 MULT = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # python tools/soak.py 20: twenty times the steps of every case
 for name, kw, x0, n in cases:
@@ -46,8 +54,15 @@ for name, kw, x0, n in cases:
     h = m.Handle(**kw)
     x = torch.tensor(x0, device="cuda"); u = torch.zeros(kw["a_dim"], device="cuda")
     t0 = time.perf_counter()
-    for i in range(n):
-        h.next_device(x.data_ptr(), u.data_ptr())
+    if "armed" in name:  # the host-synchronous loop: next(x) -> u -> plant, every call arming the next step's launch
+        xh = np.asarray(x0, np.float32).copy()
+        for i in range(n):
+            uh = h.next(xh)
+            xh[0::2] += 0.1 * xh[1::2]; xh[1::2] += 0.1 * uh  # (a crude plant: what matters is a fresh x per call)
+            xh = np.clip(xh, -50, 50)
+    else:
+        for i in range(n):
+            h.next_device(x.data_ptr(), u.data_ptr())
     h.synchronize()
     el = time.perf_counter() - t0
     U = h.get_action_sequence()
