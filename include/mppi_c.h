@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 5 /* 5: MPPI_TUNE_FUSED_STEP / _ARMED_US / _ARMED_ALWAYS (no entry point changed); 4: mppi_shard_step (one call per sharded step, the caller's collectives as function pointers), mppi_learner_save /
+#define MPPI_ABI_VERSION 5 /* 5: MPPI_TUNE_FUSED_STEP / _ARMED_US / _ARMED_ALWAYS / _PRELAUNCH (no entry point changed); 4: mppi_shard_step (one call per sharded step, the caller's collectives as function pointers), mppi_learner_save /
                               _load / _peek, MPPI_TUNE_TRACE (roctx ranges); mppi_set_mlp orders against the last step's stream;
                               3: the 13-state AUV family (MPPI_MODEL_AUV / _NN_AUV, mppi_auv_desc), StaticQuatCost / ElipseCost3D state costs,
                               mppi_auv_pieces, the learner (mppi_learner_*); 2: state_cost_kind / ellipse, transition log, tuning */
@@ -382,7 +382,11 @@ enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instea
                                          * only stores x into device memory (large BAR) and watches the pinned u slot — no launch, no dispatch between x and u.
                                          * While armed the launch occupies the GPU; a launch whose x does not come in time aborts by itself and changes nothing.
                                          * Controls are bit-identical to the unarmed path. MPPI_ERR_UNSUPPORTED without a large-BAR device. */
-       MPPI_TUNE_ARMED_ALWAYS = 12 };   /* 1: arm behind every mppi_next whatever the gap between the last two calls (tests of the deadline path) */    /* 1: the Fossen AUVModel on k_rollout_gen<0> (one wave per 64-rollout tile) instead of k_rollout_auv_pc (pose wave + velocity wave per tile) */
+       MPPI_TUNE_ARMED_ALWAYS = 12,
+       MPPI_TUNE_PRELAUNCH = 13 };      /* default 0. 1: mppi_next_device on the handle's OWN stream (stream = NULL), more than 128 tiles, runs PRE-LAUNCHED: steps alternate
+                                         * between two streams of the handle, the rollout of step n+1 is resident and draws its noise while step n finishes, and takes
+                                         * U' of step n from the finish kernel as {value, tag} granules. x_dev must be complete when the call is made and stay
+                                         * unchanged until the step has run; results are bit-identical to the plain path. Any other entry point drains both streams. */   /* 1: arm behind every mppi_next whatever the gap between the last two calls (tests of the deadline path) */    /* 1: the Fossen AUVModel on k_rollout_gen<0> (one wave per 64-rollout tile) instead of k_rollout_auv_pc (pose wave + velocity wave per tile) */
 mppi_status mppi_set_tuning(mppi_handle *h, int what, int value);
 
 /* ---- measurement (the reference only has a commented-out chrono loop, main.cpp:55-64) ------ */

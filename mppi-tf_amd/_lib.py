@@ -22,7 +22,7 @@ DBG_COSTS, DBG_BETA, DBG_ETA, DBG_WEIGHTS, DBG_NOISE, DBG_U_UPDATED, DBG_AUX = r
 CSV_REFERENCE, CSV_ROUNDTRIP = 0, 1
 # mppi_set_tuning items (diagnostics; the library reads no environment variable)
 TUNING = {"force_tile_kernel": 0, "pc_producers": 1, "pc_balance": 2, "pc_lds_min": 3, "sync_spin": 4, "p2p_fault": 5, "mlp_v1": 6, "mlp32_valu": 7,
-          "trace": 8, "gen_one_wave": 9, "fused_step": 10, "armed_us": 11, "armed_always": 12}
+          "trace": 8, "gen_one_wave": 9, "fused_step": 10, "armed_us": 11, "armed_always": 12, "prelaunch": 13}
 P2P_FAULTS = {"": 0, "export": 1, "probe": 2}
 
 FP = C.POINTER(C.c_float)

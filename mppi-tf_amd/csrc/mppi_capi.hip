@@ -104,8 +104,24 @@ static inline void xslot_store(mppi_handle *h, int i, float v, unsigned tag)
 // An armed launch nobody is going to feed (any entry point other than mppi_next, a handle that changes, destroy): the host's cancel
 // tag makes tile 0 abort at its next poll; every wave follows, the update is not applied, the stream drains. U, u and the Philox step
 // counter are exactly what they were before the launch was armed.
+// ... and the pre-launched pipeline (MPPI_TUNE_PRELAUNCH): steps are in flight on both streams; once both have drained, the plain U buffers,
+// the step counter and u are what the plain path would have left. A sequence that never came (hard deadline) is in the sticky error word.
+static hipError_t pre_quiesce(mppi_handle *h)
+{
+    if (!h->pre_active) return hipSuccess;
+    h->pre_active = false;
+    if (hipError_t e = hipStreamSynchronize(h->stream); e != hipSuccess) return e;
+    if (hipError_t e = hipStreamSynchronize(h->stream2); e != hipSuccess) return e;
+    if (h->h_arm && reinterpret_cast<volatile unsigned *>(h->h_arm + 1)[0] != 0u) {
+        reinterpret_cast<volatile unsigned *>(h->h_arm + 1)[0] = 0u;
+        h->err = "a pre-launched step never received its sequence (hard deadline): the controls since are invalid";
+        return hipErrorLaunchTimeOut;
+    }
+    return hipSuccess;
+}
 static hipError_t quiesce(mppi_handle *h)
 {
+    if (hipError_t e = pre_quiesce(h); e != hipSuccess) return e;
     if (!h->arm_inflight) return hipSuccess;
     xslot_store(h, 0, 0.0f, h->arm_seq | mppi::kArmCancelBit);
     store_fence();
@@ -201,6 +217,11 @@ extern "C" void mppi_destroy(mppi_handle *h)
     (void)quiesce(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->pre_ev) (void)hipEventDestroy(h->pre_ev);
+    if (h->pre_ev2) (void)hipEventDestroy(h->pre_ev2);
+    if (h->d_ugr) (void)hipFree(h->d_ugr);
+    if (h->d_cu_ctr) (void)hipFree(h->d_cu_ctr);
     if (h->d_step_recs) (void)hipFree(h->d_step_recs);
     if (h->d_xslot) (void)hipFree(h->d_xslot);
     if (h->d_decision) (void)hipFree(h->d_decision);
@@ -560,7 +581,8 @@ static hipError_t launch_mlp(mppi_handle *h, hipStream_t st, int src, int mode, 
 // Combine nb records (element (b,col) at recs[b*sb + col*sc]) and, if apply, update: U' = U_in + V/eta -> U_out,
 // u_out = U'[0]. More than 1024 records are first folded 16:1 (k_combine_group) into row-major scratch.
 static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *recs, int sb, int sc, int nb,
-                                const float *U_in, float *U_out, float *u_out, float *record_out, int apply, bool xchg = false, unsigned armed_seq = 0)
+                                const float *U_in, float *U_out, float *u_out, float *record_out, int apply, bool xchg = false, unsigned armed_seq = 0,
+                                const FinishPre pre = FinishPre{nullptr, nullptr, 0u, 0ull})
 {
     // a profiled step = the rollout kernel + the finish that applies the update
     TraceRange tr(h, apply ? "mppi:finish" : "mppi:record");
@@ -584,7 +606,7 @@ static hipError_t launch_finish(mppi_handle *h, hipStream_t st, const float *rec
     else
         hipExtLaunchKernelGGL(k_finish_cols, dim3(h->HA), dim3(kThreads), 0, st, f0, f1, 0, recs, sb, sc, nb, h->HA, h->a, h->hc.neg_inv_lambda,
                               U_in, U_out, u_out, record_out, apply, h->d_step, h->d_dbg, (const float *)h->d_clip, nil_dev,
-                              armed_seq ? (const unsigned long long *)h->d_decision : (const unsigned long long *)nullptr, armed_seq);
+                              armed_seq ? (const unsigned long long *)h->d_decision : (const unsigned long long *)nullptr, armed_seq, pre);
     hipError_t e = hipGetLastError();
     if (prof && e == hipSuccess) { h->prof_stream = st; h->prof_n++; }
     return e;
@@ -934,10 +956,88 @@ static mppi_status arm_launch(mppi_handle *h, const float *U_in, float *U_out, u
     return MPPI_OK;
 }
 
+// The pre-launched pipelined step (MPPI_TUNE_PRELAUNCH; k_step_pc<.., STEP_PRE> + k_finish_cols with FinishPre). Step n goes to stream
+// n & 1 of the handle: its rollout is eligible as soon as the finish of step n-2 (the launch before it on that stream) is done, i.e. while
+// step n-1 still runs on the other stream; it draws its noise in the CU slots step n-1's workgroups leave and waits for step n-1's U' as
+// granules. Order that keeps the two grids from competing for slots: step n-1's workgroups are all resident long before step n becomes
+// eligible (that takes the finish of n-2, which takes the END of rollout n-2, whose slots rollout n-1 — eligible since finish n-3 — has
+// taken). Start-up has no such history and builds it with two events: rollout 2 (second stream) behind rollout 1 — it would otherwise share
+// the chip with it —, and rollout 3 (first stream, behind finish 1) behind the moment the second stream got PAST that wait: rollout 2 is
+// the next packet of its queue then, and rollout 3 sees the event through the same cross-queue latency that rollout 2 has already paid
+// (measured without it: rollout 3 became resident first, held every slot waiting for finish 2, and rollout 2 never ran — the deadline).
+// (one round of the grid: a rollout with workgroups still undispatched while the NEXT step's waiting workgroups hold the slots would never finish)
+static int pre_slots(const mppi_handle *h)
+{
+    const int NG = (h->H + 3) / 4;
+    const int per_cu = h->pc_np == 3 ? (NG <= 18 && 6 * 4 * h->a <= 80 ? 4 : 2) : 3; // k_step_pc's __launch_bounds__
+    return per_cu * h->n_cu;
+}
+static bool pre_shape_ok(const mppi_handle *h) { return step_shape_ok(h) && h->nb > 128 && h->nb <= pre_slots(h) && h->d_arm != nullptr; }
+static bool pre_ok(const mppi_handle *h) { return h->prelaunch && pre_shape_ok(h) && !fuse_ok(h); }
+
+static mppi_status pre_step(mppi_handle *h, const float *x_dev, float *u_dev)
+{
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->arm_inflight) HIP_TRY(h, quiesce(h));
+    if (!h->pre_active) { // enter: everything enqueued so far drains; the sequence as it stands becomes the first granules, the step counter the mirror
+        if (!h->stream2) HIP_TRY(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        if (!h->pre_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->pre_ev, hipEventDisableTiming));
+        if (!h->pre_ev2) HIP_TRY(h, hipEventCreateWithFlags(&h->pre_ev2, hipEventDisableTiming));
+        if (!h->d_ugr) HIP_TRY(h, hipMalloc((void **)&h->d_ugr, sizeof(unsigned long long) * 2 * (size_t)h->HA));
+        if (!h->d_cu_ctr) {
+            HIP_TRY(h, hipMalloc((void **)&h->d_cu_ctr, sizeof(int) * 4096));
+            HIP_TRY(h, hipMemset(h->d_cu_ctr, 0, sizeof(int) * 4096));
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream2));
+        std::vector<float> U(h->HA);
+        unsigned long long step = 0;
+        HIP_TRY(h, hipMemcpy(U.data(), h->U_cur(), sizeof(float) * h->HA, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(&step, h->d_step, sizeof(step), hipMemcpyDeviceToHost));
+        const unsigned tag = h->next_seq();
+        std::vector<unsigned long long> g(2 * (size_t)h->HA, 0ull);
+        for (int i = 0; i < h->HA; ++i) {
+            uint32_t bits;
+            std::memcpy(&bits, &U[i], 4);
+            g[i] = ((unsigned long long)tag << 32) | bits;
+        }
+        HIP_TRY(h, hipMemcpy(h->d_ugr, g.data(), sizeof(unsigned long long) * g.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, ensure_record_layout(h, h->stream, h->nb));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->pre_buf = 0; h->pre_tag = tag; h->pre_step = step; h->pre_count = 0; h->pre_active = true;
+    }
+    hipStream_t st = (h->pre_count & 1ull) ? h->stream2 : h->stream;
+    if (h->pre_count == 1) HIP_TRY(h, hipEventRecord(h->pre_ev2, h->stream2)); // (behind the wait for rollout 1, in front of rollout 2)
+    const unsigned seq = h->next_seq();
+    const unsigned long long *ugr_in = h->d_ugr + (size_t)h->pre_buf * h->HA;
+    unsigned long long *ugr_out = h->d_ugr + (size_t)(1 - h->pre_buf) * h->HA;
+    {
+        TraceRange tr(h, "mppi:rollout");
+        const bool prof = h->prof_n < h->prof_cap;
+        h->kev0 = prof ? h->ev[4 * h->prof_n + 0] : nullptr;
+        h->kev1 = prof ? h->ev[4 * h->prof_n + 1] : nullptr;
+        mppi_step_launch L{STEP_PRE, x_dev, h->U_cur(), h->U_other(), u_dev, seq};
+        L.ugr = ugr_in; L.utag = h->pre_tag; L.step_index = h->pre_step;
+        const hipError_t e = launch_step(h, st, &L);
+        h->kev0 = h->kev1 = nullptr;
+        HIP_TRY(h, e);
+    }
+    if (h->pre_count == 0) HIP_TRY(h, hipEventRecord(h->pre_ev, st)); // (start-up: see above)
+    h->norm_two_pass = 0;
+    HIP_TRY(h, launch_finish(h, st, h->d_part, 1, h->nbp, h->nbp, h->U_cur(), h->U_other(), u_dev, nullptr, 1, false, 0,
+                             FinishPre{ugr_in, ugr_out, seq, h->pre_step}));
+    if (h->pre_count == 0) HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->pre_ev, 0));
+    if (h->pre_count == 1) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->pre_ev2, 0)); // rollout 3 behind the second stream's release
+    h->U_advance(); // (no sequence filter on this path: step_shape_ok)
+    h->pre_buf = 1 - h->pre_buf; h->pre_tag = seq; h->pre_step += 1ull; h->pre_count += 1ull;
+    return MPPI_OK;
+}
+
 extern "C" mppi_status mppi_next_device(mppi_handle *h, const float *x_dev, float *u_dev, void *stream)
 {
     if (!h || !x_dev || !u_dev) return h ? fail(h, MPPI_ERR_INVALID_ARG, "NULL device pointer") : MPPI_ERR_INVALID_ARG;
     if (h->shard_count != 1) return fail(h, MPPI_ERR_INVALID_ARG, "sharded handle: use mppi_shard_partial / mppi_shard_finish");
+    if (stream == nullptr && pre_ok(h)) return pre_step(h, x_dev, u_dev);
     MPPI_ENTER(h);
     TraceRange step_range(h, "mppi:step");
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
@@ -1411,6 +1511,10 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
             return fail(h, MPPI_ERR_UNSUPPORTED, "armed launches need the point-mass producer/consumer path and a large-BAR system (the host stores x straight into device memory)");
         h->arm_us = value; break;
     case MPPI_TUNE_ARMED_ALWAYS: h->arm_always = value != 0; break;
+    case MPPI_TUNE_PRELAUNCH:
+        if (value != 0 && !pre_shape_ok(h))
+            return fail(h, MPPI_ERR_UNSUPPORTED, "the pre-launched step serves the point-mass producer/consumer path with the diagonal quadratic cost, more than 128 tiles and at most one round of the grid, one shard");
+        h->prelaunch = value != 0; break;
     case MPPI_TUNE_FORCE_TILE_KERNEL: h->force_tile = value != 0; break;
     case MPPI_TUNE_PC_PRODUCERS:
         if (value != 3 && value != 5) return fail(h, MPPI_ERR_INVALID_ARG, "producer waves per workgroup: 3 or 5");

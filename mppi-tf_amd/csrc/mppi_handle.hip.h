@@ -113,6 +113,17 @@ struct mppi_handle {
     bool arm_inflight = false;  // an armed launch of sequence number arm_seq sits in the stream, waiting for x
     unsigned arm_seq = 0;
     long long last_next_ns = 0; // steady-clock time of the previous mppi_next (the arming rule looks at the gap)
+    // the pre-launched pipelined step (MPPI_TUNE_PRELAUNCH; k_step_pc<.., STEP_PRE>): steps alternate between `stream` and `stream2`
+    int prelaunch = 0;            // tuning: mppi_next_device on the handle's own stream pre-launches (0: off)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t pre_ev = nullptr, pre_ev2 = nullptr; // start-up order (pre_step, mppi_capi.hip)
+    unsigned long long *d_ugr = nullptr; // [2][HA] sequence granules {value, tag}
+    int *d_cu_ctr = nullptr;             // [4096] workgroup arrivals per CU (role placement of a pre-launched grid)
+    bool pre_active = false;      // steps are in flight on both streams; the plain U buffers / step counter are valid again after pre_quiesce
+    int pre_buf = 0;              // which half of d_ugr holds the sequence the NEXT launch reads
+    unsigned pre_tag = 0;         // ... and its tag
+    unsigned long long pre_step = 0; // host mirror of the Philox step counter
+    unsigned long long pre_count = 0; // launches since the mode was entered (parity = stream)
     unsigned next_seq() { step_seq = (step_seq + 1u) & 0x7fffffffu; if (step_seq == 0u) step_seq = 1u; return step_seq; }
     size_t xchg_step_slots() const { return (size_t)2 * HA * shard_count * 3; }
     size_t xchg_inbox_bytes() const { return sizeof(unsigned long long) * (xchg_step_slots() + (size_t)2 * shard_count); }
@@ -137,7 +148,10 @@ MPPI_DECL_A(mppi_launch_pc_a, MPPI_PC_PARAMS)
 MPPI_DECL_A(mppi_launch_mlp_a, MPPI_MLP_PARAMS)
 // one launch of k_step_pc (mppi_step.hip.h): mode = STEP_FUSE | STEP_ARM bits; the sequence it reads / writes is given explicitly
 // (an armed launch for step n+1 is enqueued before step n's bookkeeping is committed)
-struct mppi_step_launch { int mode; const float *x_dev, *U_in; float *U_out, *u_out; unsigned seq; };
+struct mppi_step_launch {
+    int mode; const float *x_dev, *U_in; float *U_out, *u_out; unsigned seq;
+    const unsigned long long *ugr = nullptr; unsigned utag = 0; unsigned long long step_index = 0; // STEP_PRE: this step's sequence as granules, their tag, the Philox step index
+};
 #define MPPI_STEP_PARAMS mppi_handle *h, hipStream_t st, const mppi_step_launch *L
 MPPI_DECL_A(mppi_launch_step_a, MPPI_STEP_PARAMS)
 #undef MPPI_DECL_A

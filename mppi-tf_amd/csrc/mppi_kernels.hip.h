@@ -596,11 +596,23 @@ __device__ __forceinline__ void column_combine(Load ld, int nb, float neg_inv_la
 }
 
 #if defined(MPPI_UNIT_CAPI) // non-template kernel: defined in ONE translation unit (mppi_capi.hip)
+// Behind a PRE-LAUNCHED rollout (k_step_pc<.., STEP_PRE>, mppi_step.hip.h): the sequence travels between the steps as 8-byte {value, tag}
+// granules — the finish of step n reads U from granules `in` (complete: its rollout waited for every one of them), writes the SHIFTED U' as
+// granules `out` tagged `tag` (what step n+1's rollout, already resident on the other stream, is polling for) beside the plain U_out, and
+// takes the Philox step counter from the host's mirror (`step`): nothing it reads was written by a kernel of the other stream as plain stores.
+struct FinishPre {
+    const unsigned long long *in;
+    unsigned long long *out;
+    unsigned tag;
+    unsigned long long step;
+};
+
 __global__ __launch_bounds__(kThreads) void k_finish_cols(
-    const float *__restrict__ recs, int sb, int sc, int nb, int /*HA*/, int a, float neg_inv_lambda,
+    const float *__restrict__ recs, int sb, int sc, int nb, int HA, int a, float neg_inv_lambda,
     const float *__restrict__ U_in, float *__restrict__ U_out, float *__restrict__ u_out,
     float *__restrict__ record_out, int apply, unsigned long long *__restrict__ step_ctr, float *__restrict__ dbg,
-    const float *__restrict__ clip, const float *__restrict__ nil_dev, const unsigned long long *__restrict__ verdict, unsigned seq)
+    const float *__restrict__ clip, const float *__restrict__ nil_dev, const unsigned long long *__restrict__ verdict, unsigned seq,
+    const FinishPre pre)
 {
     __shared__ float red_f[kThreads / 64];
     __shared__ double red_d[2][kThreads / 64];
@@ -609,8 +621,9 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols(
     // an aborted launch leaves U, u and the step counter as they were
     if (verdict != nullptr && verdict[0] != (((unsigned long long)seq << 32) | 1ull)) return;
     if (nil_dev != nullptr) neg_inv_lambda = nil_dev[0]; // two-pass normalizeCost: the temperature of this step (k_cost_minmax)
-    const float u_old = U_in[c];
-    const unsigned long long step_old = step_ctr[0];
+    if (pre.in != nullptr) __builtin_amdgcn_s_setprio(3); // (the next step's rollout is resident around these waves, drawing noise — and waiting for them)
+    const float u_old = pre.in != nullptr ? __uint_as_float((unsigned)__hip_atomic_load(pre.in + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : U_in[c];
+    const unsigned long long step_old = pre.in != nullptr ? pre.step : step_ctr[0];
     float lo = -INFINITY, hi = INFINITY; // clip_act (controller_base.py:500-504): [a_min | a_max], NULL = off
     if (clip != nullptr) { lo = clip[c % a]; hi = clip[a + c % a]; }
     float beta;
@@ -628,6 +641,11 @@ __global__ __launch_bounds__(kThreads) void k_finish_cols(
             U_out[c] = un;            // U' ; the next step reads U_out + a (the shifted sequence)
             if (c < a) u_out[c] = un; // mGetNew
             if (c == 0) step_ctr[0] = step_old + 1ull;
+            if (pre.out != nullptr) { // the shifted sequence as granules: column c is row c - a of the next step, the last a rows are zero (mShift / mInit0)
+                const int dst = c >= a ? c - a : HA - a + c;
+                const float val = c >= a ? un : 0.0f;
+                __hip_atomic_store(pre.out + dst, ((unsigned long long)pre.tag << 32) | (unsigned long long)__float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }

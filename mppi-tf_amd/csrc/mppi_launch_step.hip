@@ -9,9 +9,9 @@
 template <int A, int NP, int NSLOT, int MODE>
 static hipError_t launch_step_inst(mppi_handle *h, hipStream_t st, const mppi_step_launch *L)
 {
-    constexpr bool FUSE = (MODE & STEP_FUSE) != 0, ARM = (MODE & STEP_ARM) != 0;
+    constexpr bool FUSE = (MODE & STEP_FUSE) != 0, ARM = (MODE & STEP_ARM) != 0, PRE = (MODE & STEP_PRE) != 0;
     constexpr int NW = NP + 1;
-    const size_t lds = std::max(pc_lds_floats(A, NP) * 4 + (ARM ? sizeof(float) * (size_t)h->HA : 0), (size_t)h->pc_lds_min);
+    const size_t lds = std::max(pc_lds_floats(A, NP) * 4 + ((ARM || PRE) ? sizeof(float) * (size_t)h->HA : 0), (size_t)h->pc_lds_min);
     const int nb = (h->K_local + 63) / 64;
     const int ncw = FUSE ? (h->HA + NW - 1) / NW : 0;
     const dim3 g(nb + ncw), b(64 * NW);
@@ -25,6 +25,8 @@ static hipError_t launch_step_inst(mppi_handle *h, hipStream_t st, const mppi_st
     sa.hard_ticks = sa.soft_ticks + 50ll * 100000ll;        // + 50 ms: nothing in this kernel ever spins longer
     sa.U_in = L->U_in; sa.U_out = L->U_out; sa.u_out = L->u_out; sa.step_ctr = h->d_step; sa.dbg = h->d_dbg; sa.clip = h->d_clip;
     sa.neg_inv_lambda = h->hc.neg_inv_lambda; sa.a = h->a; sa.HA = h->HA;
+    sa.ugr = L->ugr; sa.utag = L->utag; sa.step_index = L->step_index; sa.cu_ctr = h->d_cu_ctr;
+    if (PRE) sa.hard_ticks = 20ll * 100000ll; // 20 ms: a sequence that has not come by then never will (sticky error word)
     const DevConsts *dC = h->dC;
     const unsigned long long *stp = h->d_step;
     const void *fn = h->sigma_diag ? reinterpret_cast<const void *>(k_step_pc<A, NP, NSLOT, true, MODE>) : reinterpret_cast<const void *>(k_step_pc<A, NP, NSLOT, false, MODE>);
@@ -47,6 +49,10 @@ hipError_t MPPI_CAT(mppi_launch_step_a, MPPI_UNIT_A)(MPPI_STEP_PARAMS)
         // configs[1], 8.37 -> 8.18 at K = 3000 / H = 50 (r05). H <= 84; MPPI_TUNE_FUSED_STEP = 2 keeps the six-wave workgroup.
         if (h->fuse_step != 2 && NG <= 21) return launch_step_inst<AA, 7, 3, STEP_FUSE>(h, st, L);
         return small ? launch_step_inst<AA, 5, 4, STEP_FUSE>(h, st, L) : launch_step_inst<AA, 5, 8, STEP_FUSE>(h, st, L);
+    }
+    if (L->mode & STEP_PRE) { // the pre-launched pipelined step: more than 128 tiles (below, the fused step is one launch already)
+        if (h->pc_np == 3) return NG <= 18 ? launch_step_inst<AA, 3, 6, STEP_PRE>(h, st, L) : launch_step_inst<AA, 3, 11, STEP_PRE>(h, st, L);
+        return NG <= 20 ? launch_step_inst<AA, 5, 4, STEP_PRE>(h, st, L) : launch_step_inst<AA, 5, 8, STEP_PRE>(h, st, L);
     }
     if (!(L->mode & STEP_ARM)) return hipErrorInvalidValue; // (the plain rollout is k_rollout_pc)
     if (h->pc_np == 3) return NG <= 18 ? launch_step_inst<AA, 3, 6, STEP_ARM>(h, st, L) : launch_step_inst<AA, 3, 11, STEP_ARM>(h, st, L);

@@ -20,13 +20,21 @@
 //   slot as soon as it is complete but gives up only on tile 0's abort (or a hard deadline, which raises a sticky error): a late x that
 //   races with the abort makes some tiles roll out for nothing, never a half-applied step — the column waves / the finish kernel apply
 //   the update only under tile 0's accept. Every spin has a wall-clock bound: a silent host is a timeout, never a hang.
+// STEP_PRE  (second session of r05) the PRE-LAUNCHED pipelined step: the launch of step n+1 goes to the handle's SECOND stream while step n
+//   still runs on the first. Its workgroups take the CU slots step n's workgroups leave, the producers draw the whole horizon's noise —
+//   half of a step's priced cycles, and the only part that does not depend on step n — and the consumer wave waits for the sequence U' of
+//   step n, which k_finish_cols publishes as {value, tag} granules (FinishPre, mppi_kernels.hip.h); then the chunks are published from
+//   registers + U and the recurrence runs as in k_rollout_pc. What it hides: the two dependent dispatches of a step (tools/two_controllers.py:
+//   independent controllers fill them — 18.2 -> 14.2 us per step). The finish kernel fits beside four resident rollout workgroups on a CU
+//   (104 x 4 + 32 of 512 VGPRs), so a waiting grid cannot starve it; the wait is bounded by the hard deadline (sticky error word) like
+//   every other spin here. Records go out as plain floats for k_finish_cols; the Philox step index comes from the host's mirror.
 #pragma once
 #include "mppi_kernels.hip.h"
 
 namespace mppi {
 
 typedef unsigned long long u64;
-enum { STEP_FUSE = 1, STEP_ARM = 2 };
+enum { STEP_FUSE = 1, STEP_ARM = 2, STEP_PRE = 4 };
 constexpr unsigned kArmAccept = 1u, kArmAbort = 2u, kArmCancelBit = 0x80000000u; // tags are 31-bit launch sequence numbers; bit 31 = the host's cancel
 
 struct StepArgs {
@@ -46,6 +54,11 @@ struct StepArgs {
     const float *clip;
     float neg_inv_lambda;
     int a, HA;
+    // PRE: the sequence of THIS step as granules [HA] (written by the previous step's finish, tag utag); the Philox step index
+    const u64 *ugr;
+    unsigned utag;
+    unsigned long long step_index;
+    int *cu_ctr;             // PRE: arrivals per CU [4096] (key: XCC_ID << 8 | HW_ID's se, sh, cu), never reset
 };
 
 __device__ __forceinline__ void gr_store(u64 *p, float v, unsigned seq)
@@ -90,6 +103,42 @@ __device__ __forceinline__ bool arm_wait(const StepArgs &sa, bool decider, int l
 #pragma unroll
     for (int i = 0; i < S; ++i) x[i] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)xbits, i));
     return go;
+}
+
+#ifndef MPPI_PRE_NOWAIT
+#define MPPI_PRE_NOWAIT 0 // (timing study, tools/build_unit_variant.py: 1 = take whatever the granules hold — what the wait itself costs)
+#endif
+// The consumer wave of a pre-launched tile waits for the sequence: lane 0 watches ONE granule (the last row's: any would do — every tile
+// then sweeps them all) with a sleep, then the wave sweeps the HA granules (lane l: l, l + 64, ...) until every tag is this step's and parks
+// the values in LDS. -> false: the hard deadline passed (sticky error word; the tile exits without a record).
+__device__ __forceinline__ bool pre_wait(const StepArgs &sa, int lane, float *U_s)
+{
+    const long long t0 = wall_clock64();
+    const int HA = sa.HA;
+    for (unsigned it = 0;; ++it) {
+        u64 g = 0ull;
+        if (lane == 0) g = gr_load(sa.ugr + (HA - 1));
+        if ((unsigned)__builtin_amdgcn_readfirstlane((int)(g >> 32)) == sa.utag || MPPI_PRE_NOWAIT) break;
+        if ((it & 7u) == 7u && wall_clock64() - t0 > sa.hard_ticks) {
+            if (lane == 0) __hip_atomic_store(sa.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    for (unsigned it = 0;; ++it) {
+        bool ok = true;
+        for (int i = lane; i < HA; i += 64) {
+            const u64 g = gr_load(sa.ugr + i);
+            ok = ok && (unsigned)(g >> 32) == sa.utag;
+            U_s[i] = __uint_as_float((unsigned)g);
+        }
+        if (wave_all(ok) || MPPI_PRE_NOWAIT) return true;
+        if ((it & 7u) == 7u && wall_clock64() - t0 > sa.hard_ticks) {
+            if (lane == 0) __hip_atomic_store(sa.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
 }
 
 // One wavefront = one horizon-action column c of the fused step: (beta, eta, V_c) over the nbp = 128 record slots in k_finish_cols'
@@ -195,7 +244,8 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 
     const unsigned long long *__restrict__ step_ctr, float *__restrict__ cost, float *__restrict__ partials,
     const int rsb, const int rsc, const int balance, const StepArgs sa)
 {
-    constexpr bool FUSE = (MODE & STEP_FUSE) != 0, ARM = (MODE & STEP_ARM) != 0;
+    constexpr bool FUSE = (MODE & STEP_FUSE) != 0, ARM = (MODE & STEP_ARM) != 0, PRE = (MODE & STEP_PRE) != 0;
+    static_assert(!PRE || (!FUSE && !ARM), "a pre-launched step is neither fused nor armed");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 2 * A;
     constexpr int NW = NP + 1;
@@ -222,11 +272,23 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 
     float *buf = smem;
     float *w_s = smem;
     MPPI_TL_DECL(); // (timing-study builds only, mppi_ablate.hip.h: slots 0..9 the consumer, 10 + 8 p + {0 start, 1..4 chunk published, 5 weights, 6 stored} producer p; 100 MHz stamps)
-    float *U_s = smem + 2 * CH; // ARM: the nominal sequence [H A]
-    __shared__ int go_s;        // ARM: -1 no x yet, 1 x is here (set by the consumer the moment it sees it), 0 the step is off
+    float *U_s = smem + 2 * CH; // ARM, PRE: the nominal sequence [H A]
+    __shared__ int go_s;        // ARM: -1 no x yet, 1 x is here (set by the consumer the moment it sees it), 0 the step is off; PRE: 1 the sequence is here, 0 off
 
     // role placement: as k_rollout_pc (SIMD-true consumer when the 4 waves sit on 4 SIMDs; speed only)
-    const int gen = (int)(blockIdx.x >> 8);
+    int gen = (int)(blockIdx.x >> 8);
+    if constexpr (PRE) {
+        // A pre-launched grid takes the slots the previous step's workgroups leave, in whatever order they leave them: blockIdx says nothing
+        // about which workgroups share a CU (with gen = blockIdx >> 8 a CU got up to four consumers on ONE SIMD: 25.7 us per step). The CU
+        // counts its arrivals instead: consecutive arrivals take consecutive roles, whichever step they belong to.
+        __shared__ int slot_s;
+        if (tid == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            slot_s = atomicAdd(sa.cu_ctr + ((((hw >> 8) & 0xffu) | ((xcc & 0xfu) << 8)) & 4095u), 1);
+        }
+        __syncthreads();
+        gen = (int)((unsigned)slot_s % (unsigned)(NW == 4 ? 4 : 3));
+    }
     int wave = (wave_hw + NW - gen % NW) % NW;
     if (NW == 4 && balance) {
         __shared__ int simd_s[4];
@@ -244,6 +306,10 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 
         if constexpr (FUSE) gr_store(sa.recs + (size_t)col * sa.nbp + slot_b, v, sa.seq);
         else partials[(size_t)slot_b * rsb + (size_t)col * rsc] = v;
     };
+    if constexpr (PRE) {
+        if (tid == 0) go_s = -1;
+        __syncthreads();
+    }
     if constexpr (ARM) { // the nominal sequence into LDS while nothing else can be done (scalar loads after x arrives would sit on the critical path)
         for (int i = tid; i < H * A; i += 64 * NW) U_s[i] = U_dev[i];
         if (tid == 0) go_s = -1;
@@ -254,7 +320,7 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 
         // ------------------------------------------------------------------ producers
         const int p = wave - 1;
         const unsigned int gk = (unsigned int)C->k_offset + (unsigned int)(k0 + lane);
-        const unsigned long long base = step_ctr[0] * (unsigned long long)NG;
+        const unsigned long long base = (PRE ? sa.step_index : step_ctr[0]) * (unsigned long long)NG; // (PRE: step n-1's finish has not run yet — the host's mirror)
         const unsigned long long seed = C->seed;
         float eps_r[NREG];
         PcProducerConsts<A> pcst;
@@ -309,7 +375,38 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 
                 }
             }
         };
-        if constexpr (!ARM) {
+        if constexpr (PRE) {
+            // what does not need the sequence: the horizon's noise into registers, group by group for as long as the sequence has not come
+            // (this launch became resident when the previous step's workgroups retired: what it draws now, it draws while that step's finish
+            // runs); then the consumer's word (B_go), and from there k_rollout_pc's order — the groups not drawn yet are drawn in front of
+            // their chunk, while the consumer is already at work on the earlier ones. The consumer's barrier count is k_rollout_pc's.
+            int drawn = 0; // slots [0, drawn) hold their noise
+            static_for<0, NSLOT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if (drawn == i && *static_cast<volatile int *>(&go_s) < 0) { draw(ic); drawn = i + 1; }
+            });
+            __syncthreads(); // B_go: the sequence is in U_s (or the step is off)
+            if (*static_cast<volatile int *>(&go_s) <= 0) return;
+            static_for<0, NSLOT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const int g = NP * i + p;
+                if (balance) pc_set_prio(i, nch, gen, balance);
+                if (i >= drawn) draw(ic); // (also the zeros of a group beyond the horizon: phase C sums every register)
+                if (i < nch) {
+                    if (g < NG) {
+                        float ug[4][A];
+#pragma unroll
+                        for (int tl = 0; tl < 4; ++tl) {
+                            const int tt = min(4 * g + tl, H - 1);
+#pragma unroll
+                            for (int j = 0; j < A; ++j) ug[tl][j] = U_s[tt * A + j];
+                        }
+                        publish(ic, ug);
+                    }
+                    __syncthreads(); // chunk i published
+                }
+            });
+        } else if constexpr (!ARM) {
             // k_rollout_pc's order: per horizon group the nominal actions (scalar loads, hidden behind the Philox rounds), the noise, the slots
             static_for<0, NSLOT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -402,6 +499,14 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 
             if (lane == 0) *static_cast<volatile int *>(&go_s) = go ? 1 : 0; // (the producers look at it between two groups of noise)
             __syncthreads(); // B_go
             if (!go) return;
+        } else if constexpr (PRE) {
+            const bool go = pre_wait(sa, lane, U_s);
+            if (lane == 0) *static_cast<volatile int *>(&go_s) = go ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < S; ++i) x[i] = x_dev[i];
+            __syncthreads(); // B_go
+            if (!go) return;
+            __syncthreads(); // chunk 0 published
         } else {
             MPPI_STAMP_RT(0);
             MPPI_STAMP(60); // (shader-clock stamps 60 / 61 against the 100 MHz stamps 0 / 9: the clock the tile really ran at)

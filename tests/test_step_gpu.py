@@ -291,3 +291,95 @@ def test_contracted_instance_against_fp64(m, K, H, a):
         U = h.get_action_sequence()
         x = plant(x, u, a)
     h.close()
+
+
+# ---------------------------------------------------------------------------------------- the pre-launched pipelined step (MPPI_TUNE_PRELAUNCH)
+def device_steps(h, x, n, a):
+    """n pipelined steps on the handle's OWN stream (stream = None: the only place the pre-launched path serves), then drain"""
+    import torch
+    xd = torch.tensor(np.asarray(x, F32), device="cuda")
+    ud = torch.zeros(a, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(n):
+        h.next_device(xd.data_ptr(), ud.data_ptr(), None)
+    h.synchronize()
+    torch.cuda.synchronize()
+    return ud.cpu().numpy()
+
+
+PRE_SHAPES = [(65536, 64, 3), (16384, 64, 3), (8256, 32, 2), (40000, 50, 3), (30000, 100, 1), (65536, 72, 2), (20000, 17, 4), (9000, 64, 2)]
+
+
+@pytest.mark.parametrize("K,H,a", PRE_SHAPES)
+def test_prelaunched_step_equals_plain_step(m, K, H, a):
+    """Steps alternating between the handle's two streams, each rollout resident before the previous step's U' exists and fed with it as
+    granules: controls, U', costs, beta, eta and the step counter are the plain two-launch step's bits — after 1, 2, 3 steps (the start-up
+    order), after many, and again after the pipeline has drained and is entered anew."""
+    c = cfg_of(K, H, a)
+    hp, h0 = m.Handle(tuning={"prelaunch": 1}, **c), m.Handle(**c)
+    x = (np.arange(2 * a) % 3 - 1).astype(F32) * F32(0.1)
+    total = 0
+    for n in (1, 2, 3, 9, 40):
+        up, u0 = device_steps(hp, x, n, a), device_steps(h0, x, n, a)
+        total += n
+        np.testing.assert_array_equal(up, u0, err_msg="after %d steps" % total)
+        np.testing.assert_array_equal(hp.get_action_sequence(), h0.get_action_sequence())
+        np.testing.assert_array_equal(hp.debug_get(m.DBG_COSTS), h0.debug_get(m.DBG_COSTS))
+        assert float(hp.debug_get(m.DBG_BETA)) == float(h0.debug_get(m.DBG_BETA)) and float(hp.debug_get(m.DBG_ETA)) == float(h0.debug_get(m.DBG_ETA))
+        assert hp.get_step_counter() == h0.get_step_counter() == total
+    hp.close(); h0.close()
+
+
+def test_prelaunched_step_against_the_oracle(m):
+    """The pre-launched step's sample costs against the oracle's on the noise the step drew: bit for bit; U' within 1e-5."""
+    K, H, a = 9000, 20, 3
+    c = cfg_of(K, H, a)
+    h = m.Handle(tuning={"prelaunch": 1}, **c)
+    p = orc.Problem(tau=H, s=2 * a, a=a, dt=0.1, mass=1.0, lam=1.0, sigma=c["sigma"], goal=c["goal"], Q=c["Q"])
+    x = np.array([0.1, 0, -0.2, 0, 0.3, 0], F32)
+    for step in range(3):
+        U = h.get_action_sequence().reshape(H, a).copy()
+        device_steps(h, x, 1, a)
+        eps = h.debug_get(m.DBG_NOISE)  # the noise the last step used
+        np.testing.assert_allclose(eps, orc.noise(1, step, 0, K, H, a, c["sigma"]), rtol=0, atol=5e-6)
+        u_ref, U_ref, c_ref = p.next_with_noise(x, U, eps)
+        np.testing.assert_array_equal(h.debug_get(m.DBG_COSTS), c_ref)
+        np.testing.assert_allclose(h.get_action_sequence().reshape(H, a), U_ref, rtol=0, atol=U_TOL)  # (the shifted sequence, as the oracle returns it)
+    h.close()
+
+
+def test_prelaunched_step_mixes_with_every_other_entry_point(m):
+    """Any other entry point drains both streams first: host-synchronous steps, injected noise, a new goal, a new sequence between
+    pre-launched steps give what the same calls give on a plain handle."""
+    K, H, a = 20000, 32, 3
+    c = cfg_of(K, H, a)
+    hp, h0 = m.Handle(tuning={"prelaunch": 1}, **c), m.Handle(**c)
+    x = np.array([0.2, 0, -0.1, 0, 0.0, 0.1], F32)
+    rng = np.random.default_rng(0)
+    for h in (hp, h0):
+        device_steps(h, x, 3, a)
+        h.next(x)
+        device_steps(h, x, 2, a)
+        h.set_goal(np.array([0.5, 0, 0.5, 0, 0.5, 0], F32))
+        device_steps(h, x, 2, a)
+        h.set_action_sequence(np.full((H, a), 0.05, F32))
+        device_steps(h, x, 4, a)
+    np.testing.assert_array_equal(hp.get_action_sequence(), h0.get_action_sequence())
+    np.testing.assert_array_equal(hp.debug_get(m.DBG_COSTS), h0.debug_get(m.DBG_COSTS))
+    assert hp.get_step_counter() == h0.get_step_counter() == 12
+    eps = (0.25 * rng.standard_normal((K, H, a))).astype(F32)
+    np.testing.assert_array_equal(hp.next_with_noise(x, eps), h0.next_with_noise(x, eps))
+    hp.close(); h0.close()
+
+
+def test_prelaunch_is_refused_where_it_does_not_apply(m):
+    """<= 128 tiles run the fused one-launch step; more than one round of the grid would let a waiting grid starve the running one."""
+    for K, H, a in ((4096, 64, 2), (300000, 64, 3)):
+        h = m.Handle(**cfg_of(K, H, a))
+        with pytest.raises(m.MppiError):
+            h.set_tuning("prelaunch", 1)
+        h.close()
+    h = m.Handle(normalize_cost=True, **cfg_of(65536, 64, 3))
+    with pytest.raises(m.MppiError):
+        h.set_tuning("prelaunch", 1)
+    h.close()
