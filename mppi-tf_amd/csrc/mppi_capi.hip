@@ -972,8 +972,8 @@ static int pre_slots(const mppi_handle *h)
     const int per_cu = h->pc_np == 3 ? (NG <= 18 && 6 * 4 * h->a <= 80 ? 4 : 2) : 3; // k_step_pc's __launch_bounds__
     return per_cu * h->n_cu;
 }
-static bool pre_shape_ok(const mppi_handle *h) { return step_shape_ok(h) && h->nb > 128 && h->nb <= pre_slots(h) && h->d_arm != nullptr; }
-static bool pre_ok(const mppi_handle *h) { return h->prelaunch && pre_shape_ok(h) && !fuse_ok(h); }
+static bool pre_shape_ok(const mppi_handle *h) { return step_shape_ok(h) && (fuse_ok(h) || (h->nb > 128 && h->nb <= pre_slots(h))) && h->d_arm != nullptr; }
+static bool pre_ok(const mppi_handle *h) { return h->prelaunch && pre_shape_ok(h); }
 
 static mppi_status pre_step(mppi_handle *h, const float *x_dev, float *u_dev)
 {
@@ -1002,7 +1002,7 @@ static mppi_status pre_step(mppi_handle *h, const float *x_dev, float *u_dev)
             g[i] = ((unsigned long long)tag << 32) | bits;
         }
         HIP_TRY(h, hipMemcpy(h->d_ugr, g.data(), sizeof(unsigned long long) * g.size(), hipMemcpyHostToDevice));
-        HIP_TRY(h, ensure_record_layout(h, h->stream, h->nb));
+        if (!fuse_ok(h)) HIP_TRY(h, ensure_record_layout(h, h->stream, h->nb));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->pre_buf = 0; h->pre_tag = tag; h->pre_step = step; h->pre_count = 0; h->pre_active = true;
     }
@@ -1011,21 +1011,29 @@ static mppi_status pre_step(mppi_handle *h, const float *x_dev, float *u_dev)
     const unsigned seq = h->next_seq();
     const unsigned long long *ugr_in = h->d_ugr + (size_t)h->pre_buf * h->HA;
     unsigned long long *ugr_out = h->d_ugr + (size_t)(1 - h->pre_buf) * h->HA;
+    const bool fused = fuse_ok(h); // <= 128 tiles: the column waves of the same grid finish the step (and write the next step's granules)
     {
         TraceRange tr(h, "mppi:rollout");
         const bool prof = h->prof_n < h->prof_cap;
         h->kev0 = prof ? h->ev[4 * h->prof_n + 0] : nullptr;
         h->kev1 = prof ? h->ev[4 * h->prof_n + 1] : nullptr;
-        mppi_step_launch L{STEP_PRE, x_dev, h->U_cur(), h->U_other(), u_dev, seq};
-        L.ugr = ugr_in; L.utag = h->pre_tag; L.step_index = h->pre_step;
+        mppi_step_launch L{STEP_PRE | (fused ? STEP_FUSE : 0), x_dev, h->U_cur(), h->U_other(), u_dev, seq};
+        L.ugr = ugr_in; L.utag = h->pre_tag; L.step_index = h->pre_step; L.ugr_out = fused ? ugr_out : nullptr;
         const hipError_t e = launch_step(h, st, &L);
         h->kev0 = h->kev1 = nullptr;
         HIP_TRY(h, e);
     }
     if (h->pre_count == 0) HIP_TRY(h, hipEventRecord(h->pre_ev, st)); // (start-up: see above)
     h->norm_two_pass = 0;
-    HIP_TRY(h, launch_finish(h, st, h->d_part, 1, h->nbp, h->nbp, h->U_cur(), h->U_other(), u_dev, nullptr, 1, false, 0,
-                             FinishPre{ugr_in, ugr_out, seq, h->pre_step}));
+    if (!fused) {
+        HIP_TRY(h, launch_finish(h, st, h->d_part, 1, h->nbp, h->nbp, h->U_cur(), h->U_other(), u_dev, nullptr, 1, false, 0,
+                                 FinishPre{ugr_in, ugr_out, seq, h->pre_step}));
+    } else if (h->prof_n < h->prof_cap) { // (a profiled fused step has no finish launch: an empty interval, as fused_step records it)
+        HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 2], st));
+        HIP_TRY(h, hipEventRecord(h->ev[4 * h->prof_n + 3], st));
+        h->prof_stream = st;
+        h->prof_n++;
+    }
     if (h->pre_count == 0) HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->pre_ev, 0));
     if (h->pre_count == 1) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->pre_ev2, 0)); // rollout 3 behind the second stream's release
     h->U_advance(); // (no sequence filter on this path: step_shape_ok)
@@ -1513,7 +1521,7 @@ extern "C" mppi_status mppi_set_tuning(mppi_handle *h, int what, int value)
     case MPPI_TUNE_ARMED_ALWAYS: h->arm_always = value != 0; break;
     case MPPI_TUNE_PRELAUNCH:
         if (value != 0 && !pre_shape_ok(h))
-            return fail(h, MPPI_ERR_UNSUPPORTED, "the pre-launched step serves the point-mass producer/consumer path with the diagonal quadratic cost, more than 128 tiles and at most one round of the grid, one shard");
+            return fail(h, MPPI_ERR_UNSUPPORTED, "the pre-launched step serves the point-mass producer/consumer path with the diagonal quadratic cost, at most one round of the grid, one shard");
         h->prelaunch = value != 0; break;
     case MPPI_TUNE_FORCE_TILE_KERNEL: h->force_tile = value != 0; break;
     case MPPI_TUNE_PC_PRODUCERS:

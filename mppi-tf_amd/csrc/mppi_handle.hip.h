@@ -151,6 +151,7 @@ MPPI_DECL_A(mppi_launch_mlp_a, MPPI_MLP_PARAMS)
 struct mppi_step_launch {
     int mode; const float *x_dev, *U_in; float *U_out, *u_out; unsigned seq;
     const unsigned long long *ugr = nullptr; unsigned utag = 0; unsigned long long step_index = 0; // STEP_PRE: this step's sequence as granules, their tag, the Philox step index
+    unsigned long long *ugr_out = nullptr; // STEP_PRE | STEP_FUSE: the next step's granules (the column waves write them)
 };
 #define MPPI_STEP_PARAMS mppi_handle *h, hipStream_t st, const mppi_step_launch *L
 MPPI_DECL_A(mppi_launch_step_a, MPPI_STEP_PARAMS)

@@ -25,7 +25,7 @@ static hipError_t launch_step_inst(mppi_handle *h, hipStream_t st, const mppi_st
     sa.hard_ticks = sa.soft_ticks + 50ll * 100000ll;        // + 50 ms: nothing in this kernel ever spins longer
     sa.U_in = L->U_in; sa.U_out = L->U_out; sa.u_out = L->u_out; sa.step_ctr = h->d_step; sa.dbg = h->d_dbg; sa.clip = h->d_clip;
     sa.neg_inv_lambda = h->hc.neg_inv_lambda; sa.a = h->a; sa.HA = h->HA;
-    sa.ugr = L->ugr; sa.utag = L->utag; sa.step_index = L->step_index; sa.cu_ctr = h->d_cu_ctr;
+    sa.ugr = L->ugr; sa.utag = L->utag; sa.step_index = L->step_index; sa.cu_ctr = h->d_cu_ctr; sa.ugr_out = L->ugr_out;
     if (PRE) sa.hard_ticks = 20ll * 100000ll; // 20 ms: a sequence that has not come by then never will (sticky error word)
     const DevConsts *dC = h->dC;
     const unsigned long long *stp = h->d_step;
@@ -43,6 +43,10 @@ hipError_t MPPI_CAT(mppi_launch_step_a, MPPI_UNIT_A)(MPPI_STEP_PARAMS)
     if (L->mode & STEP_FUSE) { // <= 128 tiles: always the 6-wave workgroup
         if (h->pc_np != 5) return hipErrorInvalidValue;
         const bool small = NG <= 20;
+        if (L->mode & STEP_PRE) { // the one-launch step, pre-launched: two grids in flight (they fit side by side: at most 2 x (128 + 33) workgroups)
+            if (h->fuse_step != 2 && NG <= 21) return launch_step_inst<AA, 7, 3, STEP_FUSE | STEP_PRE>(h, st, L);
+            return small ? launch_step_inst<AA, 5, 4, STEP_FUSE | STEP_PRE>(h, st, L) : launch_step_inst<AA, 5, 8, STEP_FUSE | STEP_PRE>(h, st, L);
+        }
         if (L->mode & STEP_ARM) return small ? launch_step_inst<AA, 5, 4, STEP_FUSE | STEP_ARM>(h, st, L) : launch_step_inst<AA, 5, 8, STEP_FUSE | STEP_ARM>(h, st, L);
         // One workgroup per CU and 3/4 of the chip empty: SEVEN producer waves (two waves on every SIMD, chunks of 28 steps) publish the
         // horizon 1.4x sooner than five and the consumer's chain no longer waits for its last chunk — 9.23 -> 8.98 us per step at

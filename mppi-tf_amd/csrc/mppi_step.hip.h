@@ -59,6 +59,7 @@ struct StepArgs {
     unsigned utag;
     unsigned long long step_index;
     int *cu_ctr;             // PRE: arrivals per CU [4096] (key: XCC_ID << 8 | HW_ID's se, sh, cu), never reset
+    u64 *ugr_out;            // PRE + FUSE: where the column waves leave the SHIFTED U' as granules tagged seq (the next step's ugr)
 };
 
 __device__ __forceinline__ void gr_store(u64 *p, float v, unsigned seq)
@@ -148,8 +149,11 @@ __device__ __forceinline__ bool pre_wait(const StepArgs &sa, int lane, float *U_
 __device__ __forceinline__ void step_column(const StepArgs &sa, int c, int lane)
 {
     const int nbp = sa.nbp, nb = sa.nb;
-    const float u_old = sa.U_in[c];
-    const unsigned long long step_old = sa.step_ctr[0];
+    // (pre-launched: the sequence and the step counter as k_finish_cols takes them under FinishPre — nothing here was written by the other stream's grid
+    // as plain stores; the granule is read BELOW, once this grid's tiles have published: they could only after every granule of the sequence had come —
+    // a column wave is resident long before the previous step's column waves have written them)
+    float u_old = sa.ugr != nullptr ? 0.0f : sa.U_in[c];
+    const unsigned long long step_old = sa.ugr != nullptr ? sa.step_index : sa.step_ctr[0];
     float lo = -INFINITY, hi = INFINITY;
     if (sa.clip != nullptr) { lo = sa.clip[c % sa.a]; hi = sa.clip[sa.a + c % sa.a]; }
     const u64 *pb = sa.recs, *pe = sa.recs + nbp, *pv = sa.recs + (size_t)(2 + c) * nbp;
@@ -210,6 +214,7 @@ __device__ __forceinline__ void step_column(const StepArgs &sa, int c, int lane)
         __builtin_amdgcn_s_sleep(2);
     }
     MPPI_COL_STAMP(sa, c, lane, 2);
+    if (sa.ugr != nullptr) u_old = __uint_as_float((unsigned)gr_load(sa.ugr + c));
     const float beta = wave_min(fminf(bb[0], bb[1]));
     double se[2], sv[2];
 #pragma unroll
@@ -231,6 +236,10 @@ __device__ __forceinline__ void step_column(const StepArgs &sa, int c, int lane)
         sa.U_out[c] = un;                // U' ; the next step reads U_out + a (the shifted sequence)
         if (c < sa.a) sa.u_out[c] = un;  // mGetNew
         if (c == 0) sa.step_ctr[0] = step_old + 1ull;
+        if (sa.ugr_out != nullptr) { // column c is row c - a of the next step's sequence, its last a rows are zero (mShift / mInit0)
+            const int dst = c >= sa.a ? c - sa.a : sa.HA - sa.a + c;
+            gr_store(sa.ugr_out + dst, c >= sa.a ? un : 0.0f, sa.seq);
+        }
     }
     MPPI_COL_STAMP(sa, c, lane, 3);
 }
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 
     const int rsb, const int rsc, const int balance, const StepArgs sa)
 {
     constexpr bool FUSE = (MODE & STEP_FUSE) != 0, ARM = (MODE & STEP_ARM) != 0, PRE = (MODE & STEP_PRE) != 0;
-    static_assert(!PRE || (!FUSE && !ARM), "a pre-launched step is neither fused nor armed");
+    static_assert(!PRE || !ARM, "a pre-launched step is not an armed one");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 2 * A;
     constexpr int NW = NP + 1;
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(64 * (NP + 1), ((MODE & STEP_FUSE) ? 2 : NP == 5 ? 
             static_for<0, NSLOT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 const int g = NP * i + p;
-                if (balance) pc_set_prio(i, nch, gen, balance);
+                if (balance && !FUSE) pc_set_prio(i, nch, gen, balance);
                 if (i >= drawn) draw(ic); // (also the zeros of a group beyond the horizon: phase C sums every register)
                 if (i < nch) {
                     if (g < NG) {

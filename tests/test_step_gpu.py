@@ -307,7 +307,8 @@ def device_steps(h, x, n, a):
     return ud.cpu().numpy()
 
 
-PRE_SHAPES = [(65536, 64, 3), (16384, 64, 3), (8256, 32, 2), (40000, 50, 3), (30000, 100, 1), (65536, 72, 2), (20000, 17, 4), (9000, 64, 2)]
+PRE_SHAPES = [(65536, 64, 3), (16384, 64, 3), (8256, 32, 2), (40000, 50, 3), (30000, 100, 1), (65536, 72, 2), (20000, 17, 4), (9000, 64, 2),
+              (4096, 64, 2), (3000, 50, 3), (128, 32, 1), (8192, 64, 3), (777, 100, 4), (64, 4, 2)]  # (the last six: <= 128 tiles, the one-launch step pre-launched)
 
 
 @pytest.mark.parametrize("K,H,a", PRE_SHAPES)
@@ -373,8 +374,8 @@ def test_prelaunched_step_mixes_with_every_other_entry_point(m):
 
 
 def test_prelaunch_is_refused_where_it_does_not_apply(m):
-    """<= 128 tiles run the fused one-launch step; more than one round of the grid would let a waiting grid starve the running one."""
-    for K, H, a in ((4096, 64, 2), (300000, 64, 3)):
+    """More than one round of the grid would let a waiting grid starve the running one; normalizeCost is not the step's one pass."""
+    for K, H, a in ((300000, 64, 3),):
         h = m.Handle(**cfg_of(K, H, a))
         with pytest.raises(m.MppiError):
             h.set_tuning("prelaunch", 1)
