@@ -419,6 +419,40 @@ def sync_latency(m, workload, H, K, mlp, steps=200, warmup=20, think_us=0.0, **h
     return float(np.median(ts)), float(ts[int(0.95 * (len(ts) - 1))])
 
 
+def prelaunched_record(m, workload, H, K, budget_s=0.25):
+    """The PRE-LAUNCHED pipelined step (MPPI_TUNE_PRELAUNCH, opt-in; mppi_capi.hip pre_step): steps alternate between the handle's two
+    own streams, step n+1's rollout is resident and draws its noise while step n finishes. Reported BESIDE the headline, never as it:
+    the state of step n+1 has to be in place before step n's control exists (a throughput mode — x does not wait for u), and the
+    steps do not ride the caller's stream. Same controls bit for bit (tests/test_step_gpu.py). -> {"ms_per_step", "value"} or a note."""
+    import numpy as np
+    import torch
+    a = WORKLOADS[workload][0]
+    try:
+        h = m.Handle(k=K, tuning={"prelaunch": 1}, **cfg_of(workload, H))
+    except Exception as e:
+        return {"unavailable": str(e)[:80]}
+    try:
+        x, u = torch.zeros(2 * a, dtype=torch.float32, device="cuda"), torch.zeros(a, dtype=torch.float32, device="cuda")
+        xp, up = x.data_ptr(), u.data_ptr()
+
+        def batch(n):
+            t0 = time.perf_counter()
+            for _ in range(n):
+                h.next_device(xp, up, None)
+            h.synchronize()
+            return (time.perf_counter() - t0) / n
+        batch(20)  # (a pipeline that cannot form — every wait is bounded at 20 ms — shows here, cheaply: the error surfaces at the drain)
+        batch(300)
+        ws, t0 = [], time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or len(ws) < 5:
+            ws.append(batch(400))
+        assert np.isfinite(u.cpu().numpy()).all()
+        el = float(np.median(ws))
+        return {"ms_per_step": r4(1e3 * el), "value": r4(K / el), "batches": len(ws)}
+    finally:
+        h.close()
+
+
 _kernel_profiles = None
 
 
@@ -823,8 +857,19 @@ def main():
                 out["sub_records"][0]["rank_ms_per_step"] = [r4(q) for q in subs[0]["rank_ms_per_step"]]
         if world == 1:
             out["ms_per_control_step_sync"] = sync_record(m, headline, H, K, r["mlp"], **head_kw)
+            if not is_mlp and headline not in GEN and not head_kw:
+                try:
+                    out["prelaunched"] = dict(prelaunched_record(m, headline, H, K), mode="MPPI_TUNE_PRELAUNCH=1 (opt-in; x of step n+1 in place before u of step n)")
+                except Exception as e:  # an opt-in path's figure must never cost the line
+                    sys.stderr.write("bench.py: pre-launched figure skipped: %s\n" % e)
             for sr, s_ in zip(out.get("sub_records", []), subs):  # configs[1]: the synchronous figure too
                 if s_["workload"] == "pm2d":
+                    try:
+                        q = prelaunched_record(m, "pm2d", s_["H"], s_["K_per_gpu"])
+                        if "ms_per_step" in q:
+                            sr["prelaunched_ms"] = q["ms_per_step"]
+                    except Exception as e:
+                        sys.stderr.write("bench.py: pm2d pre-launched figure skipped: %s\n" % e)
                     try:
                         q = sync_record(m, "pm2d", s_["H"], s_["K_per_gpu"], None)
                         sr["sync_ms"] = {k: q[k] for k in ("median", "p95") if k in q}

@@ -46,6 +46,11 @@ cases = [
  ("pm3d fused H=120", dict(k=2048, **dict(pm, tau=120)), np.zeros(6, np.float32), 2000),
  ("pm3d armed sync", dict(k=65536, tuning={"armed_us": 500}, **pm), np.zeros(6, np.float32), 3000),
  ("pm2d armed sync", dict(k=4096, tuning={"armed_us": 500}, **pm2), np.zeros(4, np.float32), 4000),
+ # r05, second session: the pre-launched pipelined step (two streams, granules for U'), drained and re-entered every 997 steps
+ ("pm3d pre-launched", dict(k=65536, tuning={"prelaunch": 1}, **pm), np.zeros(6, np.float32), 6000),
+ ("pm2d pre-launched", dict(k=4096, tuning={"prelaunch": 1}, **pm2), np.zeros(4, np.float32), 8000),
+ ("pm3d pre K3000", dict(k=3000, tuning={"prelaunch": 1}, **dict(pm, tau=50)), np.zeros(6, np.float32), 4000),
+ ("pm3d pre K16384", dict(k=16384, tuning={"prelaunch": 1}, **pm), np.zeros(6, np.float32), 4000),
 ]
 MULT = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # python tools/soak.py 20: twenty times the steps of every case
 for name, kw, x0, n in cases:
@@ -63,6 +68,7 @@ for name, kw, x0, n in cases:
     else:
         for i in range(n):
             h.next_device(x.data_ptr(), u.data_ptr())
+            if "pre" in name and i % 997 == 996: h.synchronize()
     h.synchronize()
     el = time.perf_counter() - t0
     U = h.get_action_sequence()
