@@ -490,6 +490,32 @@ __device__ __forceinline__ void nnauv_step(const MlpDev *__restrict__ M, const f
 // theta_z), R = Rz Ry Rx; entries "safe-shrunk" by (1 - 4 eps), the gimbal-lock branch for | |r20| - 1 | < 1e-6 (the tests pin the
 // CPU restatement of the same algorithm against scipy's as_euler('xyz')). asinf / atan2f are the device library's.
 __device__ __forceinline__ float nonzero_sign(float v) { return v >= 0.0f ? 1.0f : -1.0f; }
+// atan2 for the pose wave of k_rollout_nnspeed_pc (r05, second session). The device library's atan2f is 43 vector instructions — an IEEE
+// division (12) and the zero / infinity / NaN cases — twice per step and rollout, on the wave that shares its SIMD's vector pipe with the
+// network wave. Here x is never zero (euler_from_quat adds +-eps to it) and nothing is infinite: min/max, v_rcp_f32 (1 ulp), an odd
+// polynomial in explicit fused multiply-adds (fitted on [0, 1], 1.07 ulp over 2e6 fp32 arguments against fp64: the recipe is in DESIGN_HISTORY),
+// the two quadrant folds and the sign: 21 instructions, within 2 ulp of the library's result. NOT used by the kernels whose costs are held
+// bit for bit to the oracle's (the Fossen model has no Euler angles).
+__device__ __forceinline__ float atan2_pose(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = t * t;
+    float p = 0x1.7ed2fap-9f;
+    p = __builtin_fmaf(p, s, -0x1.0c2c96p-6f);
+    p = __builtin_fmaf(p, s, 0x1.61fe5ep-5f);
+    p = __builtin_fmaf(p, s, -0x1.3556fap-4f);
+    p = __builtin_fmaf(p, s, 0x1.b4e15p-4f);
+    p = __builtin_fmaf(p, s, -0x1.230aep-3f);
+    p = __builtin_fmaf(p, s, 0x1.9978f4p-3f);
+    p = __builtin_fmaf(p, s, -0x1.5554dcp-2f);
+    float a = __builtin_fmaf(t * s, p, t);
+    a = ay > ax ? (float)(3.14159265358979323846 / 2.0) - a : a;
+    a = x < 0.0f ? (float)3.14159265358979323846 - a : a;
+    return __builtin_copysignf(a, y);
+}
+template <bool FAST = false>
 __device__ __forceinline__ void euler_from_quat(const float (&q)[4], float (&e)[3])
 {
     constexpr float eps = 2.0f * 1.1920928955078125e-07f, shr = 1.0f - 4.0f * eps;
@@ -515,13 +541,14 @@ __device__ __forceinline__ void euler_from_quat(const float (&q)[4], float (&e)[
     // with it are exact. The cosf it replaces was 117 of this function's 324 vector instructions (full-range argument reduction).
     r00 = nonzero_sign(r00) * eps + r00;
     r22 = nonzero_sign(r22) * eps + r22;
-    e[2] = atan2f(r10, r00);
-    e[0] = atan2f(r21, r22);
+    e[2] = FAST ? atan2_pose(r10, r00) : atan2f(r10, r00);
+    e[0] = FAST ? atan2_pose(r21, r22) : atan2f(r21, r22);
     e[1] = th_y;
 }
 
 // nn_model.py:463-472 next_state: pose' = normalize_quat(pose + J(x) vel dt), vel' = vel + delta; J = [[rot, 0], [0, T]] with THIS class's
 // T rows (:545-555: (-x,-y,-z), (w,-z,y), (z,w,-x), (-y,x,w) — AUVModel's rows rotated by one; the model is the specification)
+template <bool FAST = false> // FAST (the pose wave of k_rollout_nnspeed_pc): the quaternion's 1 / sqrt as ONE v_rsq_f32 (1 ulp) — tf.math.l2_normalize is x * rsqrt(max(sum x^2, eps)) — instead of an IEEE square root and an IEEE division (27 instructions)
 __device__ __forceinline__ void nnauv_speed_next_state(float dt, float (&x)[kGenS], const float (&delta)[6])
 {
     const float q[4] = {x[3], x[4], x[5], x[6]};
@@ -536,7 +563,16 @@ __device__ __forceinline__ void nnauv_speed_next_state(float dt, float (&x)[kGen
     }
 #pragma unroll
     for (int i = 0; i < 7; ++i) x[i] = xn[i];
-    normalize_quat(x);
+    if constexpr (FAST) {
+        float ss = x[3] * x[3];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) ss = ss + x[3 + i] * x[3 + i];
+        const float inv = __builtin_amdgcn_rsqf(ss < 1e-12f ? 1e-12f : ss);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[3 + i] = x[3 + i] * inv;
+    } else {
+        normalize_quat(x);
+    }
 #pragma unroll
     for (int i = 0; i < 6; ++i) x[7 + i] = x[7 + i] + delta[i];
 }
@@ -1068,6 +1104,9 @@ __device__ __forceinline__ bool handoff_get(const float *slot, float (&v)[N], co
 // layer's B operand as it stands (k slot (s, g) = unit 4 g + s: the weights are loaded in that order). Inputs reach the four column blocks by
 // a 4 x 4 transpose of 16-lane rows per k step (2 v_permlane32_swap + 2 v_permlane16_swap), the 6 outputs come back by the same butterfly
 // with sums. Through builtins: with 4-register accumulators hipcc's own allocation and hazard padding are fine (145 VGPRs); the relu on an accumulator is ONE v_max_i32. 0.222 -> 0.188 ms.
+#ifndef MPPI_NNSPEED_POSE_FAST
+#define MPPI_NNSPEED_POSE_FAST 1 // (A/B: tools/build_unit_variant.py -DMPPI_NNSPEED_POSE_FAST=0 = the device library's atan2f and the IEEE 1 / sqrt in the pose wave)
+#endif
 constexpr int kNnspeedPcThreads = 256;
 struct GenQuadConsts { // kernel-local copy of the diagonal quadratic cost (no constant re-fetch behind the per-step barrier)
     float goal[kGenS], qdiag[kGenS];
@@ -1427,12 +1466,12 @@ __global__ __launch_bounds__(kNnspeedPcThreads, 2) void k_rollout_nnspeed_pc(
             }
             MPPI_PCT(t, 1, 1); // cost done
             if constexpr ((MPPI_PC_ABL & 2) == 0) // (timing study: no pose work)
-            nnauv_speed_next_state(dt, x, zero6); // the pose from the OLD velocities (nn_model.py:463-472); x[7..12] + 0 is exact
+            nnauv_speed_next_state<MPPI_NNSPEED_POSE_FAST != 0>(dt, x, zero6); // the pose from the OLD velocities (nn_model.py:463-472); x[7..12] + 0 is exact
             MPPI_PCT(t, 1, 2); // pose done
             if ((MPPI_PC_ABL & 2) == 0 && t + 1 < H) {
                 const float q4[4] = {x[3], x[4], x[5], x[6]};
                 float eu[3];
-                euler_from_quat(q4, eu);
+                euler_from_quat<MPPI_NNSPEED_POSE_FAST != 0>(q4, eu);
                 handoff_put<3>(&eu_s[pair][(t + 1) & 1][0][lane], eu, t + 2);
             }
             MPPI_PCT(t, 1, 5); // Euler angles done, handed over
