@@ -68,6 +68,7 @@ def parse_args():
     ap.add_argument("--fp-contract", action="store_true", help="the contracted instance of the point-mass rollout (MPPI_FLAG_FP_CONTRACT: fused multiply-adds; not bit-identical to the reference's rounding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true")
+    ap.add_argument("--no-prelaunched", action="store_true", help="skip the opt-in pre-launched pipeline's figure (under rocprofv3 --pmc dispatches are serialised: the pipeline cannot form, every step runs into its 20 ms deadline and the figure is skipped anyway)")
     return ap.parse_args()
 
 
@@ -857,13 +858,13 @@ def main():
                 out["sub_records"][0]["rank_ms_per_step"] = [r4(q) for q in subs[0]["rank_ms_per_step"]]
         if world == 1:
             out["ms_per_control_step_sync"] = sync_record(m, headline, H, K, r["mlp"], **head_kw)
-            if not is_mlp and headline not in GEN and not head_kw:
+            if not is_mlp and headline not in GEN and not head_kw and not args.no_prelaunched:
                 try:
                     out["prelaunched"] = dict(prelaunched_record(m, headline, H, K), mode="MPPI_TUNE_PRELAUNCH=1 (opt-in; x of step n+1 in place before u of step n)")
                 except Exception as e:  # an opt-in path's figure must never cost the line
                     sys.stderr.write("bench.py: pre-launched figure skipped: %s\n" % e)
             for sr, s_ in zip(out.get("sub_records", []), subs):  # configs[1]: the synchronous figure too
-                if s_["workload"] == "pm2d":
+                if s_["workload"] == "pm2d" and not args.no_prelaunched:
                     try:
                         q = prelaunched_record(m, "pm2d", s_["H"], s_["K_per_gpu"])
                         if "ms_per_step" in q:

@@ -35,6 +35,12 @@ def test_every_workload_prints_the_contract_line(workload, samples, horizon):
     assert abs(out["value"] - samples / (out["ms_per_step"] * 1e-3)) <= 0.02 * out["value"]
     assert out["config"]["workload"]
     assert out["ms_per_control_step_sync"]["median"] > 0
+    if workload.startswith("pm"):  # the opt-in pre-launched pipeline rides beside the headline (never as it): a figure, or why there is none
+        pre = out["prelaunched"]
+        assert pre.get("ms_per_step", 0) > 0 or "unavailable" in pre, pre
+        assert "prelaunched" not in out["config"]["workload"]
+    else:
+        assert "prelaunched" not in out
 
 
 @pytest.mark.parametrize("workload,extra", [("pm2d", []), ("auv", ["--samples", "4096", "--horizon", "8"]), ("nnspeed", ["--samples", "4096", "--horizon", "8"])])

@@ -24,11 +24,14 @@ for SPEC in "$@"; do
   mkdir -p $D
   STEPS=100
   case $WL in mlp) STEPS=10;; mlp32|nnauv|auv|nnspeed) STEPS=30;; esac
-  BENCH="python3 $R/bench.py --workload $WL $EXTRA --steps $STEPS --warmup 3 --no-cpu-baseline --no-subrecords --min-time 0"
+  BENCH="python3 $R/bench.py --workload $WL $EXTRA --steps $STEPS --warmup 3 --no-cpu-baseline --no-subrecords --no-prelaunched --min-time 0"
   echo "== $NAME: $BENCH"
   # the stats pass times the kernel in steady state: batches repeated for 0.3 s, as bench.py's timed region does (a 100-step run alone is over
   # before the clocks have ramped: 18.1 us for the headline kernel against 15.7-16.0 us here, profiles/r04_philox_ab_rocprofv3.txt)
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- ${BENCH/--min-time 0/--min-time 0.3} > $D/stats.log 2>&1
+  STATS_BENCH=${BENCH/--min-time 0/--min-time 0.3}
+  # (the stats pass keeps the opt-in pre-launched pipeline's figure: under --kernel-trace it forms — k_step_pc<.., 4 | 5> then appear with a duration that INCLUDES their wait
+  # for U'; the counter passes serialise dispatches, the pipeline cannot form there and is left out: --no-prelaunched)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- ${STATS_BENCH/--no-prelaunched /} > $D/stats.log 2>&1
   find $D/stats -name '*kernel_trace.csv' -delete   # tens of thousands of dispatch rows: only the stats summary travels back (gpurun merges <= 64 MiB)
   # VALU instructions by class (the issue-rate floor) and the busy cycles of the issue ports: own passes
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --kernel-trace --output-format csv -d $D/pmc_sq2 -- $BENCH > $D/pmc_sq2.log 2>&1
