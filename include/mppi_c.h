@@ -372,7 +372,7 @@ enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instea
         * the library has no link dependency on it; the call fails with MPPI_ERR_UNSUPPORTED when it cannot be found. Shows in
         * `rocprofv3 --marker-trace`. */
        MPPI_TUNE_TRACE = 8,
-       MPPI_TUNE_GEN_ONE_WAVE = 9,
+       MPPI_TUNE_GEN_ONE_WAVE = 9,      /* 1: the Fossen AUVModel on k_rollout_gen<0> (one wave per 64-rollout tile) instead of k_rollout_auv_pc (pose wave + velocity wave per tile) */
        /* r05 (ABI 5), the point-mass producer/consumer path with the diagonal quadratic cost (mppi_step.hip.h): */
        MPPI_TUNE_FUSED_STEP = 10,       /* default 1: a handle of <= 128 tiles (K <= 8192) runs its Philox step as ONE launch — tiles and the column waves that
                                          * finish them in one grid, records handed over as {value, sequence} granules (seven producer waves per tile where H <= 84);
@@ -382,11 +382,13 @@ enum { MPPI_TUNE_FORCE_TILE_KERNEL = 0, /* 1: the LDS-tile rollout kernel instea
                                          * only stores x into device memory (large BAR) and watches the pinned u slot — no launch, no dispatch between x and u.
                                          * While armed the launch occupies the GPU; a launch whose x does not come in time aborts by itself and changes nothing.
                                          * Controls are bit-identical to the unarmed path. MPPI_ERR_UNSUPPORTED without a large-BAR device. */
-       MPPI_TUNE_ARMED_ALWAYS = 12,
-       MPPI_TUNE_PRELAUNCH = 13 };      /* default 0. 1: mppi_next_device on the handle's OWN stream (stream = NULL), more than 128 tiles, runs PRE-LAUNCHED: steps alternate
+       MPPI_TUNE_ARMED_ALWAYS = 12,     /* 1: arm behind every mppi_next whatever the gap between the last two calls (tests of the deadline path) */
+       MPPI_TUNE_PRELAUNCH = 13 };      /* default 0. 1: mppi_next_device on the handle's OWN stream (stream = NULL) runs PRE-LAUNCHED: steps alternate
                                          * between two streams of the handle, the rollout of step n+1 is resident and draws its noise while step n finishes, and takes
-                                         * U' of step n from the finish kernel as {value, tag} granules. x_dev must be complete when the call is made and stay
-                                         * unchanged until the step has run; results are bit-identical to the plain path. Any other entry point drains both streams. */   /* 1: arm behind every mppi_next whatever the gap between the last two calls (tests of the deadline path) */    /* 1: the Fossen AUVModel on k_rollout_gen<0> (one wave per 64-rollout tile) instead of k_rollout_auv_pc (pose wave + velocity wave per tile) */
+                                         * U' of step n from the finish kernel (<= 128 tiles: from the column waves of step n's one launch) as {value, tag} granules. x_dev must be complete when the call is made and stay
+                                         * unchanged until the step has run — in particular it cannot wait for u of the step before (a throughput mode, not a closed loop);
+                                         * results are bit-identical to the plain path. Any other entry point drains both streams. MPPI_ERR_UNSUPPORTED for a grid of more than
+                                         * one round of the chip. */
 mppi_status mppi_set_tuning(mppi_handle *h, int what, int value);
 
 /* ---- measurement (the reference only has a commented-out chrono loop, main.cpp:55-64) ------ */
