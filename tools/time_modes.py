@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """r05: one shape, every way of running its control step — pipelined (device-resident x) and host-synchronous (mppi_next),
-two launches / one fused launch / armed. Usage: python tools/time_modes.py [K H a] [--steps N]
+two launches / one fused launch / pre-launched / armed. Usage: python tools/time_modes.py [K H a] [--steps N]
 Prints one JSON line per mode (wall per step; kernel time by the launch's own timestamps where profiled)."""
 import json
 import os
@@ -71,6 +71,10 @@ print(json.dumps(out))
 modes = [("two_launches", {"fused_step": 0})] + ([("fused", {"fused_step": 1})] if nb <= 128 else [])
 for name, t in modes:
     print(json.dumps({"pipelined": name, **pipelined(t)}), flush=True)
+try:  # the opt-in pre-launched pipeline (MPPI_TUNE_PRELAUNCH): its kernel_us INCLUDES the wait for U' of the step before
+    print(json.dumps({"pipelined": "pre-launched", **pipelined({"prelaunch": 1})}), flush=True)
+except Exception as e:
+    print(json.dumps({"pipelined": "pre-launched", "error": str(e)[:120]}), flush=True)
 for name, t in modes:
     print(json.dumps({"sync": name, **sync(t)}), flush=True)
     try:
