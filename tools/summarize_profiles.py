@@ -158,4 +158,16 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
         latest["kernels"][kname] = rec
         print("%-50s %-12s stats %s  floor_us %s  mfma_busy %s" % (kname, wl, (rec["stats"] or {}).get("avg_us"), (rec.get("valu") or {}).get("floor_us"),
                                                                   (rec.get("mfma") or {}).get("mfma_busy_frac")))
+    # the pre-launched instances (k_step_pc<.., 4 | 5>, MPPI_TUNE_PRELAUNCH): they run in the --kernel-trace pass only — the counter passes serialise
+    # dispatches, the two-stream pipeline cannot form there and bench.py leaves it out (--no-prelaunched) — so their record is the stats alone
+    for kname, st in stats.items():
+        if "k_step_pc" in kname and kname.rstrip(">").rsplit(", ", 1)[-1] in ("4", "5") and kname not in summary:
+            latest["kernels"][kname] = {"code_sha": wl_sha, "tag": "%s_%s" % (tag, wl), "stats": st,
+                                        "note": "the pre-launched step (MPPI_TUNE_PRELAUNCH, opt-in): the duration INCLUDES the wait for U' of the previous step - resident early is "
+                                                "the point; no counters: rocprofv3 --pmc serialises dispatches and the pipeline cannot form there"}
+            print("%-50s %-12s stats %s  (pre-launched: kernel-trace only)" % (kname, wl, st.get("avg_us")))
+# one source hash per file: entries of earlier sources go (bench.py reads an entry only when its code_sha is the running sources' anyway)
+for kname in [k_ for k_, v_ in latest["kernels"].items() if v_.get("code_sha") != code_sha]:
+    print("dropped (older sources): %s" % kname)
+    del latest["kernels"][kname]
 json.dump(latest, open(latest_path, "w"), indent=1, sort_keys=True)
